@@ -1,0 +1,33 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, 'tests', 'golden', 'inb377_small.npz')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+@pytest.fixture(scope='session')
+def golden():
+    import numpy as np
+    g = np.load(GOLDEN)
+    return {k: g[k] for k in g.files}
+
+
+@pytest.fixture(scope='session')
+def small_setup(golden):
+    """(cfg, state_dict, batch(torch, cpu)) matching the golden file's seeds."""
+    import invr  # noqa: F401
+    from invr import scene, params
+    from invr.config import make_cfg
+    meta = dict(zip(golden['meta_keys'].tolist(), golden['meta_vals'].tolist()))
+    cfg = make_cfg(table_log2=int(meta['table_log2']), N_samples=int(meta['n_samples']))
+    sd = params.init_state_dict(cfg, seed=int(meta['param_seed']))
+    batch_np, extras = scene.make_scene(int(meta['H']), int(meta['W']), seed=int(meta['scene_seed']))
+    return cfg, sd, scene.to_torch(batch_np), extras

@@ -1,0 +1,151 @@
+"""Pin the oracle (oracle/nvr_oracle.py) against vectors produced by the imported reference
+(tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import torch
+
+from oracle import nvr_oracle as O
+from invr import params
+from invr.config import make_cfg, PART_NAMES
+
+TOL = 2e-6
+
+
+def close(a, b, tol=TOL):
+    a = a.detach().numpy() if torch.is_tensor(a) else np.asarray(a)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = float(np.abs(a - b).max()) if a.size else 0.0
+    assert err <= tol, err
+
+
+def test_known_answer_table_geometry(golden):
+    """start_hash / prime / row counts at full inb_377 sizes (SURVEY.md §8c known-answer facts)."""
+    full = make_cfg()
+    for name, row in zip(golden['facts_names'].tolist(), golden['facts']):
+        sp = params.part_grid_spec(full, name)
+        assert (sp['start_hash'], sp['T'], sp['dense_rows'], sp['n_hash']) == tuple(int(v) for v in row)
+    expect = {'body': (6, 1048583), 'leg': (13, 1048583), 'head': (11, 262147), 'larm': (9, 32771), 'rarm': (9, 32771)}
+    for n, (sh, T) in expect.items():
+        sp = params.part_grid_spec(full, n)
+        assert sp['start_hash'] == sh and sp['T'] == T
+    d = params.deformer_grid_spec(full)
+    assert d['start_hash'] == 6 and d['T'] == 16411 and d['dense_rows'] == 12276
+    # total parameter count of the reference network at inb_377 defaults
+    tot = 0
+    for n in PART_NAMES:
+        sp = params.part_grid_spec(full, n)
+        occ, rgb = params.mlp_dims(full, n)
+        tot += sp['dense_rows'] * 16 + sp['n_hash'] * sp['T'] * 16 + 6 + 4 * 16 + 16 + 24 + 8 + 100 * 8
+        tot += sum(a * b + b for a, b in zip(occ[:-1], occ[1:])) + sum(a * b + b for a, b in zip(rgb[:-1], rgb[1:]))
+    tot += d['dense_rows'] * 2 + d['n_hash'] * d['T'] * 2 + 6 + 4 * 8 + 8 + 24 + (19 * 32 + 32 + 32 * 32 + 32 + 32 * 3 + 3)
+    assert tot == 285993711
+
+
+def test_sampling_and_volumes(golden, small_setup):
+    cfg, sd, batch, _ = small_setup
+    sel = torch.from_numpy(golden['sel_rays'].astype(np.int64))
+    pts, z = O.sample_points(batch['ray_o'][:, sel], batch['ray_d'][:, sel], batch['near'][:, sel],
+                             batch['far'][:, sel], cfg.N_samples)
+    close(pts, golden['wpts']); close(z, golden['z_vals'])
+    pp = O.world_to_pose(pts.reshape(-1, 3), batch['R'][0], batch['Th'][0])
+    close(pp[None], golden['pose_pts'])
+    pn = O.sample_volume(pp, batch['pbw'][0][..., -1:], batch['pbounds'][0])[:, 0]
+    close(pn, golden['pnorm'])
+    act = (pn < cfg.smpl_thresh).nonzero(as_tuple=True)[0]
+    assert np.array_equal(act.numpy(), golden['active_idx'])
+    uv = O.sample_volume(torch.from_numpy(golden['uv_pts'][0]), batch['tuv'][0], batch['tbounds'][0])
+    close(uv.t()[None], golden['uv_out'])
+
+
+def test_knn_warp_deformer(golden, small_setup):
+    cfg, sd, batch, _ = small_setup
+    m = O.Model(sd, cfg)
+    b = {k: v[0] for k, v in batch.items()}
+    pp = torch.from_numpy(golden['pose_pts'][0])
+    act = torch.from_numpy(golden['active_idx'].astype(np.int64))
+    ap = pp[act]
+    S = cfg.N_samples
+    sel = torch.from_numpy(golden['sel_rays'].astype(np.int64))
+    pd = O.world_dirs_to_pose(b['ray_d'][sel][:, None].expand(-1, S, -1).reshape(-1, 3), b['R'])[act]
+    bw, dist = O.knn_blend(ap, b['part_pts'], b['part_pbw'], b['lengths2'])
+    close(torch.cat([bw, dist[..., None]], -1)[None], golden['knn_bw'])
+    pflag = dist < cfg.smpl_thresh
+    assert np.array_equal(pflag.numpy()[None], golden['pflag'])
+    x_b, d_b = O.lbs_warp(ap, pd, bw, b['A'], b['big_A'])
+    close(x_b.reshape(1, -1, 3), golden['init_bigpose'], 5e-6)
+    close(d_b[None], golden['tpose_dirs'], 5e-6)
+    resd = torch.zeros_like(x_b)
+    resd[pflag] = O.deformer(x_b[pflag], sd, m.dspec, b['tuv'], b['tbounds'], b['frame_dim'])
+    close(resd[None], golden['resd'])
+    close((x_b + resd)[None], golden['tpose'], 5e-6)
+
+
+def test_hash_embedder_variants(golden, small_setup):
+    cfg, sd, batch, _ = small_setup
+    m = O.Model(sd, cfg)
+    for tag, pid in (('body', 0), ('head', 2)):
+        y = O.hash_embed(torch.from_numpy(golden['emb_%s_x' % tag]), sd,
+                         'tpose_human.part_networks.%d.embedder.' % pid, m.pspec[pid])
+        close(y, golden['emb_%s_y' % tag], 5e-6)
+    y = O.hash_embed(torch.from_numpy(golden['emb_deform_x']), sd, 'tpose_deformer.embedder.', m.dspec)
+    close(y, golden['emb_deform_y'])
+    # start_hash == 0 -> single (L,T,F) table, sum over levels (not features)
+    kw = dict(n_levels=6, n_features_per_level=4, log2_hashmap_size=8, base_resolution=8, b=1.38,
+              sum=True, sum_over_features=False, separate_dense=True, use_batch_bounds=False)
+    sp = params.grid_spec(bbox=[[-1, -1, -1], [1, 2, 1]], **kw)
+    assert sp['start_hash'] == 0 and not sp['separate_dense']
+    tab = (np.random.RandomState(11).standard_normal((sp['L'], sp['T'], sp['F'])) * 0.1).astype(np.float32)
+    sd0 = {'e.bounds': torch.from_numpy(sp['bbox']), 'e.entries_size': torch.from_numpy(sp['size']),
+           'e.entries_num': torch.tensor(sp['res']), 'e.offsets': torch.from_numpy(params.CORNER_OFFSETS),
+           'e.hash': torch.from_numpy(tab)}
+    close(O.hash_embed(torch.from_numpy(golden['emb_allhash_x']), sd0, 'e.', sp), golden['emb_allhash_y'], 5e-6)
+
+
+def test_part_fields_and_merge(golden, small_setup):
+    cfg, sd, batch, _ = small_setup
+    m = O.Model(sd, cfg)
+    tpose = torch.from_numpy(golden['tpose'][0]); tdirs = torch.from_numpy(golden['tpose_dirs'][0])
+    pflag = torch.from_numpy(golden['pflag'][0])
+    raws = torch.zeros(tpose.shape[0], 5, 4)
+    for pid in range(5):
+        f = pflag[:, pid]
+        r = O.part_field(tpose[f, pid], tdirs[f, pid], sd, pid, m.pspec[pid], m.n_occ[pid], m.n_rgb[pid],
+                         batch['latent_index'][0], m.n_freq)
+        close(r, golden['part%d_raw' % pid], 5e-6)
+        raws[f, pid] = r
+    raw, occ = O.merge_parts(raws)
+    close(raw, golden['merged_raw'], 5e-6); close(occ[:, None], golden['merged_occ'], 5e-6)
+    close(raws[..., 3:], golden['tocc'], 5e-6)
+
+
+def test_full_render_64x64x32(golden, small_setup):
+    """BASELINE config 1: 64x64 image, 32 samples per ray, eval mode."""
+    cfg, sd, batch, _ = small_setup
+    m = O.Model(sd, cfg)
+    with torch.no_grad():
+        r = O.render(m, batch)
+    close(r['rgb_map'], golden['render_rgb_map'], 5e-6)
+    close(r['acc_map'], golden['render_acc_map'], 5e-6)
+    raw = r['raw'][0].numpy()
+    nz = np.nonzero(raw[:, 3] != 0)[0]
+    assert np.array_equal(nz, golden['render_raw_nz_idx'])
+    close(raw[nz], golden['render_raw_nz'], 5e-6)
+    # chunked == unchunked (inb_renderer.py:217-237)
+    with torch.no_grad():
+        rc = O.render(m, batch, chunk=512)
+    close(rc['rgb_map'], r['rgb_map'].numpy(), 1e-6)
+
+
+def test_train_mode_forward(golden, small_setup):
+    """Train-mode quantities (stratified jitter, distortion loss, resd/tocc layouts)."""
+    cfg, sd, batch, _ = small_setup
+    m = O.Model(sd, cfg)
+    tsel = torch.from_numpy(golden['train_rays'].astype(np.int64))
+    tb = dict(batch)
+    for k in ('ray_o', 'ray_d', 'near', 'far'):
+        tb[k] = batch[k][:, tsel]
+    with torch.no_grad():
+        r = O.render(m, tb, jitter=torch.from_numpy(golden['train_jitter']), want_train=True)
+    close(r['rgb_map'], golden['train_rgb_map'], 5e-6)
+    close(r['resd'].reshape(1, -1, 3), golden['train_resd'])
+    close(r['tocc'].reshape(1, -1, 1), golden['train_tocc'], 5e-6)
+    close(O.distortion_loss(r['weights'], r['z'])[None], golden['train_reg_distortion_loss'], 5e-6)
