@@ -1,0 +1,176 @@
+/*
+ * invr.h — C ABI of libinvr.so, the MI355X (gfx950) per-ray render path of Instant-NVR.
+ *
+ * The reference (zju3dv/instant-nvr) has NO native code on this path: the path is ~2.9k ATen
+ * calls per 4096-ray chunk issued from Python.  The boundary a maintainer binds
+ * is therefore the Python plug-in seam (lib/networks/make_network.py:5-8,
+ * lib/networks/renderer/make_renderer.py:5-16, lib/train/trainers/make_trainer.py:4-7) and this
+ * header is what the replacement classes call through ctypes.  Each entry point names the
+ * reference function(s) it replaces.
+ *
+ * Conventions
+ *  - plain C, no torch types; every pointer marked "dev" is a device (HBM) address; structs are
+ *    host memory and are read during the call only (they may be freed when the call returns).
+ *  - float32 values, int32/int64 indices as stated.  Tensors are dense, row-major, in the
+ *    reference's own layouts (nn.Linear weight = (out,in); hash tables = (rows,F) / (H,T,F)).
+ *  - the caller owns all memory.  Kernels use only the explicit workspace
+ *    (invr_workspace_bytes) and never allocate.
+ *  - all work is enqueued on `stream` (a hipStream_t, passed as void*; NULL = default stream);
+ *    no call synchronises the device.
+ *  - return 0 on success, non-zero on error; invr_last_error() gives the message (thread-local).
+ *    No C++ exception crosses the boundary.
+ */
+#ifndef INVR_H
+#define INVR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define INVR_NUM_PARTS 5
+#define INVR_MAX_LEVELS 16
+#define INVR_MAX_LINEAR 4
+#define INVR_NUM_JOINTS 24
+
+/* One multi-resolution grid encoder: constructor arithmetic of
+ * lib/networks/embedders/part_base_embedder.py:13-104 (res, cell size, dense/hash split, prime T). */
+typedef struct InvrGrid {
+    const float* dense;            /* dev (dense_rows, F) or NULL when !separate_dense            */
+    const float* hash;             /* dev (n_hash, T, F); (L, T, F) when !separate_dense          */
+    const float* bounds;           /* dev (2,3) min xyz / max xyz (a checkpoint parameter, :50)   */
+    int32_t n_levels;              /* L                                                            */
+    int32_t n_features;            /* F                                                            */
+    int32_t start_hash;            /* first hashed level (:63-68)                                  */
+    int32_t separate_dense;        /* :69                                                          */
+    int64_t table_len;             /* T = nextprime(2^log2_hashmap_size) (:42)                     */
+    int32_t res[INVR_MAX_LEVELS];  /* entries_num (:52)                                            */
+    float cell[INVR_MAX_LEVELS];   /* entries_size, float32(1/(res-1)) (:54,57)                    */
+    int64_t dense_off[INVR_MAX_LEVELS]; /* first row of level l inside `dense` (:129)             */
+    int32_t sum;                   /* :163                                                         */
+    int32_t sum_over_features;     /* :164                                                         */
+    int32_t include_input;         /* :172                                                         */
+} InvrGrid;
+
+/* Softplus MLP: lib/networks/bw_deform/part_base_network.py:11-24 / uv_deformer.py:15-21 */
+typedef struct InvrMlp {
+    const float* weight[INVR_MAX_LINEAR];  /* dev (dims[i+1], dims[i]) */
+    const float* bias[INVR_MAX_LINEAR];    /* dev (dims[i+1])          */
+    int32_t dims[INVR_MAX_LINEAR + 1];
+    int32_t n_linear;
+} InvrMlp;
+
+/* One body-part field: part_base_network.py:31-42 */
+typedef struct InvrPart {
+    InvrGrid grid;
+    InvrMlp occ;                 /* 19 -> 64 -> 17                                                */
+    InvrMlp rgb;                 /* 70 -> 64 (-> 64) -> 3                                         */
+    const float* rgb_latent;     /* dev (num_latent_code, latent_dim)                              */
+    int32_t latent_dim;
+    int32_t num_latent_code;
+} InvrPart;
+
+/* inb_part_network_multiassign.py:68-75,172-182 */
+typedef struct InvrModel {
+    InvrPart part[INVR_NUM_PARTS];
+    InvrGrid deform_grid;        /* uv_deformer.py:14                                             */
+    InvrMlp deform_mlp;          /* 19 -> 32 -> 32 -> 3                                           */
+    int32_t n_dir_freq;          /* viewdir_embedder.kwargs.res (4)                                */
+    int32_t geo_feature_dim;     /* 16                                                             */
+} InvrModel;
+
+/* Per-frame tensors of the collated `batch` dict (lib/datasets/h36m/tpose_dataset.py:454-600),
+ * leading batch dim of 1 dropped. */
+typedef struct InvrScene {
+    const float* R;              /* dev (3,3)                                                      */
+    const float* Th;             /* dev (3)                                                        */
+    const float* A;              /* dev (24,4,4)                                                   */
+    const float* big_A;          /* dev (24,4,4)                                                   */
+    const float* pbw;            /* dev (Dx,Dy,Dz,C) blend-weight volume; last channel = distance  */
+    int32_t pbw_dims[3];
+    int32_t pbw_channels;        /* C (25)                                                         */
+    const float* pbounds;        /* dev (2,3)                                                      */
+    const float* tuv;            /* dev (Dx',Dy',Dz',2)                                            */
+    int32_t tuv_dims[3];
+    const float* tbounds;        /* dev (2,3)                                                      */
+    const float* part_pts;       /* dev (P,M,3)                                                    */
+    const float* part_pbw;       /* dev (P,M,24)                                                   */
+    const int64_t* lengths2;     /* dev (P)                                                        */
+    int32_t part_stride;         /* M                                                              */
+    const float* frame_dim;      /* dev (1)                                                        */
+    const int64_t* latent_index; /* dev (1)                                                        */
+    float smpl_thresh;           /* cfg.smpl_thresh                                                */
+    int32_t tpose_viewdir;       /* cfg.tpose_viewdir                                              */
+} InvrScene;
+
+/* Device-side statistics block written by invr_render_fwd (int32[INVR_STATS_LEN]). */
+#define INVR_STATS_LEN 16
+#define INVR_STAT_ACTIVE 0        /* Na: samples that passed the near-surface cull                 */
+#define INVR_STAT_PAIRS 1         /* [1..5]: flagged (point,part) pairs per part                    */
+#define INVR_STAT_OVERFLOW 6      /* non-zero if max_active was too small (results truncated)       */
+
+const char* invr_last_error(void);
+int invr_version(void);
+/* sizeof() of the ABI structs as compiled (0 InvrGrid, 1 InvrMlp, 2 InvrPart, 3 InvrModel,
+ * 4 InvrScene): lets a binding verify its struct mirrors. */
+size_t invr_sizeof(int32_t which);
+
+/* Bytes of workspace invr_render_fwd needs for n_rays x n_samples with at most max_active
+ * samples surviving the cull (pass n_rays*n_samples for the worst case). */
+size_t invr_workspace_bytes(int64_t n_rays, int32_t n_samples, int64_t max_active);
+
+/* Renderer.render / get_pixel_value, eval outputs (lib/networks/renderer/inb_renderer.py:53-76,
+ * 204-239) over the whole ray list without chunking:
+ *   get_wsampling_points (:15-31) -> Network.forward (inb_part_network_multiassign.py:126-168)
+ *   -> volume_rendering (lib/utils/net_utils.py:12-44, epsilon = 0).
+ * ray_o, ray_d (n_rays,3); near, far (n_rays); jitter (n_rays,n_samples) uniform [0,1) or NULL
+ * (NULL = eval / perturb 0).  Outputs: rgb_map (n_rays,3), acc_map (n_rays); optional
+ * raw (n_rays*n_samples,4), occ (n_rays*n_samples), weights (n_rays,n_samples), z_vals
+ * (n_rays,n_samples), stats (INVR_STATS_LEN int32); pass NULL to skip any optional output. */
+int invr_render_fwd(const InvrScene* scene, const InvrModel* model,
+                    const float* ray_o, const float* ray_d, const float* near, const float* far,
+                    const float* jitter, int64_t n_rays, int32_t n_samples,
+                    float* rgb_map, float* acc_map, float* raw, float* occ, float* weights,
+                    float* z_vals, int32_t* stats,
+                    void* workspace, size_t workspace_bytes, int64_t max_active, void* stream);
+
+/* ---- stage-level entry points (each is also a step of invr_render_fwd) ---------------------- */
+
+/* HashEmbedder.forward (part_base_embedder.py:106-174).  xyz (n,3) -> out (n,out_dim). */
+int invr_grid_encode_fwd(const InvrGrid* grid, const float* xyz, int64_t n, float* out, void* stream);
+
+/* pts_sample_blend_weights / pts_sample_uv (lib/utils/blend_utils.py:501-555): trilinear,
+ * border, align_corners.  vol (Dx,Dy,Dz,C) sampled at channels [c0, c0+nc) -> out (n,nc). */
+int invr_sample_volume(const float* vol, const int32_t dims[3], int32_t channels, int32_t c0, int32_t nc,
+                       const float* bounds, const float* pts, int64_t n, float* out, void* stream);
+
+/* pts_knn_blend_weights_multiassign_batch (blend_utils.py:817-825,741-763): pose_pts (n,3) ->
+ * bw (n,P,24), dist (n,P).  Exact brute-force 4-NN per part. */
+int invr_knn_blend(const InvrScene* scene, const float* pose_pts, int64_t n, float* bw, float* dist,
+                   void* stream);
+
+/* Network.pose_points_to_tpose_points (inb_part_network_multiassign.py:77-120): LBS inverse warp
+ * to the big pose + residual deformer for flagged pairs.  pose_pts, pose_dirs (n,3); bw (n,P,24);
+ * flag (n,P) uint8 -> tpose (n,P,3), tdirs (n,P,3), resd (n,P,3) (zeros where !flag). */
+int invr_warp_deform(const InvrScene* scene, const InvrModel* model, const float* pose_pts,
+                     const float* pose_dirs, const float* bw, const uint8_t* flag, int64_t n,
+                     float* tpose, float* tdirs, float* resd, void* stream);
+
+/* part_base_network.Network.forward (part_base_network.py:44-63) for part `pid`:
+ * tpts, tdirs (n,3) -> raw (n,4) = [sigmoid rgb, occ].  workspace >= invr_part_field_workspace(n). */
+size_t invr_part_field_workspace(int64_t n);
+int invr_part_field_fwd(const InvrModel* model, int32_t pid, const int64_t* latent_index,
+                        const float* tpts, const float* tdirs, int64_t n, float* raw,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* volume_rendering (net_utils.py:18-44) with epsilon 0: raw (n_rays,n_samples,4) ->
+ * weights (n_rays,n_samples) [optional], rgb_map (n_rays,3), acc_map (n_rays). */
+int invr_composite_fwd(const float* raw, int64_t n_rays, int32_t n_samples, float* weights,
+                       float* rgb_map, float* acc_map, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INVR_H */

@@ -1,0 +1,201 @@
+"""ctypes binding of libinvr.so (include/invr.h).  PyTorch-ROCm tensors in, tensors out.
+
+The library is the product path: if it is missing this module raises at import (no CPU
+fallback).  ``lib()`` loads it lazily so that CPU-only host logic (config, params, scene,
+state_dict handling) stays importable on a box without the .so or without a GPU.
+"""
+import ctypes as C
+import os
+
+import torch
+
+from . import params
+from .config import NUM_PARTS, PART_NAMES
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libinvr.so')
+
+MAX_LEVELS, MAX_LINEAR, STATS_LEN = 16, 4, 16
+_f32p, _i32p, _i64p, _u8p = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_uint8)
+
+
+class InvrGrid(C.Structure):
+    _fields_ = [('dense', C.c_void_p), ('hash', C.c_void_p), ('bounds', C.c_void_p),
+                ('n_levels', C.c_int32), ('n_features', C.c_int32), ('start_hash', C.c_int32),
+                ('separate_dense', C.c_int32), ('table_len', C.c_int64),
+                ('res', C.c_int32 * MAX_LEVELS), ('cell', C.c_float * MAX_LEVELS),
+                ('dense_off', C.c_int64 * MAX_LEVELS),
+                ('sum', C.c_int32), ('sum_over_features', C.c_int32), ('include_input', C.c_int32)]
+
+
+class InvrMlp(C.Structure):
+    _fields_ = [('weight', C.c_void_p * MAX_LINEAR), ('bias', C.c_void_p * MAX_LINEAR),
+                ('dims', C.c_int32 * (MAX_LINEAR + 1)), ('n_linear', C.c_int32)]
+
+
+class InvrPart(C.Structure):
+    _fields_ = [('grid', InvrGrid), ('occ', InvrMlp), ('rgb', InvrMlp), ('rgb_latent', C.c_void_p),
+                ('latent_dim', C.c_int32), ('num_latent_code', C.c_int32)]
+
+
+class InvrModel(C.Structure):
+    _fields_ = [('part', InvrPart * NUM_PARTS), ('deform_grid', InvrGrid), ('deform_mlp', InvrMlp),
+                ('n_dir_freq', C.c_int32), ('geo_feature_dim', C.c_int32)]
+
+
+class InvrScene(C.Structure):
+    _fields_ = [('R', C.c_void_p), ('Th', C.c_void_p), ('A', C.c_void_p), ('big_A', C.c_void_p),
+                ('pbw', C.c_void_p), ('pbw_dims', C.c_int32 * 3), ('pbw_channels', C.c_int32),
+                ('pbounds', C.c_void_p), ('tuv', C.c_void_p), ('tuv_dims', C.c_int32 * 3),
+                ('tbounds', C.c_void_p), ('part_pts', C.c_void_p), ('part_pbw', C.c_void_p),
+                ('lengths2', C.c_void_p), ('part_stride', C.c_int32), ('frame_dim', C.c_void_p),
+                ('latent_index', C.c_void_p), ('smpl_thresh', C.c_float), ('tpose_viewdir', C.c_int32)]
+
+
+EXPORTS = ['invr_last_error', 'invr_version', 'invr_sizeof', 'invr_workspace_bytes', 'invr_render_fwd',
+           'invr_grid_encode_fwd', 'invr_sample_volume', 'invr_knn_blend', 'invr_warp_deform',
+           'invr_part_field_workspace', 'invr_part_field_fwd', 'invr_composite_fwd']
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError('libinvr.so is not built (%s); run `python -c "import __graft_entry__ as g; g.build()"`. '
+                               'There is no CPU fallback for the render path.' % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.invr_last_error.restype = C.c_char_p
+        L.invr_version.restype = C.c_int
+        L.invr_sizeof.restype = C.c_size_t
+        L.invr_sizeof.argtypes = [C.c_int32]
+        for i, t in enumerate((InvrGrid, InvrMlp, InvrPart, InvrModel, InvrScene)):
+            if L.invr_sizeof(i) != C.sizeof(t):
+                raise RuntimeError('libinvr ABI mismatch: struct %s is %d bytes in the library, %d in the binding'
+                                   % (t.__name__, L.invr_sizeof(i), C.sizeof(t)))
+        L.invr_workspace_bytes.restype = C.c_size_t
+        L.invr_workspace_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int64]
+        L.invr_part_field_workspace.restype = C.c_size_t
+        L.invr_part_field_workspace.argtypes = [C.c_int64]
+        vp = C.c_void_p
+        L.invr_render_fwd.argtypes = [C.POINTER(InvrScene), C.POINTER(InvrModel), vp, vp, vp, vp, vp, C.c_int64,
+                                      C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, C.c_int64, vp]
+        L.invr_grid_encode_fwd.argtypes = [C.POINTER(InvrGrid), vp, C.c_int64, vp, vp]
+        L.invr_sample_volume.argtypes = [vp, C.c_int32 * 3, C.c_int32, C.c_int32, C.c_int32, vp, vp, C.c_int64, vp, vp]
+        L.invr_knn_blend.argtypes = [C.POINTER(InvrScene), vp, C.c_int64, vp, vp, vp]
+        L.invr_warp_deform.argtypes = [C.POINTER(InvrScene), C.POINTER(InvrModel), vp, vp, vp, vp, C.c_int64, vp, vp, vp, vp]
+        L.invr_part_field_fwd.argtypes = [C.POINTER(InvrModel), C.c_int32, vp, vp, vp, C.c_int64, vp, vp, C.c_size_t, vp]
+        L.invr_composite_fwd.argtypes = [vp, C.c_int64, C.c_int32, vp, vp, vp, vp]
+        for n in ('invr_render_fwd', 'invr_grid_encode_fwd', 'invr_sample_volume', 'invr_knn_blend',
+                  'invr_warp_deform', 'invr_part_field_fwd', 'invr_composite_fwd'):
+            getattr(L, n).restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def check(status):
+    if status != 0:
+        raise RuntimeError('libinvr: ' + lib().invr_last_error().decode())
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t, dtype=torch.float32):
+    """Device pointer of a contiguous CUDA tensor of the expected dtype (None -> NULL)."""
+    if t is None:
+        return C.c_void_p(0)
+    assert t.is_cuda, 'libinvr needs device tensors (got a CPU tensor)'
+    assert t.dtype == dtype, (t.dtype, dtype)
+    assert t.is_contiguous()
+    return C.c_void_p(t.data_ptr())
+
+
+def _f32c(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+def make_grid(spec, dense, hsh, bounds, keep):
+    """InvrGrid from params.grid_spec(...) + table tensors.  `keep` collects tensors to keep alive."""
+    g = InvrGrid()
+    hsh = _f32c(hsh); keep.append(hsh)
+    g.hash = hsh.data_ptr()
+    if dense is not None:
+        dense = _f32c(dense); keep.append(dense)
+        g.dense = dense.data_ptr()
+    bounds = _f32c(bounds); keep.append(bounds)
+    g.bounds = bounds.data_ptr()
+    g.n_levels, g.n_features, g.start_hash = spec['L'], spec['F'], spec['start_hash']
+    g.separate_dense, g.table_len = int(spec['separate_dense']), spec['T']
+    for l in range(spec['L']):
+        g.res[l] = spec['res'][l]
+        g.cell[l] = float(spec['size'][l])
+        g.dense_off[l] = spec['dense_off'][l]
+    g.sum, g.sum_over_features, g.include_input = int(spec['sum']), int(spec['sum_over_features']), int(spec['include_input'])
+    return g
+
+
+def make_mlp(weights, biases, keep):
+    m = InvrMlp()
+    m.n_linear = len(weights)
+    for i, (w, b) in enumerate(zip(weights, biases)):
+        w, b = _f32c(w), _f32c(b)
+        keep += [w, b]
+        m.weight[i], m.bias[i] = w.data_ptr(), b.data_ptr()
+        m.dims[i], m.dims[i + 1] = w.shape[1], w.shape[0]
+    return m
+
+
+def make_model(sd, cfg, keep):
+    """InvrModel from a reference-keyed state_dict of device tensors."""
+    m = InvrModel()
+    dspec = params.deformer_grid_spec(cfg)
+    p = 'tpose_deformer.embedder.'
+    m.deform_grid = make_grid(dspec, sd.get(p + 'dense'), sd[p + 'hash'], sd[p + 'bounds'], keep)
+    m.deform_mlp = make_mlp([sd['tpose_deformer.mlp.%d.weight' % k] for k in (0, 2, 4)],
+                            [sd['tpose_deformer.mlp.%d.bias' % k] for k in (0, 2, 4)], keep)
+    for i, name in enumerate(PART_NAMES):
+        q = 'tpose_human.part_networks.%d.' % i
+        spec = params.part_grid_spec(cfg, name)
+        part = m.part[i]
+        part.grid = make_grid(spec, sd.get(q + 'embedder.dense'), sd[q + 'embedder.hash'], sd[q + 'embedder.bounds'], keep)
+        occ_dims, rgb_dims = params.mlp_dims(cfg, name)
+        part.occ = make_mlp([sd[q + 'occ.linears.%d.weight' % k] for k in range(len(occ_dims) - 1)],
+                            [sd[q + 'occ.linears.%d.bias' % k] for k in range(len(occ_dims) - 1)], keep)
+        part.rgb = make_mlp([sd[q + 'rgb.linears.%d.weight' % k] for k in range(len(rgb_dims) - 1)],
+                            [sd[q + 'rgb.linears.%d.bias' % k] for k in range(len(rgb_dims) - 1)], keep)
+        lat = _f32c(sd[q + 'rgb_latent']); keep.append(lat)
+        part.rgb_latent = lat.data_ptr()
+        part.latent_dim, part.num_latent_code = lat.shape[1], lat.shape[0]
+    m.n_dir_freq = cfg.viewdir_embedder.kwargs['res']
+    m.geo_feature_dim = cfg.geo_feature_dim
+    return m
+
+
+def make_scene(batch, cfg, keep):
+    """InvrScene from the reference's collated batch dict (device tensors, leading dim 1)."""
+    s = InvrScene()
+
+    def f(k):
+        t = _f32c(batch[k][0]); keep.append(t)
+        return t
+    s.R, s.Th, s.A, s.big_A = f('R').data_ptr(), f('Th').data_ptr(), f('A').data_ptr(), f('big_A').data_ptr()
+    pbw, tuv = f('pbw'), f('tuv')
+    s.pbw, s.tuv = pbw.data_ptr(), tuv.data_ptr()
+    for a in range(3):
+        s.pbw_dims[a], s.tuv_dims[a] = pbw.shape[a], tuv.shape[a]
+    s.pbw_channels = pbw.shape[3]
+    assert tuv.shape[3] == 2
+    s.pbounds, s.tbounds = f('pbounds').data_ptr(), f('tbounds').data_ptr()
+    pp, pb = f('part_pts'), f('part_pbw')
+    assert pp.shape[0] == NUM_PARTS and pb.shape[2] == 24
+    s.part_pts, s.part_pbw, s.part_stride = pp.data_ptr(), pb.data_ptr(), pp.shape[1]
+    l2 = batch['lengths2'][0].to(torch.int64).contiguous(); keep.append(l2)
+    s.lengths2 = l2.data_ptr()
+    fd = batch['frame_dim'].reshape(-1)[:1].to(torch.float32).contiguous(); keep.append(fd)
+    li = batch['latent_index'].reshape(-1)[:1].to(torch.int64).contiguous(); keep.append(li)
+    s.frame_dim, s.latent_index = fd.data_ptr(), li.data_ptr()
+    s.smpl_thresh, s.tpose_viewdir = float(cfg.smpl_thresh), int(bool(cfg.tpose_viewdir))
+    return s

@@ -1,0 +1,172 @@
+// Shared device helpers and internal launch declarations for libinvr (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/invr.h"
+
+#define INVR_WAVE 64
+#define HASH_P1 19349663ull
+#define HASH_P2 83492791ull
+
+// ---- error plumbing (host) -----------------------------------------------------------------
+void invr_set_error(const char* fmt, ...);
+#define INVR_CHECK(cond, ...)                \
+    do {                                     \
+        if (!(cond)) {                       \
+            invr_set_error(__VA_ARGS__);     \
+            return 1;                        \
+        }                                    \
+    } while (0)
+#define INVR_HIP(call)                                                              \
+    do {                                                                            \
+        hipError_t e_ = (call);                                                     \
+        if (e_ != hipSuccess) {                                                     \
+            invr_set_error("%s failed: %s", #call, hipGetErrorString(e_));          \
+            return 1;                                                               \
+        }                                                                           \
+    } while (0)
+#define INVR_LAUNCH_CHECK()                                                         \
+    do {                                                                            \
+        hipError_t e_ = hipGetLastError();                                          \
+        if (e_ != hipSuccess) {                                                     \
+            invr_set_error("kernel launch failed (%s:%d): %s", __FILE__, __LINE__,  \
+                           hipGetErrorString(e_));                                  \
+            return 1;                                                               \
+        }                                                                           \
+    } while (0)
+
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- device-side parameter blocks (passed by value as kernel arguments) ----------------------
+struct GridDev {
+    const float* dense;
+    const float* hash;
+    const float* bounds;
+    int32_t L, F, start_hash, separate_dense;
+    int64_t T;
+    double inv_T;
+    int32_t res[INVR_MAX_LEVELS];
+    float cell[INVR_MAX_LEVELS];
+    int64_t dense_off[INVR_MAX_LEVELS];
+    int32_t sum, sum_over_features, include_input;
+};
+
+struct VolDev {          // (Dx,Dy,Dz,C) volume + (2,3) bounds
+    const float* data;
+    const float* bounds;
+    int32_t dx, dy, dz, c;
+};
+
+struct SceneDev {
+    const float* R;
+    const float* Th;
+    const float* A;
+    const float* big_A;
+    VolDev pbw;
+    VolDev tuv;
+    const float* part_pts;
+    const float* part_pbw;
+    const int64_t* lengths2;
+    int32_t M;
+    const float* frame_dim;
+    const int64_t* latent_index;
+    float thresh;
+    int32_t tpose_viewdir;
+};
+
+struct MlpDev {
+    const float* w[INVR_MAX_LINEAR];
+    const float* b[INVR_MAX_LINEAR];
+    int32_t dims[INVR_MAX_LINEAR + 1];
+    int32_t n_linear;
+};
+
+GridDev make_grid_dev(const InvrGrid* g);
+SceneDev make_scene_dev(const InvrScene* s);
+MlpDev make_mlp_dev(const InvrMlp* m);
+
+// ---- device math ------------------------------------------------------------------------------
+// torch.nn.Softplus(beta=1, threshold=20): x > 20 ? x : log1p(exp(x))
+__device__ __forceinline__ float softplus_f(float x) {
+    // max(x,0) + log1p(exp(-|x|)) is the same function, without overflow, and keeps relative
+    // accuracy for very negative x (the occupancy head needs it: occ = 1-exp(-softplus)).
+    float e = __expf(-fabsf(x));
+    float l = (e < 1e-4f) ? e * (1.0f - 0.5f * e) : __logf(1.0f + e);
+    float r = fmaxf(x, 0.0f) + l;
+    return x > 20.0f ? x : r;
+}
+
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// torch.linspace(0,1,S)[i] in float32 (symmetric fill used by ATen's CPU/GPU kernels)
+__device__ __forceinline__ float linspace01(int i, int S) {
+    float step = 1.0f / (float)(S - 1);
+    return (i < S / 2) ? step * (float)i : 1.0f - step * (float)(S - 1 - i);
+}
+
+// Trilinear sample of channel block [c0,c0+NC) of a (Dx,Dy,Dz,C) volume at a pose/canonical
+// point; F.grid_sample(mode=bilinear, padding_mode=border, align_corners=True) semantics with the
+// reference's xyz->zyx flip (blend_utils.py:501-555): axis a index = ((u_a+1)/2)*(size_a-1),
+// clamped to [0,size_a-1] before corner selection.
+template <int NC>
+__device__ __forceinline__ void sample_volume_dev(const VolDev& v, int c0, float px, float py, float pz, float* out) {
+    const float b0x = v.bounds[0], b0y = v.bounds[1], b0z = v.bounds[2];
+    const float b1x = v.bounds[3], b1y = v.bounds[4], b1z = v.bounds[5];
+    float gx = (px - b0x) / (b1x - b0x) * 2.0f - 1.0f;
+    float gy = (py - b0y) / (b1y - b0y) * 2.0f - 1.0f;
+    float gz = (pz - b0z) / (b1z - b0z) * 2.0f - 1.0f;
+    float ix = ((gx + 1.0f) / 2.0f) * (float)(v.dx - 1);
+    float iy = ((gy + 1.0f) / 2.0f) * (float)(v.dy - 1);
+    float iz = ((gz + 1.0f) / 2.0f) * (float)(v.dz - 1);
+    ix = fminf(fmaxf(ix, 0.0f), (float)(v.dx - 1));
+    iy = fminf(fmaxf(iy, 0.0f), (float)(v.dy - 1));
+    iz = fminf(fmaxf(iz, 0.0f), (float)(v.dz - 1));
+    float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+    int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+    float tx = ix - fx, ty = iy - fy, tz = iz - fz;
+    int x1 = min(x0 + 1, v.dx - 1), y1 = min(y0 + 1, v.dy - 1), z1 = min(z0 + 1, v.dz - 1);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) out[c] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        int xx = (k & 4) ? x1 : x0, yy = (k & 2) ? y1 : y0, zz = (k & 1) ? z1 : z0;
+        float w = ((k & 4) ? tx : 1.0f - tx) * ((k & 2) ? ty : 1.0f - ty) * ((k & 1) ? tz : 1.0f - tz);
+        const float* p = v.data + (((int64_t)xx * v.dy + yy) * v.dz + zz) * v.c + c0;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) out[c] = fmaf(w, p[c], out[c]);
+    }
+}
+
+// (a ^ b*P1 ^ c*P2) mod T, exact for T < 2^31 and products < 2^52 (int64 arithmetic of
+// part_base_embedder.py:132-136) using one fp64 reciprocal multiply + correction.
+__device__ __forceinline__ uint32_t hash_mod(uint32_t cx, uint32_t cy, uint32_t cz, int64_t T, double inv_T) {
+    uint64_t x = (uint64_t)cx ^ ((uint64_t)cy * HASH_P1) ^ ((uint64_t)cz * HASH_P2);
+    double xd = (double)x;
+    double q = floor(xd * inv_T);
+    double r = fma(-q, (double)T, xd);
+    if (r < 0.0) r += (double)T;
+    if (r >= (double)T) r -= (double)T;
+    return (uint32_t)r;
+}
+
+// Normalised coordinate -> per-axis clipped corners and fractional offsets of one level
+// (part_base_embedder.py:115-118): f = x / cell; c0 = clip(trunc(f)), c1 = clip(trunc(f + 1));
+// t = f - c0 (may leave [0,1] outside the box -> extrapolation).
+__device__ __forceinline__ void level_corners(float x, float cell, int res, int& c0, int& c1, float& t) {
+    float f = x / cell;
+    int a = (int)f;              // v_cvt_i32_f32: truncates toward zero (torch .long())
+    int b = (int)(f + 1.0f);
+    c0 = min(max(a, 0), res - 1);
+    c1 = min(max(b, 0), res - 1);
+    t = f - (float)c0;
+}
+
+// ---- kernel launchers (defined in the .hip files) ---------------------------------------------
+int launch_grid_encode_generic(const GridDev& g, const float* xyz, int64_t n, float* out, hipStream_t st);
+int launch_sample_volume(const VolDev& v, int c0, int nc, const float* pts, int64_t n, float* out, hipStream_t st);
+int launch_knn_blend_dense(const SceneDev& s, const float* pose_pts, int64_t n, float* bw, float* dist, hipStream_t st);
+int launch_warp_deform_dense(const SceneDev& s, const GridDev& dg, const MlpDev& dm, const float* pose_pts,
+                             const float* pose_dirs, const float* bw, const uint8_t* flag, int64_t n,
+                             float* tpose, float* tdirs, float* resd, hipStream_t st);
+int launch_composite(const float* raw, int64_t n_rays, int S, float* weights, float* rgb_map, float* acc_map, hipStream_t st);

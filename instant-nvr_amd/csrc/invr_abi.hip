@@ -1,0 +1,261 @@
+// C-ABI entry points of libinvr.so (include/invr.h) and the stream-ordered orchestration of one
+// render: cull -> KNN pairs -> warp+deform -> per part {encode -> MLP} -> merge+composite.
+// No host synchronisation anywhere: survivor / pair counts stay on the device and the consumers
+// are persistent grid-stride kernels that read them.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include "pipeline.h"
+
+static thread_local char g_err[512] = "";
+
+void invr_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* invr_last_error(void) { return g_err; }
+extern "C" int invr_version(void) { return 1; }
+extern "C" size_t invr_sizeof(int32_t which) {
+    switch (which) {
+        case 0: return sizeof(InvrGrid);
+        case 1: return sizeof(InvrMlp);
+        case 2: return sizeof(InvrPart);
+        case 3: return sizeof(InvrModel);
+        case 4: return sizeof(InvrScene);
+        default: return 0;
+    }
+}
+
+GridDev make_grid_dev(const InvrGrid* g) {
+    GridDev d;
+    memset(&d, 0, sizeof(d));
+    d.dense = g->dense; d.hash = g->hash; d.bounds = g->bounds;
+    d.L = g->n_levels; d.F = g->n_features; d.start_hash = g->start_hash; d.separate_dense = g->separate_dense;
+    d.T = g->table_len; d.inv_T = 1.0 / (double)g->table_len;
+    for (int l = 0; l < INVR_MAX_LEVELS; ++l) { d.res[l] = g->res[l]; d.cell[l] = g->cell[l]; d.dense_off[l] = g->dense_off[l]; }
+    d.sum = g->sum; d.sum_over_features = g->sum_over_features; d.include_input = g->include_input;
+    return d;
+}
+
+MlpDev make_mlp_dev(const InvrMlp* m) {
+    MlpDev d;
+    memset(&d, 0, sizeof(d));
+    for (int i = 0; i < INVR_MAX_LINEAR; ++i) { d.w[i] = m->weight[i]; d.b[i] = m->bias[i]; }
+    for (int i = 0; i <= INVR_MAX_LINEAR; ++i) d.dims[i] = m->dims[i];
+    d.n_linear = m->n_linear;
+    return d;
+}
+
+SceneDev make_scene_dev(const InvrScene* s) {
+    SceneDev d;
+    memset(&d, 0, sizeof(d));
+    d.R = s->R; d.Th = s->Th; d.A = s->A; d.big_A = s->big_A;
+    d.pbw = VolDev{s->pbw, s->pbounds, s->pbw_dims[0], s->pbw_dims[1], s->pbw_dims[2], s->pbw_channels};
+    d.tuv = VolDev{s->tuv, s->tbounds, s->tuv_dims[0], s->tuv_dims[1], s->tuv_dims[2], 2};
+    d.part_pts = s->part_pts; d.part_pbw = s->part_pbw; d.lengths2 = s->lengths2; d.M = s->part_stride;
+    d.frame_dim = s->frame_dim; d.latent_index = s->latent_index;
+    d.thresh = s->smpl_thresh; d.tpose_viewdir = s->tpose_viewdir;
+    return d;
+}
+
+static int check_grid(const InvrGrid* g, const char* what) {
+    INVR_CHECK(g->n_levels >= 1 && g->n_levels <= INVR_MAX_LEVELS, "%s: n_levels %d out of range", what, g->n_levels);
+    INVR_CHECK(g->n_features >= 1 && g->n_features <= 16, "%s: n_features %d out of range", what, g->n_features);
+    INVR_CHECK(g->hash != nullptr && g->bounds != nullptr, "%s: null table/bounds", what);
+    INVR_CHECK(!g->separate_dense || g->dense != nullptr, "%s: separate_dense without dense table", what);
+    INVR_CHECK(g->table_len > 1 && g->table_len < (1ll << 31), "%s: table_len out of range", what);
+    for (int l = 0; l < g->n_levels; ++l) INVR_CHECK(g->res[l] >= 2 && g->res[l] <= 8192, "%s: level %d resolution %d out of range", what, l, g->res[l]);
+    return 0;
+}
+
+static int check_mlp_deform(const InvrMlp* m) {
+    INVR_CHECK(m->n_linear == 3 && m->dims[0] == 19 && m->dims[1] == 32 && m->dims[2] == 32 && m->dims[3] == 3,
+               "deformer MLP must be 19-32-32-3");
+    return 0;
+}
+
+// ---- workspace carve -----------------------------------------------------------------------------
+struct Carver {
+    char* base;
+    size_t off;
+    template <class T> T* take(size_t n) {
+        off = align_up(off, 256);
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += n * sizeof(T);
+        return p;
+    }
+};
+
+static size_t carve(Workspace& w, void* base, int64_t N, int64_t cap) {
+    Carver c{(char*)base, 0};
+    int64_t nb = cdiv(N, 256);
+    w.cap = cap;
+    w.counters = c.take<int32_t>(CNT_LEN);
+    w.part_aabb = c.take<float>(INVR_NUM_PARTS * 6);
+    w.mask = c.take<unsigned long long>(nb * 4);
+    w.block_cnt = c.take<int32_t>(nb);
+    w.block_off = c.take<int32_t>(nb);
+    w.active_idx = c.take<int32_t>(cap);
+    w.slot_of_sample = c.take<int32_t>(N);
+    w.pflags = c.take<uint8_t>(cap);
+    for (int p = 0; p < INVR_NUM_PARTS; ++p) {
+        w.l_slot[p] = c.take<int32_t>(cap);
+        w.l_nn[p] = c.take<int32_t>(cap * 4);
+        w.l_w[p] = c.take<float>(cap * 4);
+        w.l_x[p] = c.take<float>(cap * 3);
+        w.l_d[p] = c.take<float>(cap * 3);
+    }
+    w.emb[0] = c.take<float>(cap * EMB_K);
+    w.emb[1] = c.take<float>(cap * EMB_K);
+    w.raws = c.take<float4>(cap * INVR_NUM_PARTS);
+    return align_up(c.off, 256);
+}
+
+extern "C" size_t invr_workspace_bytes(int64_t n_rays, int32_t n_samples, int64_t max_active) {
+    Workspace w;
+    int64_t N = n_rays * (int64_t)n_samples;
+    if (max_active <= 0 || max_active > N) max_active = N;
+    if (max_active < 1) max_active = 1;
+    return carve(w, nullptr, N > 0 ? N : 1, max_active);
+}
+
+__global__ void k_export_stats(const int32_t* counters, int32_t* stats) {
+    int t = threadIdx.x;
+    if (t < INVR_STATS_LEN) stats[t] = t < CNT_LEN ? counters[t] : 0;
+}
+
+static PartMlpDev make_part_mlp(const InvrModel* m, int p, const int64_t* latent_index) {
+    PartMlpDev pm;
+    pm.occ = make_mlp_dev(&m->part[p].occ);
+    pm.rgb = make_mlp_dev(&m->part[p].rgb);
+    pm.rgb_latent = m->part[p].rgb_latent;
+    pm.latent_index = latent_index;
+    pm.latent_dim = m->part[p].latent_dim;
+    pm.n_freq = m->n_dir_freq;
+    pm.geo_dim = m->geo_feature_dim;
+    return pm;
+}
+
+extern "C" int invr_render_fwd(const InvrScene* scene, const InvrModel* model,
+                               const float* ray_o, const float* ray_d, const float* near, const float* far,
+                               const float* jitter, int64_t n_rays, int32_t n_samples,
+                               float* rgb_map, float* acc_map, float* raw, float* occ, float* weights,
+                               float* z_vals, int32_t* stats,
+                               void* workspace, size_t workspace_bytes, int64_t max_active, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    INVR_CHECK(scene && model, "invr_render_fwd: null scene/model");
+    INVR_CHECK(n_rays >= 0 && n_samples >= 2, "invr_render_fwd: need n_rays >= 0 and n_samples >= 2");
+    if (n_rays == 0) return 0;
+    INVR_CHECK(ray_o && ray_d && near && far && rgb_map && acc_map, "invr_render_fwd: null ray/output pointer");
+    const int64_t N = n_rays * (int64_t)n_samples;
+    INVR_CHECK(N < (1ll << 31), "invr_render_fwd: n_rays*n_samples must be < 2^31 (got %lld); split the ray list", (long long)N);
+    if (max_active <= 0 || max_active > N) max_active = N;
+    Workspace w;
+    size_t need = carve(w, workspace, N, max_active);
+    INVR_CHECK(workspace != nullptr && workspace_bytes >= need, "invr_render_fwd: workspace too small (%zu < %zu bytes)", workspace_bytes, need);
+    INVR_CHECK(((uintptr_t)workspace & 255) == 0, "invr_render_fwd: workspace must be 256-byte aligned");
+    if (check_grid(&model->deform_grid, "deformer grid") || check_mlp_deform(&model->deform_mlp)) return 1;
+    INVR_CHECK(model->deform_grid.n_levels == 8 && model->deform_grid.n_features == 2 && !model->deform_grid.sum &&
+               model->deform_grid.include_input, "deformer grid must be 8 levels x 2 features, sum=False, include_input");
+    for (int p = 0; p < INVR_NUM_PARTS; ++p) if (check_grid(&model->part[p].grid, "part grid")) return 1;
+    INVR_CHECK(scene->pbw_channels >= 1 && scene->part_stride >= 1, "invr_render_fwd: bad scene dims");
+
+    RenderArgs a;
+    a.scene = make_scene_dev(scene);
+    a.ray_o = ray_o; a.ray_d = ray_d; a.near = near; a.far = far; a.jitter = jitter; a.z_vals = z_vals;
+    a.R = n_rays; a.S = n_samples; a.N = N;
+
+    INVR_HIP(hipMemsetAsync(w.counters, 0, CNT_LEN * sizeof(int32_t), st));
+    if (launch_cull(a, w, max_active, st)) return 1;
+    if (launch_knn_pairs(a, w, st)) return 1;
+    GridDev dg = make_grid_dev(&model->deform_grid);
+    MlpDev dm = make_mlp_dev(&model->deform_mlp);
+    if (launch_warp_pairs(a, w, dg, dm, st)) return 1;
+    for (int p = 0; p < INVR_NUM_PARTS; ++p) {
+        GridDev g = make_grid_dev(&model->part[p].grid);
+        float* emb = w.emb[p & 1];
+        if (launch_part_encode(g, w.l_x[p], w.cap, w.counters + CNT_PAIRS + p, w.cap, emb, st)) return 1;
+        PartMlpDev pm = make_part_mlp(model, p, scene->latent_index);
+        if (launch_part_mlp(pm, emb, w.l_d[p], w.cap, w.l_slot[p], w.counters + CNT_PAIRS + p, w.cap, w.raws, p, nullptr, st)) return 1;
+    }
+    if (launch_merge_composite(a, w, rgb_map, acc_map, raw, occ, weights, st)) return 1;
+    if (stats) {
+        hipLaunchKernelGGL(k_export_stats, dim3(1), dim3(64), 0, st, w.counters, stats);
+        INVR_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+// ---- stage-level entry points -------------------------------------------------------------------
+extern "C" int invr_grid_encode_fwd(const InvrGrid* grid, const float* xyz, int64_t n, float* out, void* stream) {
+    INVR_CHECK(grid && (n == 0 || (xyz && out)), "invr_grid_encode_fwd: null pointer");
+    if (check_grid(grid, "grid")) return 1;
+    return launch_grid_encode_generic(make_grid_dev(grid), xyz, n, out, (hipStream_t)stream);
+}
+
+extern "C" int invr_sample_volume(const float* vol, const int32_t dims[3], int32_t channels, int32_t c0, int32_t nc,
+                                  const float* bounds, const float* pts, int64_t n, float* out, void* stream) {
+    INVR_CHECK(vol && dims && bounds && (n == 0 || (pts && out)), "invr_sample_volume: null pointer");
+    INVR_CHECK(c0 >= 0 && nc >= 1 && c0 + nc <= channels, "invr_sample_volume: channel range [%d,%d) outside %d", c0, c0 + nc, channels);
+    VolDev v{vol, bounds, dims[0], dims[1], dims[2], channels};
+    return launch_sample_volume(v, c0, nc, pts, n, out, (hipStream_t)stream);
+}
+
+extern "C" int invr_knn_blend(const InvrScene* scene, const float* pose_pts, int64_t n, float* bw, float* dist, void* stream) {
+    INVR_CHECK(scene && (n == 0 || (pose_pts && bw && dist)), "invr_knn_blend: null pointer");
+    return launch_knn_blend_dense(make_scene_dev(scene), pose_pts, n, bw, dist, (hipStream_t)stream);
+}
+
+extern "C" int invr_warp_deform(const InvrScene* scene, const InvrModel* model, const float* pose_pts,
+                                const float* pose_dirs, const float* bw, const uint8_t* flag, int64_t n,
+                                float* tpose, float* tdirs, float* resd, void* stream) {
+    INVR_CHECK(scene && model && (n == 0 || (pose_pts && pose_dirs && bw && flag && tpose && tdirs && resd)), "invr_warp_deform: null pointer");
+    if (check_grid(&model->deform_grid, "deformer grid") || check_mlp_deform(&model->deform_mlp)) return 1;
+    return launch_warp_deform_dense(make_scene_dev(scene), make_grid_dev(&model->deform_grid), make_mlp_dev(&model->deform_mlp),
+                                    pose_pts, pose_dirs, bw, flag, n, tpose, tdirs, resd, (hipStream_t)stream);
+}
+
+__global__ void k_aos_to_soa(const float* a, const float* b, int64_t n, float* xs, float* ds, int32_t* count) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *count = (int32_t)n;
+    if (i >= n) return;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { xs[c * n + i] = a[i * 3 + c]; ds[c * n + i] = b[i * 3 + c]; }
+}
+
+extern "C" size_t invr_part_field_workspace(int64_t n) {
+    if (n < 1) n = 1;
+    return align_up(256 + (size_t)n * (3 + 3 + EMB_K) * sizeof(float) + 3 * 256, 256);
+}
+
+extern "C" int invr_part_field_fwd(const InvrModel* model, int32_t pid, const int64_t* latent_index,
+                                   const float* tpts, const float* tdirs, int64_t n, float* raw,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    INVR_CHECK(model && latent_index && pid >= 0 && pid < INVR_NUM_PARTS, "invr_part_field_fwd: bad model/pid");
+    if (n == 0) return 0;
+    INVR_CHECK(tpts && tdirs && raw, "invr_part_field_fwd: null pointer");
+    INVR_CHECK(n < (1ll << 31), "invr_part_field_fwd: n too large");
+    INVR_CHECK(workspace && workspace_bytes >= invr_part_field_workspace(n), "invr_part_field_fwd: workspace too small");
+    if (check_grid(&model->part[pid].grid, "part grid")) return 1;
+    Carver c{(char*)workspace, 0};
+    int32_t* count = c.take<int32_t>(1);
+    float* xs = c.take<float>(3 * n);
+    float* ds = c.take<float>(3 * n);
+    float* emb = c.take<float>(EMB_K * n);
+    hipLaunchKernelGGL(k_aos_to_soa, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, tpts, tdirs, n, xs, ds, count);
+    INVR_LAUNCH_CHECK();
+    if (launch_part_encode(make_grid_dev(&model->part[pid].grid), xs, n, count, n, emb, st)) return 1;
+    PartMlpDev pm = make_part_mlp(model, pid, latent_index);
+    return launch_part_mlp(pm, emb, ds, n, nullptr, count, n, nullptr, pid, reinterpret_cast<float4*>(raw), st);
+}
+
+extern "C" int invr_composite_fwd(const float* raw, int64_t n_rays, int32_t n_samples, float* weights,
+                                  float* rgb_map, float* acc_map, void* stream) {
+    INVR_CHECK(n_rays == 0 || (raw && rgb_map && acc_map), "invr_composite_fwd: null pointer");
+    INVR_CHECK(n_samples >= 1, "invr_composite_fwd: n_samples must be >= 1");
+    return launch_composite(raw, n_rays, n_samples, weights, rgb_map, acc_map, (hipStream_t)stream);
+}

@@ -1,0 +1,102 @@
+// K7 + K8: max-occupancy part merge and alpha compositing along the ray.
+// Replaces TPoseHuman.forward's merge (inb_part_network_multiassign.py:229-256, cfg.aggr == ""),
+// the scatter into full-size raw/occ (:156-159) and volume_rendering / render_weights
+// (lib/utils/net_utils.py:12-44 as called at inb_renderer.py:72, i.e. epsilon = 0, no background).
+//
+// One wave per ray, lane = sample (64 samples per pass): transmittance is an exclusive product
+// scan done with 6 wave shuffles, rgb/acc are wave reductions.  The merge is done on the fly from
+// the per-(slot,part) results, so the (N,4) raw tensor is only written when the caller wants it.
+#include "pipeline.h"
+
+#define CMP_BLOCK 256
+
+__device__ __forceinline__ float wave_incl_prod(float x, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        float y = __shfl_up(x, d);
+        if (lane >= d) x *= y;
+    }
+    return x;
+}
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d);
+    return x;
+}
+
+struct DenseRaw {      // raw (R,S,4) given
+    const float4* raw;
+    __device__ __forceinline__ float4 get(int64_t i) const { return raw[i]; }
+};
+struct MergedRaw {     // merge per-part results of the survivor slot of sample i
+    const int32_t* slot_of_sample;
+    const uint8_t* pflags;
+    const float4* raws;
+    __device__ __forceinline__ float4 get(int64_t i) const {
+        const int slot = slot_of_sample[i];
+        float4 best = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (slot >= 0) {
+            const unsigned fl = pflags[slot];
+            // argmax over the 5 parts with zeros for unflagged parts, first maximum wins (:253-255)
+#pragma unroll
+            for (int p = 0; p < INVR_NUM_PARTS; ++p) {
+                float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (fl & (1u << p)) c = raws[(int64_t)slot * INVR_NUM_PARTS + p];
+                if (p == 0 || c.w > best.w) best = c;
+            }
+        }
+        return best;
+    }
+};
+
+template <class Src>
+__global__ __launch_bounds__(CMP_BLOCK) void k_composite(Src src, int64_t R, int S, float* __restrict__ weights,
+                                                         float* __restrict__ rgb_map, float* __restrict__ acc_map,
+                                                         float4* __restrict__ raw_out, float* __restrict__ occ_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t ray = (int64_t)blockIdx.x * (CMP_BLOCK / 64) + (threadIdx.x >> 6);
+    if (ray >= R) return;
+    float T_run = 1.0f, ar = 0.f, ag = 0.f, ab = 0.f, aw = 0.f;
+    for (int s0 = 0; s0 < S; s0 += 64) {
+        const int s = s0 + lane;
+        const bool live = s < S;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live) {
+            v = src.get(ray * S + s);
+            if (raw_out) raw_out[ray * S + s] = v;
+            if (occ_out) occ_out[ray * S + s] = v.w;
+        }
+        const float alpha = v.w;
+        const float incl = wave_incl_prod(1.0f - alpha, lane);          // cumprod(1 - alpha + 0)
+        float excl = __shfl_up(incl, 1);
+        if (lane == 0) excl = 1.0f;
+        const float wgt = alpha * (T_run * excl);                        // render_weights (:12-15)
+        if (live && weights) weights[ray * S + s] = wgt;
+        ar = fmaf(wgt, v.x, ar); ag = fmaf(wgt, v.y, ag); ab = fmaf(wgt, v.z, ab); aw += wgt;
+        T_run *= __shfl(incl, 63);
+    }
+    ar = wave_sum(ar); ag = wave_sum(ag); ab = wave_sum(ab); aw = wave_sum(aw);
+    if (lane == 0) {
+        rgb_map[ray * 3] = ar; rgb_map[ray * 3 + 1] = ag; rgb_map[ray * 3 + 2] = ab;
+        acc_map[ray] = aw;
+    }
+}
+
+int launch_composite(const float* raw, int64_t n_rays, int S, float* weights, float* rgb_map, float* acc_map, hipStream_t st) {
+    if (n_rays == 0) return 0;
+    DenseRaw src{reinterpret_cast<const float4*>(raw)};
+    hipLaunchKernelGGL(k_composite<DenseRaw>, dim3((unsigned)cdiv(n_rays, CMP_BLOCK / 64)), dim3(CMP_BLOCK), 0, st,
+                       src, n_rays, S, weights, rgb_map, acc_map, (float4*)nullptr, (float*)nullptr);
+    INVR_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_merge_composite(const RenderArgs& a, const Workspace& w, float* rgb_map, float* acc_map, float* raw,
+                           float* occ, float* weights, hipStream_t st) {
+    if (a.R == 0) return 0;
+    MergedRaw src{w.slot_of_sample, w.pflags, w.raws};
+    hipLaunchKernelGGL(k_composite<MergedRaw>, dim3((unsigned)cdiv(a.R, CMP_BLOCK / 64)), dim3(CMP_BLOCK), 0, st,
+                       src, a.R, a.S, weights, rgb_map, acc_map, reinterpret_cast<float4*>(raw), occ);
+    INVR_LAUNCH_CHECK();
+    return 0;
+}

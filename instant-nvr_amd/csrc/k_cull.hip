@@ -1,0 +1,136 @@
+// K0 + K1: ray sampling, world->pose, near-surface cull, ORDERED stream compaction.
+// Replaces inb_renderer.py:15-31 (get_wsampling_points) and
+// inb_part_network_multiassign.py:128-140 (world->pose, pnorm < smpl_thresh, nonzero, gathers)
+// without the host-syncing nonzero: three stream-ordered launches
+//   k_cull_flag   : one thread per ray-sample -> 64-bit survivor mask per wave + per-block count
+//   k_scan_blocks : exclusive scan of the block counts (one workgroup, 8192 counts per pass)
+//   k_compact     : rank = block offset + wave prefix + popcount(mask below lane) -> active list
+// The active list is in ray-major / sample-minor order, exactly the order torch.nonzero gives,
+// so the train-time (Na*P, .) layouts of resd/tpts/tocc keep the reference's row order.
+#include "pipeline.h"
+
+#define CULL_BLOCK 256
+
+__global__ __launch_bounds__(CULL_BLOCK) void k_cull_flag(RenderArgs a, Workspace w) {
+    int64_t i = (int64_t)blockIdx.x * CULL_BLOCK + threadIdx.x;
+    bool keep = false;
+    if (i < a.N) {
+        float px, py, pz, z;
+        sample_pose_point(a, i, px, py, pz, &z, nullptr);
+        if (a.z_vals) a.z_vals[i] = z;
+        float pn;
+        sample_volume_dev<1>(a.scene.pbw, a.scene.pbw.c - 1, px, py, pz, &pn);   // distance channel
+        keep = pn < a.scene.thresh;                                               // :135
+    }
+    unsigned long long m = __ballot(keep);
+    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) w.mask[(int64_t)blockIdx.x * (CULL_BLOCK / 64) + wv] = m;
+    __shared__ int cnt[CULL_BLOCK / 64];
+    if (lane == 0) cnt[wv] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int c = 0;
+#pragma unroll
+        for (int k = 0; k < CULL_BLOCK / 64; ++k) c += cnt[k];
+        w.block_cnt[blockIdx.x] = c;
+    }
+}
+
+#define SCAN_T 1024
+#define SCAN_PER 8
+__global__ __launch_bounds__(SCAN_T) void k_scan_blocks(Workspace w, int64_t nb, int64_t max_active) {
+    __shared__ int wsum[SCAN_T / 64];
+    __shared__ int carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int64_t base = 0; base < nb; base += SCAN_T * SCAN_PER) {
+        int64_t i0 = base + (int64_t)threadIdx.x * SCAN_PER;
+        int v[SCAN_PER];
+        int tot = 0;
+#pragma unroll
+        for (int k = 0; k < SCAN_PER; ++k) {
+            v[k] = (i0 + k < nb) ? w.block_cnt[i0 + k] : 0;
+            tot += v[k];
+        }
+        int x = tot;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            int y = __shfl_up(x, d);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) wsum[wv] = x;
+        __syncthreads();
+        int woff = 0;
+        for (int k = 0; k < wv; ++k) woff += wsum[k];
+        int carry = carry_s;
+        int run = carry + woff + x - tot;
+#pragma unroll
+        for (int k = 0; k < SCAN_PER; ++k) {
+            if (i0 + k < nb) w.block_off[i0 + k] = run;
+            run += v[k];
+        }
+        __syncthreads();
+        if (threadIdx.x == SCAN_T - 1) carry_s = run;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        int na = carry_s;
+        if ((int64_t)na > max_active) {
+            w.counters[CNT_OVERFLOW] = 1;
+            na = (int)max_active;
+        }
+        w.counters[CNT_ACTIVE] = na;
+    }
+}
+
+__global__ __launch_bounds__(CULL_BLOCK) void k_compact(RenderArgs a, Workspace w, int64_t max_active) {
+    int64_t i = (int64_t)blockIdx.x * CULL_BLOCK + threadIdx.x;
+    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned long long* mk = w.mask + (int64_t)blockIdx.x * (CULL_BLOCK / 64);
+    int off = w.block_off[blockIdx.x];
+    for (int k = 0; k < wv; ++k) off += __popcll(mk[k]);
+    unsigned long long m = mk[wv];
+    bool keep = (m >> lane) & 1ull;
+    int rank = off + __popcll(m & ((1ull << lane) - 1ull));
+    if (i < a.N) {
+        int slot = -1;
+        if (keep && rank < max_active) {
+            slot = rank;
+            w.active_idx[rank] = (int32_t)i;
+        }
+        w.slot_of_sample[i] = slot;
+    }
+}
+
+int launch_cull(const RenderArgs& a, const Workspace& w, int64_t max_active, hipStream_t st) {
+    int64_t nb = cdiv(a.N, CULL_BLOCK);
+    hipLaunchKernelGGL(k_cull_flag, dim3((unsigned)nb), dim3(CULL_BLOCK), 0, st, a, w);
+    INVR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(SCAN_T), 0, st, w, nb, max_active);
+    INVR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_compact, dim3((unsigned)nb), dim3(CULL_BLOCK), 0, st, a, w, max_active);
+    INVR_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- stand-alone volume sampler (invr_sample_volume; blend_utils.py:501-555) -------------------
+template <int NC>
+__global__ void k_sample_volume(VolDev v, int c0, const float* pts, int64_t n, float* out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float o[NC];
+    sample_volume_dev<NC>(v, c0, pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2], o);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) out[i * NC + c] = o[c];
+}
+
+int launch_sample_volume(const VolDev& v, int c0, int nc, const float* pts, int64_t n, float* out, hipStream_t st) {
+    if (n == 0) return 0;
+    dim3 g((unsigned)cdiv(n, 256)), b(256);
+    if (nc == 1) hipLaunchKernelGGL(k_sample_volume<1>, g, b, 0, st, v, c0, pts, n, out);
+    else if (nc == 2) hipLaunchKernelGGL(k_sample_volume<2>, g, b, 0, st, v, c0, pts, n, out);
+    else { invr_set_error("invr_sample_volume: nc must be 1 or 2 (got %d)", nc); return 1; }
+    INVR_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,170 @@
+// K5: multi-resolution hash-grid encoder.
+// Replaces HashEmbedder.forward (lib/networks/embedders/part_base_embedder.py:106-174).
+//
+// k_part_encode — the HBM-bound kernel of the path — handles the per-part grids
+// (16 levels x 16 features, sum over features): ONE WAVE encodes ONE POINT at a time with
+//      lane = level*4 + q        (level 0..15, q = which 16-byte quarter of the 64-byte row)
+// so every corner fetch is one global_load_dwordx4 per lane and the 4 lanes of a quad read one
+// whole, contiguous 64-byte table row: 16 fully-used 64-B segments per wave instruction, 8
+// instructions (corners) per point = the 8 KiB per (point,part) pair of SURVEY.md §8(d).
+// Each lane keeps a float4 accumulator over the 8 corners (4 FMAs per row), the 16 features are
+// summed with two quad-DPP adds, level results are staged per wave in LDS ([k][64 points]) and
+// flushed as coalesced 256-byte rows into the SoA embedding buffer the MLP kernel consumes.
+// Two points are processed per iteration to keep 16 row fetches in flight per wave.
+#include "pipeline.h"
+#include "grid_generic.h"
+
+// ---- generic thread-per-point encoder (API entry point; any configuration) ---------------------
+__global__ void k_grid_encode_rt(GridDev g, const float* xyz, int64_t n, float* out, int out_dim) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float x[3];
+    grid_normalise(g, xyz + i * 3, x);
+    float* o = out + i * out_dim;
+    int off = 0;
+    if (g.include_input) { o[0] = x[0]; o[1] = x[1]; o[2] = x[2]; off = 3; }
+    float tot[16];
+    for (int f = 0; f < 16; ++f) tot[f] = 0.0f;
+    for (int l = 0; l < g.L; ++l) {
+        int64_t rows[8];
+        float wts[8];
+        const float* tab = grid_level_lookup(g, l, x, rows, wts);
+        float acc[16];
+        for (int f = 0; f < 16; ++f) acc[f] = 0.0f;
+        for (int k = 0; k < 8; ++k)
+            for (int f = 0; f < g.F; ++f) acc[f] = fmaf(wts[k], tab[rows[k] * g.F + f], acc[f]);
+        if (!g.sum) {
+            for (int f = 0; f < g.F; ++f) o[off + l * g.F + f] = acc[f];
+        } else if (g.sum_over_features) {
+            float s = 0.0f;
+            for (int f = 0; f < g.F; ++f) s += acc[f];
+            o[off + l] = s;
+        } else {
+            for (int f = 0; f < g.F; ++f) tot[f] += acc[f];
+        }
+    }
+    if (g.sum && !g.sum_over_features)
+        for (int f = 0; f < g.F; ++f) o[off + f] = tot[f];
+}
+
+int launch_grid_encode_generic(const GridDev& g, const float* xyz, int64_t n, float* out, hipStream_t st) {
+    if (n == 0) return 0;
+    if (g.F > 16 || g.L > INVR_MAX_LEVELS) { invr_set_error("grid encoder: F<=16 and L<=16 required"); return 1; }
+    int od = (g.sum ? (g.sum_over_features ? g.L : g.F) : g.L * g.F) + (g.include_input ? 3 : 0);
+    hipLaunchKernelGGL(k_grid_encode_rt, dim3((unsigned)cdiv(n, 128)), dim3(128), 0, st, g, xyz, n, out, od);
+    INVR_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- wave-cooperative 16x16 part encoder ----------------------------------------------------------
+#define ENC_BLOCK 256
+#define ENC_WAVES (ENC_BLOCK / 64)
+
+__device__ __forceinline__ float rdlane(float v, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+__device__ __forceinline__ float quad_sum(float s) {
+    // quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E
+    s += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s), 0xB1, 0xF, 0xF, true));
+    s += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s), 0x4E, 0xF, 0xF, true));
+    return s;
+}
+
+struct LaneLevel {          // per-lane constants of "my" level
+    const float4* tab;      // level table base + q*16 bytes
+    int res;
+    float cell;
+    bool hashed;
+};
+
+// issue the 8 row fetches of one point for this lane's level
+__device__ __forceinline__ void fetch_point(const GridDev& g, const LaneLevel& L, float x, float y, float z,
+                                            float4* v, float* wts) {
+    int c0[3], c1[3];
+    float t[3];
+    level_corners(x, L.cell, L.res, c0[0], c1[0], t[0]);
+    level_corners(y, L.cell, L.res, c0[1], c1[1], t[1]);
+    level_corners(z, L.cell, L.res, c0[2], c1[2], t[2]);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int cx = (k & 4) ? c1[0] : c0[0], cy = (k & 2) ? c1[1] : c0[1], cz = (k & 1) ? c1[2] : c0[2];
+        const float wx = (k & 4) ? t[0] : 1.0f - t[0], wy = (k & 2) ? t[1] : 1.0f - t[1], wz = (k & 1) ? t[2] : 1.0f - t[2];
+        wts[k] = wx * wy * wz;
+        int64_t row;
+        if (L.hashed) row = hash_mod((uint32_t)cx, (uint32_t)cy, (uint32_t)cz, g.T, g.inv_T);
+        else row = (int64_t)cx * L.res * L.res + (int64_t)cy * L.res + cz;
+        v[k] = L.tab[row * 4];                                  // 16 floats per row = 4 float4
+    }
+}
+
+__device__ __forceinline__ float reduce_point(const float4* v, const float* wts) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        a.x = fmaf(wts[k], v[k].x, a.x); a.y = fmaf(wts[k], v[k].y, a.y);
+        a.z = fmaf(wts[k], v[k].z, a.z); a.w = fmaf(wts[k], v[k].w, a.w);
+    }
+    return quad_sum((a.x + a.y) + (a.z + a.w));
+}
+
+__global__ __launch_bounds__(ENC_BLOCK) void k_part_encode(GridDev g, const float* __restrict__ xs, int64_t stride,
+                                                           const int32_t* __restrict__ count, int64_t cap,
+                                                           float* __restrict__ emb) {
+    __shared__ float semb[ENC_WAVES][EMB_K][64];
+    const int cnt = *count;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int level = lane >> 2, q = lane & 3;
+    LaneLevel L;
+    L.res = g.res[level];
+    L.cell = g.cell[level];
+    L.hashed = level >= g.start_hash;
+    const float* tb = g.separate_dense
+        ? (L.hashed ? g.hash + (int64_t)(level - g.start_hash) * g.T * 16 : g.dense + g.dense_off[level] * 16)
+        : g.hash + (int64_t)level * g.T * 16;
+    L.tab = reinterpret_cast<const float4*>(tb) + q;
+    const float b0x = g.bounds[0], b0y = g.bounds[1], b0z = g.bounds[2];
+    const float ex = g.bounds[3] - b0x, ey = g.bounds[4] - b0y, ez = g.bounds[5] - b0z;
+
+    for (int64_t tile = (int64_t)blockIdx.x * ENC_WAVES + wv; tile * 64 < cnt; tile += (int64_t)gridDim.x * ENC_WAVES) {
+        const int64_t base = tile * 64;
+        const int m = (int)min((int64_t)64, cnt - base);
+        // lane i holds the normalised coordinates of point base+i (:112)
+        const int64_t pi = base + min(lane, m - 1);
+        const float xi = (xs[pi] - b0x) / ex;
+        const float yi = (xs[stride + pi] - b0y) / ey;
+        const float zi = (xs[2 * stride + pi] - b0z) / ez;
+        semb[wv][0][lane] = xi; semb[wv][1][lane] = yi; semb[wv][2][lane] = zi;
+        semb[wv][EMB_K - 1][lane] = 0.0f;                        // pad column
+        for (int j = 0; j < m; j += 2) {
+            const int j1 = min(j + 1, m - 1);
+            float4 va[8], vb[8];
+            float wa[8], wb[8];
+            fetch_point(g, L, rdlane(xi, j), rdlane(yi, j), rdlane(zi, j), va, wa);
+            fetch_point(g, L, rdlane(xi, j1), rdlane(yi, j1), rdlane(zi, j1), vb, wb);
+            const float sa = reduce_point(va, wa);
+            const float sb = reduce_point(vb, wb);
+            if (q == 0) {
+                semb[wv][3 + level][j] = sa;
+                semb[wv][3 + level][j1] = sb;
+            }
+        }
+        // flush [k][point] rows, coalesced (wave-private LDS region: no workgroup barrier needed)
+        if (lane < m) {
+#pragma unroll
+            for (int k = 0; k < EMB_K; ++k) emb[(int64_t)k * cap + base + lane] = semb[wv][k][lane];
+        }
+    }
+}
+
+int launch_part_encode(const GridDev& g, const float* x_soa, int64_t stride, const int32_t* count, int64_t cap,
+                       float* emb, hipStream_t st) {
+    if (g.L != 16 || g.F != 16 || !g.sum || !g.sum_over_features || !g.include_input) {
+        invr_set_error("part encoder kernel supports n_levels=16, n_features_per_level=16, sum, sum_over_features, include_input (got L=%d F=%d)", g.L, g.F);
+        return 1;
+    }
+    int64_t tiles = cdiv(cap, 64 * ENC_WAVES);
+    unsigned grid = (unsigned)(tiles < 256 * 8 ? (tiles > 0 ? tiles : 1) : 256 * 8);
+    hipLaunchKernelGGL(k_part_encode, dim3(grid), dim3(ENC_BLOCK), 0, st, g, x_soa, stride, count, cap, emb);
+    INVR_LAUNCH_CHECK();
+    return 0;
+}

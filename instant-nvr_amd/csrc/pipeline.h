@@ -1,0 +1,96 @@
+// Internal data layout of one invr_render_fwd call: kernel argument blocks and the workspace carve.
+#pragma once
+#include "common.h"
+
+enum { CNT_ACTIVE = 0, CNT_PAIRS = 1 /* ..5 */, CNT_OVERFLOW = 6, CNT_LEN = 16 };
+
+#define EMB_K 20            // 19-d encoder output padded to 5 MFMA k-steps
+
+struct RenderArgs {
+    SceneDev scene;
+    const float* ray_o;
+    const float* ray_d;
+    const float* near;
+    const float* far;
+    const float* jitter;     // (R,S) or null
+    float* z_vals;           // (R,S) or null
+    int64_t R;               // rays
+    int32_t S;               // samples per ray
+    int64_t N;               // R*S
+};
+
+// All arrays live in the caller-provided workspace (HBM).  cap = max_active.
+struct Workspace {
+    unsigned long long* mask;     // ceil(N/64): survivor bit per ray-sample
+    int32_t* block_cnt;           // ceil(N/256)
+    int32_t* block_off;           // ceil(N/256)
+    int32_t* counters;            // CNT_LEN
+    int32_t* active_idx;          // cap: ray-sample index of every survivor (ordered)
+    int32_t* slot_of_sample;      // N: survivor slot or -1
+    uint8_t* pflags;              // cap: bit p set if (slot, part p) is flagged
+    float* part_aabb;             // P*6: posed-vertex AABB per part
+    // per-part pair lists, SoA, each of capacity cap
+    int32_t* l_slot[INVR_NUM_PARTS];      // cap
+    int32_t* l_nn[INVR_NUM_PARTS];        // cap*4 : neighbour rows inside part_pbw[p]
+    float* l_w[INVR_NUM_PARTS];           // cap*4 : normalised gaussian weights
+    float* l_x[INVR_NUM_PARTS];           // 3*cap : canonical (big-pose + residual) xyz, SoA
+    float* l_d[INVR_NUM_PARTS];           // 3*cap : canonical view dir, SoA
+    float* emb[2];                        // EMB_K*cap : encoder output, SoA [k][pair] (ping-pong)
+    float4* raws;                         // cap*P : [rgb, occ] per (slot, part)
+    int64_t cap;
+};
+
+// ---- z / pose-space point of a ray-sample (inb_renderer.py:17-29, blend_utils.py:366-382) ----
+__device__ __forceinline__ float sample_z(float near, float far, int s, int S, const float* jit_row) {
+    float t = linspace01(s, S);
+    float z = near * (1.0f - t) + far * t;
+    if (jit_row) {   // stratified jitter between the mid-points of neighbouring samples (:20-27)
+        float tp = linspace01(max(s - 1, 0), S), tn = linspace01(min(s + 1, S - 1), S);
+        float zp = near * (1.0f - tp) + far * tp, zn = near * (1.0f - tn) + far * tn;
+        float upper = (s == S - 1) ? z : 0.5f * (zn + z);
+        float lower = (s == 0) ? z : 0.5f * (z + zp);
+        z = lower + (upper - lower) * jit_row[s];
+    }
+    return z;
+}
+
+__device__ __forceinline__ void sample_pose_point(const RenderArgs& a, int64_t i, float& px, float& py,
+                                                  float& pz, float* zout, float* pdir) {
+    int64_t ray = i / a.S;
+    int s = (int)(i - ray * a.S);
+    float near = a.near[ray], far = a.far[ray];
+    float z = sample_z(near, far, s, a.S, a.jitter ? a.jitter + ray * a.S : nullptr);
+    if (zout) *zout = z;
+    float ox = a.ray_o[ray * 3 + 0], oy = a.ray_o[ray * 3 + 1], oz = a.ray_o[ray * 3 + 2];
+    float dx = a.ray_d[ray * 3 + 0], dy = a.ray_d[ray * 3 + 1], dz = a.ray_d[ray * 3 + 2];
+    float wx = ox + dx * z, wy = oy + dy * z, wz = oz + dz * z;          // pts = o + d*z
+    const float* R = a.scene.R;
+    const float* Th = a.scene.Th;
+    float qx = wx - Th[0], qy = wy - Th[1], qz = wz - Th[2];             // (p - Th) @ R
+    px = qx * R[0] + qy * R[3] + qz * R[6];
+    py = qx * R[1] + qy * R[4] + qz * R[7];
+    pz = qx * R[2] + qy * R[5] + qz * R[8];
+    if (pdir) {                                                          // viewdir @ R
+        pdir[0] = dx * R[0] + dy * R[3] + dz * R[6];
+        pdir[1] = dx * R[1] + dy * R[4] + dz * R[7];
+        pdir[2] = dx * R[2] + dy * R[5] + dz * R[8];
+    }
+}
+
+// ---- pipeline stage launchers ------------------------------------------------------------------
+int launch_cull(const RenderArgs& a, const Workspace& w, int64_t max_active, hipStream_t st);
+int launch_knn_pairs(const RenderArgs& a, const Workspace& w, hipStream_t st);
+int launch_warp_pairs(const RenderArgs& a, const Workspace& w, const GridDev& dg, const MlpDev& dm, hipStream_t st);
+int launch_part_encode(const GridDev& g, const float* x_soa, int64_t stride, const int32_t* count, int64_t cap,
+                       float* emb, hipStream_t st);
+struct PartMlpDev {
+    MlpDev occ, rgb;
+    const float* rgb_latent;
+    const int64_t* latent_index;
+    int32_t latent_dim, n_freq, geo_dim;
+};
+int launch_part_mlp(const PartMlpDev& pm, const float* emb, const float* d_soa, int64_t stride,
+                    const int32_t* l_slot, const int32_t* count, int64_t cap, float4* raws, int part,
+                    float4* raw_direct, hipStream_t st);
+int launch_merge_composite(const RenderArgs& a, const Workspace& w, float* rgb_map, float* acc_map, float* raw,
+                           float* occ, float* weights, hipStream_t st);

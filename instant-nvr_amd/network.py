@@ -1,0 +1,189 @@
+"""Host-side mirror of the reference's network plug-in (lib/networks/bw_deform/
+inb_part_network_multiassign.py:68-256, part_base_network.py:11-63, embedders/
+part_base_embedder.py:13-104, embedders/freq_embedder.py:5-43, deformers/uv_deformer.py:12-21).
+
+These are ``nn.Module`` containers only: they own the parameters under the reference's exact
+attribute names (so ``state_dict()`` / ``load_state_dict()`` interchange ``.pth`` files with the
+reference) and hand raw device pointers to libinvr.so.  All arithmetic of the path runs in the
+HIP kernels; there is no PyTorch fallback.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _abi, params
+from .config import cfg as global_cfg, PART_NAMES, NUM_PARTS
+
+
+class Embedder(nn.Module):
+    """Parameter container of one multi-resolution grid (part_base_embedder.py:13-104)."""
+
+    def __init__(self, spec, pid=-1, partname='undefined'):
+        super().__init__()
+        self.spec, self.pid, self.partname = spec, pid, partname
+        L, F, T = spec['L'], spec['F'], spec['T']
+        ng = dict(requires_grad=False)
+        self.bounds = nn.Parameter(torch.from_numpy(spec['bbox'].copy()), **ng)
+        self.entries_size = nn.Parameter(torch.from_numpy(spec['size'].copy()), **ng)
+        self.entries_num = nn.Parameter(torch.tensor(spec['res'], dtype=torch.int64), **ng)
+        self.entries_min = nn.Parameter(torch.zeros(L, dtype=torch.int64), **ng)
+        self.entries_cnt = nn.Parameter(torch.tensor(spec['cnt'], dtype=torch.int64), **ng)
+        self.entries_sum = nn.Parameter(torch.tensor(spec['cnt'], dtype=torch.int64).cumsum(0), **ng)
+        self.start_hash, self.n_levels, self.f, self.out_dim = spec['start_hash'], L, F, spec['out_dim']
+        self.n_entries_per_level = T
+        self.separate_dense = spec['separate_dense']
+        self.use_batch_bounds = spec['use_batch_bounds']
+        if self.separate_dense:
+            data = torch.zeros((L, T, F))
+            nn.init.kaiming_normal_(data)                    # one (L,T,F) init, then split (:70-76)
+            self.dense = nn.Parameter(torch.cat([data[i, :spec['cnt'][i]] for i in range(self.start_hash)], 0))
+            self.hash = nn.Parameter(data[self.start_hash:].clone())
+        else:
+            self.hash = nn.Parameter(torch.zeros((L, T, F)))
+            nn.init.kaiming_normal_(self.hash)
+        self.offsets = nn.Parameter(torch.from_numpy(params.CORNER_OFFSETS.copy()), **ng)
+
+    def maybe_adopt_batch_bounds(self, batch):
+        # part_base_embedder.py:107-109: bounds are re-created from the batch at iter_step == 1
+        if self.use_batch_bounds and 'iter_step' in batch and batch['iter_step'] == 1:
+            self.bounds = nn.Parameter(batch['bounds'][0][self.pid].detach().clone(), requires_grad=False)
+
+    def grid_struct(self, keep):
+        return _abi.make_grid(self.spec, self.dense if self.separate_dense else None, self.hash, self.bounds, keep)
+
+    def forward(self, xyz, batch=None):
+        """HashEmbedder.forward (:106-174) through invr_grid_encode_fwd."""
+        if batch is not None:
+            self.maybe_adopt_batch_bounds(batch)
+        keep = []
+        g = self.grid_struct(keep)
+        x = xyz.detach().to(torch.float32).contiguous()
+        out = torch.empty(x.shape[0], self.out_dim, device=x.device, dtype=torch.float32)
+        _abi.check(_abi.lib().invr_grid_encode_fwd(C.byref(g), _abi.ptr(x), x.shape[0], _abi.ptr(out), _abi.stream_ptr()))
+        return out
+
+
+class _PosEnc(nn.Module):
+    def __init__(self, multires):
+        super().__init__()
+        fb = 2. ** torch.linspace(0., multires - 1, steps=multires)
+        self.freq_bands = nn.Parameter(fb[..., None, None].expand(multires, 2, 1).clone(), requires_grad=False)
+        self.multires = multires
+
+
+class DirEmbedder(nn.Module):
+    """freq_embedder.Embedder container (:38-43); evaluated inside the part MLP kernel."""
+
+    def __init__(self, res, input_dims=3):
+        super().__init__()
+        self.embedder = _PosEnc(res)
+        self.out_dim = input_dims + input_dims * 2 * res
+
+
+class MLP(nn.Module):
+    """part_base_network.MLP container (:11-24)."""
+
+    def __init__(self, indim=16, outdim=3, d_hidden=64, n_layers=2):
+        super().__init__()
+        self.indim, self.outdim = indim, outdim
+        self.linears = nn.ModuleList([nn.Linear(indim, d_hidden)] + [nn.Linear(d_hidden, d_hidden) for _ in range(n_layers - 1)]
+                                     + [nn.Linear(d_hidden, outdim)])
+        self.actvn = nn.Softplus()
+
+
+ColorNetwork = MLP
+
+
+class PartNetwork(nn.Module):
+    """part_base_network.Network container (:31-42)."""
+
+    def __init__(self, partname, pid, cfg=None):
+        super().__init__()
+        cfg = cfg or global_cfg
+        self.pid, self.partname = pid, partname
+        self.embedder = Embedder(params.part_grid_spec(cfg, partname), pid, partname)
+        self.embedder_dir = DirEmbedder(**cfg.viewdir_embedder.kwargs)
+        occ_dims, rgb_dims = params.mlp_dims(cfg, partname)
+        self.occ = MLP(occ_dims[0], occ_dims[-1], cfg.network.occ['d_hidden'], cfg.network.occ['n_layers'])
+        self.rgb_latent = nn.Parameter(torch.zeros(cfg.num_latent_code, cfg.latent_code_dim))
+        nn.init.kaiming_normal_(self.rgb_latent)
+        ck = cfg.partnet[partname].color_network.kwargs
+        self.rgb = ColorNetwork(rgb_dims[0], 3, ck['d_hidden'], ck['n_layers'])
+
+
+class Deformer(nn.Module):
+    """uv_deformer.Deformer container (:12-21)."""
+
+    def __init__(self, cfg=None):
+        super().__init__()
+        cfg = cfg or global_cfg
+        self.embedder = Embedder(params.deformer_grid_spec(cfg))
+        self.mlp = nn.Sequential(nn.Linear(self.embedder.out_dim, 32), nn.Softplus(), nn.Linear(32, 32),
+                                 nn.Softplus(), nn.Linear(32, 3))
+
+
+class TPoseHuman(nn.Module):
+    def __init__(self, cfg=None):
+        super().__init__()
+        self.part_networks = nn.ModuleList([PartNetwork(p, i, cfg) for i, p in enumerate(PART_NAMES)])
+
+
+class Network(nn.Module):
+    """Drop-in for inb_part_network_multiassign.Network (:68-168)."""
+
+    def __init__(self, init_network=True, cfg=None):
+        super().__init__()
+        self.cfg = cfg or global_cfg
+        self.tpose_deformer = Deformer(self.cfg)
+        self.tpose_human = TPoseHuman(self.cfg)
+        self._ws = None
+
+    # -- C-ABI glue ---------------------------------------------------------------------------
+    def model_struct(self, keep):
+        sd = {k: v for k, v in self.named_parameters()}
+        return _abi.make_model(sd, self.cfg, keep)
+
+    def workspace(self, nbytes, device):
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        return self._ws
+
+    def adopt_batch_bounds(self, batch):
+        for pn in self.tpose_human.part_networks:
+            pn.embedder.maybe_adopt_batch_bounds(batch)
+
+    def render_rays(self, batch, ray_o, ray_d, near, far, n_samples, jitter=None, want_raw=True,
+                    want_weights=False, max_active=0):
+        """One invr_render_fwd call over a ray list (n,3)/(n,).  Returns a dict of device tensors."""
+        L = _abi.lib()
+        dev = ray_o.device
+        self.adopt_batch_bounds(batch)
+        keep = []
+        model = self.model_struct(keep)
+        scene = _abi.make_scene(batch, self.cfg, keep)
+        f = lambda t: t.detach().to(torch.float32).contiguous()
+        ray_o, ray_d, near, far = f(ray_o), f(ray_d), f(near), f(far)
+        n = ray_o.shape[0]
+        S = int(n_samples)
+        out = {'rgb_map': torch.empty(n, 3, device=dev), 'acc_map': torch.empty(n, device=dev),
+               'stats': torch.zeros(_abi.STATS_LEN, dtype=torch.int32, device=dev)}
+        if want_raw:
+            out['raw'] = torch.empty(n * S, 4, device=dev)
+            out['occ'] = torch.empty(n * S, device=dev)
+        if want_weights:
+            out['weights'] = torch.empty(n, S, device=dev)
+            out['z_vals'] = torch.empty(n, S, device=dev)
+        if jitter is not None:
+            jitter = f(jitter)
+        nbytes = L.invr_workspace_bytes(n, S, max_active)
+        ws = self.workspace(nbytes, dev)
+        _abi.check(L.invr_render_fwd(
+            C.byref(scene), C.byref(model), _abi.ptr(ray_o), _abi.ptr(ray_d), _abi.ptr(near), _abi.ptr(far),
+            _abi.ptr(jitter), n, S, _abi.ptr(out['rgb_map']), _abi.ptr(out['acc_map']),
+            _abi.ptr(out.get('raw')), _abi.ptr(out.get('occ')), _abi.ptr(out.get('weights')),
+            _abi.ptr(out.get('z_vals')), _abi.ptr(out['stats'], torch.int32),
+            C.c_void_p(ws.data_ptr()), nbytes, max_active, _abi.stream_ptr()))
+        out['_keep'] = keep
+        return out

@@ -1,0 +1,56 @@
+"""CPU: the C-ABI shared library loads and exports every symbol include/invr.h declares
+(no compute calls: there is no GPU here)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, 'include', 'invr.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(invr_[a-z_0-9]+)\s*\(', src)))
+
+
+def test_library_exports_header_symbols():
+    from invr import _abi
+    if not os.path.exists(_abi.LIB_PATH):
+        import __graft_entry__ as ge
+        ge.build()
+    L = _abi.lib()
+    names = declared_symbols()
+    assert len(names) >= 10
+    for n in names:
+        assert hasattr(L, n), n
+    assert sorted(_abi.EXPORTS) == names
+    assert L.invr_version() == 1
+
+
+def test_workspace_query_and_error_path():
+    from invr import _abi
+    L = _abi.lib()
+    small = L.invr_workspace_bytes(4096, 64, 0)
+    big = L.invr_workspace_bytes(8192, 64, 0)
+    capped = L.invr_workspace_bytes(8192, 64, 1000)
+    assert 0 < small < big and capped < big
+    # argument errors are reported through the status code + invr_last_error (no exceptions, no GPU touched)
+    import ctypes as C
+    st = L.invr_render_fwd(None, None, None, None, None, None, None, 1, 8, None, None, None, None, None, None, None,
+                           None, 0, 0, None)
+    assert st != 0 and b'null' in L.invr_last_error()
+    st = L.invr_composite_fwd(None, 4, 0, None, None, None, None)
+    assert st != 0
+
+
+def test_struct_sizes_match_header():
+    """ctypes mirrors must have the C layout (checked against sizes computed from the header's field lists)."""
+    import ctypes as C
+    from invr import _abi
+    assert C.sizeof(_abi.InvrGrid) == 3 * 8 + 4 * 4 + 8 + 16 * 4 + 16 * 4 + 16 * 8 + 3 * 4 + 4
+    assert C.sizeof(_abi.InvrMlp) == 8 * 8 + 5 * 4 + 4
+    assert C.sizeof(_abi.InvrPart) == C.sizeof(_abi.InvrGrid) + 2 * C.sizeof(_abi.InvrMlp) + 8 + 8
+    L = _abi.lib()
+    for i, t in enumerate((_abi.InvrGrid, _abi.InvrMlp, _abi.InvrPart, _abi.InvrModel, _abi.InvrScene)):
+        assert L.invr_sizeof(i) == C.sizeof(t), t

@@ -1,0 +1,187 @@
+"""GPU parity: the HIP path, called through the C-ABI (libinvr.so), against the oracle and the
+golden vectors of the imported reference.  fp32 tolerance stated per test; integer / index
+results (cull mask, pflag) must match exactly except at measure-zero threshold ties, which are
+detected through the oracle's decision margin and excluded explicitly."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import nvr_oracle as O          # noqa: E402  (checker only)
+from invr import _abi, params               # noqa: E402
+from invr.network import Network            # noqa: E402
+from invr.renderer import Renderer          # noqa: E402
+
+DEV = 'cuda:0'
+
+
+def cu(x):
+    return (torch.from_numpy(np.ascontiguousarray(x)) if isinstance(x, np.ndarray) else x).to(DEV)
+
+
+@pytest.fixture(scope='module')
+def gpu_setup(small_setup):
+    cfg, sd, batch, extras = small_setup
+    net = Network(cfg=cfg)
+    net.load_state_dict(sd, strict=True)
+    net = net.to(DEV).eval()
+    gb = {k: v.to(DEV) for k, v in batch.items()}
+    return cfg, sd, batch, gb, net
+
+
+def maxerr(a, b):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else a
+    b = b.detach().cpu().numpy() if torch.is_tensor(b) else b
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float(np.abs(a - b).max()) if a.size else 0.0
+
+
+def test_state_dict_layout(gpu_setup):
+    cfg, sd, _, _, net = gpu_setup
+    mine = net.state_dict()
+    assert list(mine.keys()) == list(sd.keys())
+    for k in sd:
+        assert mine[k].shape == sd[k].shape and mine[k].dtype == sd[k].dtype, k
+
+
+def test_sample_volume(gpu_setup, golden):
+    cfg, sd, batch, gb, net = gpu_setup
+    L = _abi.lib()
+    pts = cu(golden['pose_pts'][0])
+    vol = gb['pbw'][0].contiguous()
+    dims = (C.c_int32 * 3)(*vol.shape[:3])
+    out = torch.empty(pts.shape[0], 1, device=DEV)
+    _abi.check(L.invr_sample_volume(_abi.ptr(vol), dims, vol.shape[3], vol.shape[3] - 1, 1,
+                                    _abi.ptr(gb['pbounds'][0].contiguous()), _abi.ptr(pts), pts.shape[0],
+                                    _abi.ptr(out), _abi.stream_ptr()))
+    assert maxerr(out[:, 0], golden['pnorm']) < 1e-6
+    up = cu(golden['uv_pts'][0])
+    tuv = gb['tuv'][0].contiguous()
+    dims = (C.c_int32 * 3)(*tuv.shape[:3])
+    out = torch.empty(up.shape[0], 2, device=DEV)
+    _abi.check(L.invr_sample_volume(_abi.ptr(tuv), dims, 2, 0, 2, _abi.ptr(gb['tbounds'][0].contiguous()),
+                                    _abi.ptr(up), up.shape[0], _abi.ptr(out), _abi.stream_ptr()))
+    assert maxerr(out.t()[None], golden['uv_out']) < 1e-6
+
+
+def test_grid_encoder_variants(gpu_setup, golden):
+    cfg, sd, batch, gb, net = gpu_setup
+    for tag, pid in (('body', 0), ('head', 2)):
+        y = net.tpose_human.part_networks[pid].embedder(cu(golden['emb_%s_x' % tag]))
+        assert maxerr(y, golden['emb_%s_y' % tag]) < 1e-5, tag
+    y = net.tpose_deformer.embedder(cu(golden['emb_deform_x']))
+    assert maxerr(y, golden['emb_deform_y']) < 1e-5
+    # start_hash == 0: one (L,T,F) table, sum over levels
+    kw = dict(n_levels=6, n_features_per_level=4, log2_hashmap_size=8, base_resolution=8, b=1.38,
+              sum=True, sum_over_features=False, separate_dense=True, use_batch_bounds=False)
+    sp = params.grid_spec(bbox=[[-1, -1, -1], [1, 2, 1]], **kw)
+    tab = (np.random.RandomState(11).standard_normal((sp['L'], sp['T'], sp['F'])) * 0.1).astype(np.float32)
+    keep = []
+    g = _abi.make_grid(sp, None, cu(tab), cu(sp['bbox']), keep)
+    x = cu(golden['emb_allhash_x'])
+    out = torch.empty(x.shape[0], sp['out_dim'], device=DEV)
+    _abi.check(_abi.lib().invr_grid_encode_fwd(C.byref(g), _abi.ptr(x), x.shape[0], _abi.ptr(out), _abi.stream_ptr()))
+    assert maxerr(out, golden['emb_allhash_y']) < 1e-5
+
+
+def test_knn_blend(gpu_setup, golden):
+    cfg, sd, batch, gb, net = gpu_setup
+    keep = []
+    scene = _abi.make_scene(gb, cfg, keep)
+    ap = cu(golden['pose_pts'][0][golden['active_idx']])
+    n = ap.shape[0]
+    bw = torch.empty(n, 5, 24, device=DEV)
+    dist = torch.empty(n, 5, device=DEV)
+    _abi.check(_abi.lib().invr_knn_blend(C.byref(scene), _abi.ptr(ap), n, _abi.ptr(bw), _abi.ptr(dist), _abi.stream_ptr()))
+    ref = golden['knn_bw'][0]
+    assert maxerr(bw, ref[..., :24]) < 2e-6
+    assert maxerr(dist, ref[..., 24]) < 2e-6
+    margin = np.abs(ref[..., 24] - cfg.smpl_thresh)
+    flag = (dist.cpu().numpy() < cfg.smpl_thresh)
+    ok = (flag == golden['pflag'][0]) | (margin < 1e-6)
+    assert ok.all()
+
+
+def test_warp_deform(gpu_setup, golden):
+    cfg, sd, batch, gb, net = gpu_setup
+    keep = []
+    scene = _abi.make_scene(gb, cfg, keep)
+    model = net.model_struct(keep)
+    act = golden['active_idx']
+    ap = cu(golden['pose_pts'][0][act])
+    S = cfg.N_samples
+    rd = batch['ray_d'][0][torch.from_numpy(golden['sel_rays'].astype(np.int64))]
+    pd = O.world_dirs_to_pose(rd[:, None].expand(-1, S, -1).reshape(-1, 3), batch['R'][0])
+    pd = pd[torch.from_numpy(act.astype(np.int64))]
+    bw = cu(golden['knn_bw'][0][..., :24].copy())
+    flag = cu(golden['pflag'][0].astype(np.uint8))
+    n = ap.shape[0]
+    tp = torch.empty(n, 5, 3, device=DEV)
+    td = torch.empty(n, 5, 3, device=DEV)
+    rs = torch.empty(n, 5, 3, device=DEV)
+    _abi.check(_abi.lib().invr_warp_deform(C.byref(scene), C.byref(model), _abi.ptr(ap), _abi.ptr(cu(pd).contiguous()),
+                                           _abi.ptr(bw), _abi.ptr(flag, torch.uint8), n, _abi.ptr(tp), _abi.ptr(td),
+                                           _abi.ptr(rs), _abi.stream_ptr()))
+    assert maxerr(tp[None], golden['tpose']) < 1e-5
+    assert maxerr(td[None], golden['tpose_dirs']) < 1e-5
+    assert maxerr(rs[None], golden['resd']) < 2e-6
+
+
+def test_part_fields(gpu_setup, golden):
+    cfg, sd, batch, gb, net = gpu_setup
+    L = _abi.lib()
+    keep = []
+    model = net.model_struct(keep)
+    li = gb['latent_index'].reshape(-1)[:1].to(torch.int64).contiguous()
+    pflag = golden['pflag'][0]
+    for pid in range(5):
+        f = pflag[:, pid]
+        tp = cu(golden['tpose'][0][f, pid].copy())
+        td = cu(golden['tpose_dirs'][0][f, pid].copy())
+        n = tp.shape[0]
+        raw = torch.empty(n, 4, device=DEV)
+        nb = L.invr_part_field_workspace(n)
+        ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+        _abi.check(L.invr_part_field_fwd(C.byref(model), pid, _abi.ptr(li, torch.int64), _abi.ptr(tp), _abi.ptr(td), n,
+                                         _abi.ptr(raw), C.c_void_p(ws.data_ptr()), nb, _abi.stream_ptr()))
+        assert maxerr(raw, golden['part%d_raw' % pid]) < 2e-5, pid
+
+
+def test_composite_random(gpu_setup):
+    g = torch.Generator().manual_seed(4)
+    for R, S in ((1, 1), (7, 5), (33, 64), (20, 128), (9, 200)):
+        raw = torch.rand(R, S, 4, generator=g)
+        raw[..., 3] = raw[..., 3] * (torch.rand(R, S, generator=g) < 0.4)
+        w, rgb, acc = O.composite(raw[..., :3], raw[..., 3])
+        rg = cu(raw).contiguous()
+        wo = torch.empty(R, S, device=DEV)
+        ro = torch.empty(R, 3, device=DEV)
+        ao = torch.empty(R, device=DEV)
+        _abi.check(_abi.lib().invr_composite_fwd(_abi.ptr(rg), R, S, _abi.ptr(wo), _abi.ptr(ro), _abi.ptr(ao), _abi.stream_ptr()))
+        assert maxerr(wo, w) < 2e-6 and maxerr(ro, rgb) < 5e-6 and maxerr(ao, acc) < 5e-6
+
+
+def test_render_64x64x32_vs_reference_golden(gpu_setup, golden):
+    """BASELINE config 1 through Renderer.render (eval): <= 1e-4 per pixel vs the reference."""
+    cfg, sd, batch, gb, net = gpu_setup
+    r = Renderer(net)
+    ret = r.render(dict(gb))
+    assert set(ret.keys()) == {'rgb_map', 'acc_map', 'raw', 'occ'}
+    assert all(not v.is_cuda for v in ret.values())                       # reference moves eval outputs to CPU
+    assert ret['raw'].shape == (1, gb['ray_o'].shape[1] * cfg.N_samples, 4)
+    assert ret['occ'].shape == (1, gb['ray_o'].shape[1] * cfg.N_samples, 1)
+    stats = r.last_stats.cpu().numpy()
+    assert stats[6] == 0
+    assert int(stats[0]) == int(golden['render_n_active_samples'])
+    err = np.abs(ret['rgb_map'].numpy() - golden['render_rgb_map']).max(-1)[0]
+    assert int((err > 1e-4).sum()) == 0, float(err.max())
+    assert maxerr(ret['acc_map'], golden['render_acc_map']) < 1e-4
+    raw = ret['raw'][0].numpy()
+    nz = golden['render_raw_nz_idx']
+    assert np.abs(raw[nz] - golden['render_raw_nz']).max() < 1e-4
+    mask = np.ones(raw.shape[0], bool)
+    mask[nz] = False
+    assert np.abs(raw[mask]).max() == 0.0                                 # untouched samples are exact zeros
