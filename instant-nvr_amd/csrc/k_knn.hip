@@ -6,9 +6,10 @@
 // One thread per query point, 256 points per workgroup; the part's vertices stream through LDS in
 // 2048-vertex tiles and are read as wave-uniform (broadcast) ds_read_b128, so the inner loop is
 // 3 sub + 3 mul/add + 1 compare per vertex with a rarely-taken sorted-insert branch.
-// In the render pipeline a whole workgroup skips a part when every one of its points is at least
-// smpl_thresh away from that part's vertex AABB: then dist >= thresh, the pair is unflagged and
-// nothing downstream reads it (inb_part_network_multiassign.py:90, :203-206).
+// NOTE (reference quirk that parity depends on): the weights are normalised by (sum + 1e-8)
+// (blend_utils.py:748), so for a part further than ~0.5 m the gaussian weights underflow against
+// the epsilon, the "weighted distance" tends to 0 and the pair IS flagged (dist < smpl_thresh) with
+// near-zero blend weights.  Far parts therefore cannot be culled by distance.
 #include "pipeline.h"
 
 #define KNN_BLOCK 256
@@ -142,13 +143,6 @@ __global__ __launch_bounds__(KNN_BLOCK) void k_knn_pairs(RenderArgs a, Workspace
         if (live) sample_pose_point(a, w.active_idx[slot], px, py, pz, nullptr, nullptr);
         unsigned flags = 0;
         for (int p = 0; p < INVR_NUM_PARTS; ++p) {
-            // lower bound of the distance to any vertex of part p
-            const float* bb = w.part_aabb + p * 6;
-            float ex = fmaxf(fmaxf(bb[0] - px, px - bb[3]), 0.0f);
-            float ey = fmaxf(fmaxf(bb[1] - py, py - bb[4]), 0.0f);
-            float ez = fmaxf(fmaxf(bb[2] - pz, pz - bb[5]), 0.0f);
-            bool near = live && (ex * ex + ey * ey + ez * ez) < a.scene.thresh * a.scene.thresh * 1.0001f;
-            if (!__syncthreads_or(near)) continue;           // workgroup-uniform skip
             int len = (int)a.scene.lengths2[p];
             Top4 t;
             knn_scan_part(a.scene.part_pts + (int64_t)p * a.scene.M * 3, len, px, py, pz, t, sv);
