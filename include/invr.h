@@ -136,6 +136,21 @@ int invr_render_fwd(const InvrScene* scene, const InvrModel* model,
                     float* z_vals, int32_t* stats,
                     void* workspace, size_t workspace_bytes, int64_t max_active, void* stream);
 
+/* ---- per-stage timing with HIP events on the caller's stream ----------------------------------
+ * invr_profile_enable(1) makes every following invr_render_fwd record a hipEvent before/after each
+ * stage (on the stream the kernels are launched on).  invr_profile_read() waits for the recorded
+ * events, ADDS the elapsed milliseconds of every render since the last read to ms[stage], stores the
+ * number of renders in *n_renders and clears the record.  Stages: see INVR_STAGE_*. */
+#define INVR_STAGE_CULL 0
+#define INVR_STAGE_KNN 1
+#define INVR_STAGE_WARP 2
+#define INVR_STAGE_ENCODE 3       /* +part (3..7)  */
+#define INVR_STAGE_MLP 8          /* +part (8..12) */
+#define INVR_STAGE_COMPOSITE 13
+#define INVR_NUM_STAGES 14
+int invr_profile_enable(int32_t on);
+int invr_profile_read(float* ms, int32_t* n_renders);
+
 /* ---- stage-level entry points (each is also a step of invr_render_fwd) ---------------------- */
 
 /* HashEmbedder.forward (part_base_embedder.py:106-174).  xyz (n,3) -> out (n,out_dim). */

@@ -54,7 +54,10 @@ class InvrScene(C.Structure):
 
 EXPORTS = ['invr_last_error', 'invr_version', 'invr_sizeof', 'invr_workspace_bytes', 'invr_render_fwd',
            'invr_grid_encode_fwd', 'invr_sample_volume', 'invr_knn_blend', 'invr_warp_deform',
-           'invr_part_field_workspace', 'invr_part_field_fwd', 'invr_composite_fwd']
+           'invr_part_field_workspace', 'invr_part_field_fwd', 'invr_composite_fwd',
+           'invr_profile_enable', 'invr_profile_read']
+NUM_STAGES = 14
+STAGE_NAMES = ['cull', 'knn', 'warp'] + ['encode_%d' % p for p in range(5)] + ['mlp_%d' % p for p in range(5)] + ['composite']
 
 _lib = None
 
@@ -87,11 +90,25 @@ def lib():
         L.invr_warp_deform.argtypes = [C.POINTER(InvrScene), C.POINTER(InvrModel), vp, vp, vp, vp, C.c_int64, vp, vp, vp, vp]
         L.invr_part_field_fwd.argtypes = [C.POINTER(InvrModel), C.c_int32, vp, vp, vp, C.c_int64, vp, vp, C.c_size_t, vp]
         L.invr_composite_fwd.argtypes = [vp, C.c_int64, C.c_int32, vp, vp, vp, vp]
+        L.invr_profile_enable.argtypes = [C.c_int32]
+        L.invr_profile_read.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int32)]
         for n in ('invr_render_fwd', 'invr_grid_encode_fwd', 'invr_sample_volume', 'invr_knn_blend',
                   'invr_warp_deform', 'invr_part_field_fwd', 'invr_composite_fwd'):
             getattr(L, n).restype = C.c_int
         _lib = L
     return _lib
+
+
+def profile_enable(on):
+    lib().invr_profile_enable(int(bool(on)))
+
+
+def profile_read():
+    """-> ({stage name: total ms since the last read}, number of renders)."""
+    ms = (C.c_float * NUM_STAGES)()
+    n = C.c_int32(0)
+    check(lib().invr_profile_read(ms, C.byref(n)))
+    return {STAGE_NAMES[i]: float(ms[i]) for i in range(NUM_STAGES)}, int(n.value)
 
 
 def check(status):

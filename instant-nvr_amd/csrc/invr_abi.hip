@@ -77,6 +77,51 @@ static int check_mlp_deform(const InvrMlp* m) {
     return 0;
 }
 
+// ---- per-stage HIP-event profiling -----------------------------------------------------------------
+#include <vector>
+struct ProfInterval { int stage; hipEvent_t t0, t1; };
+static bool g_prof_on = false;
+static int g_prof_renders = 0;
+static std::vector<ProfInterval> g_prof_recs;
+static std::vector<hipEvent_t> g_prof_pool;
+
+static hipEvent_t prof_event() {
+    hipEvent_t e = nullptr;
+    if (!g_prof_pool.empty()) { e = g_prof_pool.back(); g_prof_pool.pop_back(); }
+    else if (hipEventCreate(&e) != hipSuccess) e = nullptr;
+    return e;
+}
+
+extern "C" int invr_profile_enable(int32_t on) { g_prof_on = on != 0; return 0; }
+
+extern "C" int invr_profile_read(float* ms, int32_t* n_renders) {
+    INVR_CHECK(ms && n_renders, "invr_profile_read: null pointer");
+    *n_renders = g_prof_renders;
+    for (auto& r : g_prof_recs) {
+        INVR_HIP(hipEventSynchronize(r.t1));
+        float t = 0.f;
+        INVR_HIP(hipEventElapsedTime(&t, r.t0, r.t1));
+        ms[r.stage] += t;
+        g_prof_pool.push_back(r.t0);
+        g_prof_pool.push_back(r.t1);
+    }
+    g_prof_recs.clear();
+    g_prof_renders = 0;
+    return 0;
+}
+
+struct ProfStage {      // RAII: one (begin,end) event pair around a stage's launches, on the launch stream
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    int stage;
+    hipStream_t st;
+    ProfStage(int stage_, hipStream_t st_) : stage(stage_), st(st_) {
+        if (g_prof_on) { t0 = prof_event(); t1 = prof_event(); if (t0 && t1) (void)hipEventRecord(t0, st); }
+    }
+    ~ProfStage() {
+        if (t0 && t1) { (void)hipEventRecord(t1, st); g_prof_recs.push_back({stage, t0, t1}); }
+    }
+};
+
 // ---- workspace carve -----------------------------------------------------------------------------
 struct Carver {
     char* base;
@@ -168,20 +213,39 @@ extern "C" int invr_render_fwd(const InvrScene* scene, const InvrModel* model,
     a.ray_o = ray_o; a.ray_d = ray_d; a.near = near; a.far = far; a.jitter = jitter; a.z_vals = z_vals;
     a.R = n_rays; a.S = n_samples; a.N = N;
 
-    INVR_HIP(hipMemsetAsync(w.counters, 0, CNT_LEN * sizeof(int32_t), st));
-    if (launch_cull(a, w, max_active, st)) return 1;
-    if (launch_knn_pairs(a, w, st)) return 1;
-    GridDev dg = make_grid_dev(&model->deform_grid);
-    MlpDev dm = make_mlp_dev(&model->deform_mlp);
-    if (launch_warp_pairs(a, w, dg, dm, st)) return 1;
-    for (int p = 0; p < INVR_NUM_PARTS; ++p) {
-        GridDev g = make_grid_dev(&model->part[p].grid);
-        float* emb = w.emb[p & 1];
-        if (launch_part_encode(g, w.l_x[p], w.cap, w.counters + CNT_PAIRS + p, w.cap, emb, st)) return 1;
-        PartMlpDev pm = make_part_mlp(model, p, scene->latent_index);
-        if (launch_part_mlp(pm, emb, w.l_d[p], w.cap, w.l_slot[p], w.counters + CNT_PAIRS + p, w.cap, w.raws, p, nullptr, st)) return 1;
+    {
+        ProfStage ps(INVR_STAGE_CULL, st);
+        INVR_HIP(hipMemsetAsync(w.counters, 0, CNT_LEN * sizeof(int32_t), st));
+        if (launch_cull(a, w, max_active, st)) return 1;
     }
-    if (launch_merge_composite(a, w, rgb_map, acc_map, raw, occ, weights, st)) return 1;
+    {
+        ProfStage ps(INVR_STAGE_KNN, st);
+        if (launch_knn_pairs(a, w, st)) return 1;
+    }
+    {
+        ProfStage ps(INVR_STAGE_WARP, st);
+        GridDev dg = make_grid_dev(&model->deform_grid);
+        MlpDev dm = make_mlp_dev(&model->deform_mlp);
+        if (launch_warp_pairs(a, w, dg, dm, st)) return 1;
+    }
+    for (int p = 0; p < INVR_NUM_PARTS; ++p) {
+        float* emb = w.emb[p & 1];
+        {
+            ProfStage ps(INVR_STAGE_ENCODE + p, st);
+            GridDev g = make_grid_dev(&model->part[p].grid);
+            if (launch_part_encode(g, w.l_x[p], w.cap, w.counters + CNT_PAIRS + p, w.cap, emb, st)) return 1;
+        }
+        {
+            ProfStage ps(INVR_STAGE_MLP + p, st);
+            PartMlpDev pm = make_part_mlp(model, p, scene->latent_index);
+            if (launch_part_mlp(pm, emb, w.l_d[p], w.cap, w.l_slot[p], w.counters + CNT_PAIRS + p, w.cap, w.raws, p, nullptr, st)) return 1;
+        }
+    }
+    {
+        ProfStage ps(INVR_STAGE_COMPOSITE, st);
+        if (launch_merge_composite(a, w, rgb_map, acc_map, raw, occ, weights, st)) return 1;
+    }
+    if (g_prof_on) ++g_prof_renders;
     if (stats) {
         hipLaunchKernelGGL(k_export_stats, dim3(1), dim3(64), 0, st, w.counters, stats);
         INVR_LAUNCH_CHECK();

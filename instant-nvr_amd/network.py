@@ -130,6 +130,11 @@ class TPoseHuman(nn.Module):
         self.part_networks = nn.ModuleList([PartNetwork(p, i, cfg) for i, p in enumerate(PART_NAMES)])
 
 
+class RenderContext:
+    def __init__(self, model, scene, keep):
+        self.model, self.scene, self.keep = model, scene, keep
+
+
 class Network(nn.Module):
     """Drop-in for inb_part_network_multiassign.Network (:68-168)."""
 
@@ -154,15 +159,21 @@ class Network(nn.Module):
         for pn in self.tpose_human.part_networks:
             pn.embedder.maybe_adopt_batch_bounds(batch)
 
-    def render_rays(self, batch, ray_o, ray_d, near, far, n_samples, jitter=None, want_raw=True,
-                    want_weights=False, max_active=0):
-        """One invr_render_fwd call over a ray list (n,3)/(n,).  Returns a dict of device tensors."""
-        L = _abi.lib()
-        dev = ray_o.device
+    def prepare(self, batch):
+        """Build the C-ABI views (InvrModel / InvrScene) of the parameters and of one batch.
+        The result can be reused for any number of render_rays calls while neither changes."""
         self.adopt_batch_bounds(batch)
         keep = []
-        model = self.model_struct(keep)
-        scene = _abi.make_scene(batch, self.cfg, keep)
+        return RenderContext(self.model_struct(keep), _abi.make_scene(batch, self.cfg, keep), keep)
+
+    def render_rays(self, batch, ray_o, ray_d, near, far, n_samples, jitter=None, want_raw=True,
+                    want_weights=False, max_active=0):
+        """One invr_render_fwd call over a ray list (n,3)/(n,).  `batch` is the collated batch dict
+        or a RenderContext from prepare().  Returns a dict of device tensors."""
+        L = _abi.lib()
+        dev = ray_o.device
+        ctx = batch if isinstance(batch, RenderContext) else self.prepare(batch)
+        model, scene, keep = ctx.model, ctx.scene, ctx.keep
         f = lambda t: t.detach().to(torch.float32).contiguous()
         ray_o, ray_d, near, far = f(ray_o), f(ray_d), f(near), f(far)
         n = ray_o.shape[0]
