@@ -73,6 +73,9 @@ struct SceneDev {
     const int64_t* latent_index;
     float thresh;
     int32_t tpose_viewdir;
+    // squared nearest-vertex distances between which a (point,part) pair is provably NOT flagged
+    // (k_knn.hip header); near_hi2 = +inf disables the class
+    float near_hi2, band_lo2;
 };
 
 struct MlpDev {

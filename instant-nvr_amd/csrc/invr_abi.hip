@@ -5,6 +5,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <math.h>
 #include "pipeline.h"
 
 static thread_local char g_err[512] = "";
@@ -58,6 +59,18 @@ SceneDev make_scene_dev(const InvrScene* s) {
     d.part_pts = s->part_pts; d.part_pbw = s->part_pbw; d.lengths2 = s->lengths2; d.M = s->part_stride;
     d.frame_dim = s->frame_dim; d.latent_index = s->latent_index;
     d.thresh = s->smpl_thresh; d.tpose_viewdir = s->tpose_viewdir;
+    // Unflagged band of the nearest-vertex distance d1 (k_knn.hip header): dist >= g(d1) with
+    // g(d) = d*w/(w+1e-8), w = exp(-d^2/0.01125); g rises ~d then collapses near 0.48 m.
+    auto g = [](double d) { double w = exp(-d * d / (2.0 * 0.075 * 0.075)); return d * w / (w + 1e-8); };
+    const double th = (double)s->smpl_thresh;
+    d.near_hi2 = __builtin_inff(); d.band_lo2 = 0.f;
+    const double lo = th * 1.01;
+    if (th > 0 && lo < 0.42 && g(lo) >= th * 1.002 && g(0.42) >= th * 1.05) {
+        double a = 0.42, b = 0.8;                       // g is decreasing on [0.42, 0.8]
+        for (int it = 0; it < 60; ++it) { double m = 0.5 * (a + b); if (g(m) >= th * 1.05) a = m; else b = m; }
+        d.near_hi2 = (float)(lo * lo * 1.0001);
+        d.band_lo2 = (float)(a * a * 0.9999);
+    }
     return d;
 }
 
@@ -134,28 +147,38 @@ struct Carver {
     }
 };
 
+#define KNN_MAX_PART 8192
 static size_t carve(Workspace& w, void* base, int64_t N, int64_t cap) {
     Carver c{(char*)base, 0};
     int64_t nb = cdiv(N, 256);
     w.cap = cap;
+    const int64_t lc = cap + 1;          // list / slot capacity incl. the far-constant entry
+    w.lcap = lc;
     w.counters = c.take<int32_t>(CNT_LEN);
-    w.part_aabb = c.take<float>(INVR_NUM_PARTS * 6);
+    w.knn.part_aabb = c.take<float>(INVR_NUM_PARTS * 6);
+    w.knn.mpad = KNN_MAX_PART;
+    w.knn.cpad = KNN_MAX_PART / 64;
+    w.knn.sverts = c.take<float4>((size_t)INVR_NUM_PARTS * w.knn.mpad);
+    w.knn.cl_lo = c.take<float4>((size_t)INVR_NUM_PARTS * w.knn.cpad);
+    w.knn.cl_hi = c.take<float4>((size_t)INVR_NUM_PARTS * w.knn.cpad);
+    w.knn.cl_rep = c.take<float4>((size_t)INVR_NUM_PARTS * w.knn.cpad);
     w.mask = c.take<unsigned long long>(nb * 4);
     w.block_cnt = c.take<int32_t>(nb);
     w.block_off = c.take<int32_t>(nb);
-    w.active_idx = c.take<int32_t>(cap);
+    w.active_idx = c.take<int32_t>(lc);
     w.slot_of_sample = c.take<int32_t>(N);
-    w.pflags = c.take<uint8_t>(cap);
+    w.pflags = c.take<uint8_t>(lc);
+    w.farflags = c.take<uint8_t>(lc);
     for (int p = 0; p < INVR_NUM_PARTS; ++p) {
-        w.l_slot[p] = c.take<int32_t>(cap);
-        w.l_nn[p] = c.take<int32_t>(cap * 4);
-        w.l_w[p] = c.take<float>(cap * 4);
-        w.l_x[p] = c.take<float>(cap * 3);
-        w.l_d[p] = c.take<float>(cap * 3);
+        w.l_slot[p] = c.take<int32_t>(lc);
+        w.l_nn[p] = c.take<int32_t>(lc * 4);
+        w.l_w[p] = c.take<float>(lc * 4);
+        w.l_x[p] = c.take<float>(lc * 3);
+        w.l_d[p] = c.take<float>(lc * 3);
     }
-    w.emb[0] = c.take<float>(cap * EMB_K);
-    w.emb[1] = c.take<float>(cap * EMB_K);
-    w.raws = c.take<float4>(cap * INVR_NUM_PARTS);
+    w.emb[0] = c.take<float>(lc * EMB_K);
+    w.emb[1] = c.take<float>(lc * EMB_K);
+    w.raws = c.take<float4>(lc * INVR_NUM_PARTS);
     return align_up(c.off, 256);
 }
 
@@ -207,6 +230,7 @@ extern "C" int invr_render_fwd(const InvrScene* scene, const InvrModel* model,
                model->deform_grid.include_input, "deformer grid must be 8 levels x 2 features, sum=False, include_input");
     for (int p = 0; p < INVR_NUM_PARTS; ++p) if (check_grid(&model->part[p].grid, "part grid")) return 1;
     INVR_CHECK(scene->pbw_channels >= 1 && scene->part_stride >= 1, "invr_render_fwd: bad scene dims");
+    INVR_CHECK(scene->part_stride <= KNN_MAX_PART, "invr_render_fwd: part_stride %d > %d vertices per part", scene->part_stride, KNN_MAX_PART);
 
     RenderArgs a;
     a.scene = make_scene_dev(scene);
@@ -233,12 +257,12 @@ extern "C" int invr_render_fwd(const InvrScene* scene, const InvrModel* model,
         {
             ProfStage ps(INVR_STAGE_ENCODE + p, st);
             GridDev g = make_grid_dev(&model->part[p].grid);
-            if (launch_part_encode(g, w.l_x[p], w.cap, w.counters + CNT_PAIRS + p, w.cap, emb, st)) return 1;
+            if (launch_part_encode(g, w.l_x[p], w.lcap, w.counters + CNT_PAIRS + p, w.lcap, emb, st)) return 1;
         }
         {
             ProfStage ps(INVR_STAGE_MLP + p, st);
             PartMlpDev pm = make_part_mlp(model, p, scene->latent_index);
-            if (launch_part_mlp(pm, emb, w.l_d[p], w.cap, w.l_slot[p], w.counters + CNT_PAIRS + p, w.cap, w.raws, p, nullptr, st)) return 1;
+            if (launch_part_mlp(pm, emb, w.l_d[p], w.lcap, w.l_slot[p], w.counters + CNT_PAIRS + p, w.lcap, w.raws, p, nullptr, st)) return 1;
         }
     }
     {

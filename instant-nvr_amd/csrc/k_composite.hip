@@ -31,17 +31,20 @@ struct DenseRaw {      // raw (R,S,4) given
 struct MergedRaw {     // merge per-part results of the survivor slot of sample i
     const int32_t* slot_of_sample;
     const uint8_t* pflags;
+    const uint8_t* farflags;
     const float4* raws;
+    int64_t const_slot;
     __device__ __forceinline__ float4 get(int64_t i) const {
         const int slot = slot_of_sample[i];
         float4 best = make_float4(0.f, 0.f, 0.f, 0.f);
         if (slot >= 0) {
-            const unsigned fl = pflags[slot];
+            const unsigned fl = pflags[slot], ff = farflags[slot];
             // argmax over the 5 parts with zeros for unflagged parts, first maximum wins (:253-255)
 #pragma unroll
             for (int p = 0; p < INVR_NUM_PARTS; ++p) {
                 float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (fl & (1u << p)) c = raws[(int64_t)slot * INVR_NUM_PARTS + p];
+                else if (ff & (1u << p)) c = raws[const_slot * INVR_NUM_PARTS + p];   // far pair: per-part constant
                 if (p == 0 || c.w > best.w) best = c;
             }
         }
@@ -94,7 +97,7 @@ int launch_composite(const float* raw, int64_t n_rays, int S, float* weights, fl
 int launch_merge_composite(const RenderArgs& a, const Workspace& w, float* rgb_map, float* acc_map, float* raw,
                            float* occ, float* weights, hipStream_t st) {
     if (a.R == 0) return 0;
-    MergedRaw src{w.slot_of_sample, w.pflags, w.raws};
+    MergedRaw src{w.slot_of_sample, w.pflags, w.farflags, w.raws, w.cap};
     hipLaunchKernelGGL(k_composite<MergedRaw>, dim3((unsigned)cdiv(a.R, CMP_BLOCK / 64)), dim3(CMP_BLOCK), 0, st,
                        src, a.R, a.S, weights, rgb_map, acc_map, reinterpret_cast<float4*>(raw), occ);
     INVR_LAUNCH_CHECK();

@@ -1,23 +1,37 @@
 // K2: per-part 4-nearest-neighbour skinning against the posed SMPL vertices.
 // Replaces pts_knn_blend_weights_multiassign_batch -> sample_blend_closest_points -> knn_points
 // (lib/utils/blend_utils.py:817-825, 741-763, 732-738; pytorch3d brute-force KNN, squared L2,
-// first lengths2[p] vertices of part p).
+// first lengths2[p] vertices of part p) and the pflag test (inb_part_network_multiassign.py:90).
 //
-// One thread per query point, 256 points per workgroup; the part's vertices stream through LDS in
-// 2048-vertex tiles and are read as wave-uniform (broadcast) ds_read_b128, so the inner loop is
-// 3 sub + 3 mul/add + 1 compare per vertex with a rarely-taken sorted-insert branch.
-// NOTE (reference quirk that parity depends on): the weights are normalised by (sum + 1e-8)
-// (blend_utils.py:748), so for a part further than ~0.5 m the gaussian weights underflow against
-// the epsilon, the "weighted distance" tends to 0 and the pair IS flagged (dist < smpl_thresh) with
-// near-zero blend weights.  Far parts therefore cannot be culled by distance.
+// REFERENCE QUIRK the design is built around: the gaussian weights are normalised by
+// (sum + 1e-8) (blend_utils.py:748).  With w = exp(-d^2 / 0.01125):
+//   * d1 (nearest vertex) < thresh            -> dist ~ d1            -> flagged   ("near")
+//   * thresh*1.01 <= d1 <= ~0.47 m            -> dist >= d1*w1/(w1+1e-8) >= thresh -> NOT flagged
+//   * d1 >~ 0.5 m                             -> weights underflow against the epsilon, dist -> 0
+//                                                -> flagged with tiny blend weights  ("band")
+//   * d1 > 0.8 m                              -> w/1e-8 < 1e-16: blend weights are 0 to 1e-16, the
+//                                                pair warps to the canonical origin with a zero view
+//                                                direction -> its field value is a per-part CONSTANT
+// So every sample evaluates ~3 parts in the reference, most of them "far" pairs that all collapse
+// onto the same canonical point.  This kernel classifies each (point, part) with cluster bounds,
+// runs the exact 4-NN only where the result can matter (near / band), marks far pairs with a bit
+// (the merge kernel substitutes the per-part constant, evaluated once per frame through the very
+// same warp/encode/MLP kernels from an appended zero-weight pair) and drops provably unflagged
+// pairs.  Exactness: near/band pairs are bit-faithful brute-force results; far pairs differ from
+// the reference by <= 1e-16 relative in the blend weights.
+//
+// Data layout: a per-frame prepare kernel Morton-sorts each part's vertices (bitonic sort in LDS),
+// writes them as float4 {x,y,z,original row} and builds 64-vertex clusters {AABB, representative}.
+// The query kernel is one thread per point; cluster records and vertices are wave-uniform reads
+// (scalar path / broadcast), pruned per wave with lb(cluster) < current 4th-best.
 #include "pipeline.h"
 
 #define KNN_BLOCK 256
-#define KNN_TILE 2048
 #define KNN_K 4
 #define KNN_EPS 1e-8f
 // 2 * radius**2 with radius = 0.075 (blend_utils.py:741,747), evaluated in double like Python does
 #define KNN_TWO_R2 ((float)(2.0 * 0.075 * 0.075))
+#define KNN_DFAR2 0.64f          // (0.8 m)^2
 
 struct Top4 {
     float d[KNN_K];
@@ -40,28 +54,6 @@ struct Top4 {
     }
 };
 
-// exact 4-NN of (px,py,pz) among verts[0..len) of one part; all threads of the block must call.
-__device__ __forceinline__ void knn_scan_part(const float* __restrict__ verts, int len, float px, float py,
-                                              float pz, Top4& t, float4* sv) {
-    t.init();
-    for (int base = 0; base < len; base += KNN_TILE) {
-        int m = min(KNN_TILE, len - base);
-        __syncthreads();
-        for (int j = threadIdx.x; j < m; j += KNN_BLOCK) {
-            const float* v = verts + (int64_t)(base + j) * 3;
-            sv[j] = make_float4(v[0], v[1], v[2], 0.0f);
-        }
-        __syncthreads();
-#pragma unroll 4
-        for (int j = 0; j < m; ++j) {
-            float4 v = sv[j];
-            float dx = px - v.x, dy = py - v.y, dz = pz - v.z;
-            float d2 = dx * dx + dy * dy + dz * dz;       // ((p1-p2)**2).sum(-1)
-            t.push(d2, base + j);
-        }
-    }
-}
-
 // gaussian weights + weighted distance (blend_utils.py:745-749)
 __device__ __forceinline__ float knn_weights(const Top4& t, float* w) {
     float d[KNN_K], s = 0.0f;
@@ -80,7 +72,8 @@ __device__ __forceinline__ float knn_weights(const Top4& t, float* w) {
     return dist;
 }
 
-// ---- dense variant: every (point, part) -> bw (n,P,24), dist (n,P) -----------------------------
+// ---- dense brute-force variant (invr_knn_blend): every (point, part) -> bw (n,P,24), dist (n,P) ----
+#define KNN_TILE 2048
 __global__ __launch_bounds__(KNN_BLOCK) void k_knn_dense(SceneDev s, const float* pose_pts, int64_t n, float* bw, float* dist) {
     __shared__ float4 sv[KNN_TILE];
     int64_t i = (int64_t)blockIdx.x * KNN_BLOCK + threadIdx.x;
@@ -89,8 +82,24 @@ __global__ __launch_bounds__(KNN_BLOCK) void k_knn_dense(SceneDev s, const float
     if (live) { px = pose_pts[i * 3]; py = pose_pts[i * 3 + 1]; pz = pose_pts[i * 3 + 2]; }
     for (int p = 0; p < INVR_NUM_PARTS; ++p) {
         int len = (int)s.lengths2[p];
+        const float* verts = s.part_pts + (int64_t)p * s.M * 3;
         Top4 t;
-        knn_scan_part(s.part_pts + (int64_t)p * s.M * 3, len, px, py, pz, t, sv);
+        t.init();
+        for (int base = 0; base < len; base += KNN_TILE) {
+            int m = min(KNN_TILE, len - base);
+            __syncthreads();
+            for (int j = threadIdx.x; j < m; j += KNN_BLOCK) {
+                const float* v = verts + (int64_t)(base + j) * 3;
+                sv[j] = make_float4(v[0], v[1], v[2], 0.0f);
+            }
+            __syncthreads();
+#pragma unroll 4
+            for (int j = 0; j < m; ++j) {
+                float4 v = sv[j];
+                float dx = px - v.x, dy = py - v.y, dz = pz - v.z;
+                t.push(dx * dx + dy * dy + dz * dz, base + j);                 // ((p1-p2)**2).sum(-1)
+            }
+        }
         if (!live) continue;
         float w[KNN_K];
         float ds = knn_weights(t, w);
@@ -114,48 +123,186 @@ int launch_knn_blend_dense(const SceneDev& s, const float* pose_pts, int64_t n, 
     return 0;
 }
 
-// ---- pipeline variant ---------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_part_aabb(SceneDev s, float* aabb) {
-    int p = blockIdx.x;
-    int len = (int)s.lengths2[p];
+// ---- per-frame prepare: Morton sort + clusters ------------------------------------------------------
+#define PREP_T 1024
+#define PREP_MAX 8192
+
+__device__ __forceinline__ unsigned spread6(unsigned v) {       // 6 bits -> every third bit
+    v &= 63u;
+    v = (v | (v << 8)) & 0x0300F;
+    v = (v | (v << 4)) & 0x030C3;
+    v = (v | (v << 2)) & 0x09249;
+    return v;
+}
+
+__global__ __launch_bounds__(PREP_T) void k_part_prepare(SceneDev s, KnnIndex ix) {
+    __shared__ unsigned keys[PREP_MAX];
+    __shared__ float red[6][PREP_T / 64];
+    const int p = blockIdx.x;
+    const int len = min((int)s.lengths2[p], PREP_MAX);
     const float* v = s.part_pts + (int64_t)p * s.M * 3;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // 1. part AABB
     float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
     float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
-    for (int j = threadIdx.x; j < len; j += 64)
+    for (int j = threadIdx.x; j < len; j += PREP_T)
 #pragma unroll
         for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], v[j * 3 + a]); hi[a] = fmaxf(hi[a], v[j * 3 + a]); }
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
+    for (int a = 0; a < 3; ++a) {
         for (int d = 32; d >= 1; d >>= 1) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], d)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], d)); }
+        if (lane == 0) { red[a][wv] = lo[a]; red[3 + a][wv] = hi[a]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+        for (int k = 0; k < PREP_T / 64; ++k) { lo[a] = fminf(lo[a], red[a][k]); hi[a] = fmaxf(hi[a], red[3 + a][k]); }
     if (threadIdx.x == 0)
 #pragma unroll
-        for (int a = 0; a < 3; ++a) { aabb[p * 6 + a] = lo[a]; aabb[p * 6 + 3 + a] = hi[a]; }
+        for (int a = 0; a < 3; ++a) { ix.part_aabb[p * 6 + a] = lo[a]; ix.part_aabb[p * 6 + 3 + a] = hi[a]; }
+    // 2. Morton keys (6 bits / axis) | original index (13 bits)
+    int n2 = 64;
+    while (n2 < len) n2 <<= 1;
+    for (int j = threadIdx.x; j < n2; j += PREP_T) {
+        unsigned key = 0xFFFFFFFFu;
+        if (j < len) {
+            unsigned q[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                float e = hi[a] - lo[a];
+                float u = e > 0.f ? (v[j * 3 + a] - lo[a]) / e : 0.f;
+                q[a] = (unsigned)fminf(fmaxf(u * 64.0f, 0.0f), 63.0f);
+            }
+            unsigned m = (spread6(q[0]) << 2) | (spread6(q[1]) << 1) | spread6(q[2]);
+            key = (m << 13) | (unsigned)j;
+        }
+        keys[j] = key;
+    }
+    __syncthreads();
+    // 3. bitonic sort
+    for (int k = 2; k <= n2; k <<= 1)
+        for (int jj = k >> 1; jj > 0; jj >>= 1) {
+            for (int i = threadIdx.x; i < n2; i += PREP_T) {
+                int l = i ^ jj;
+                if (l > i) {
+                    unsigned a = keys[i], b = keys[l];
+                    bool up = (i & k) == 0;
+                    if ((a > b) == up) { keys[i] = b; keys[l] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    // 4. sorted vertices {x,y,z,orig} and clusters of 64
+    const int64_t voff = (int64_t)p * ix.mpad;
+    for (int j = threadIdx.x; j < len; j += PREP_T) {
+        int o = (int)(keys[j] & 8191u);
+        ix.sverts[voff + j] = make_float4(v[o * 3], v[o * 3 + 1], v[o * 3 + 2], __int_as_float(o));
+    }
+    const int ncl = (len + 63) >> 6;
+    for (int c = wv; c < ncl; c += PREP_T / 64) {
+        int j = c * 64 + lane;
+        float x[3];
+        bool ok = j < len;
+        int o = ok ? (int)(keys[j] & 8191u) : 0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) x[a] = v[o * 3 + a];
+        float clo[3], chi[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            clo[a] = ok ? x[a] : __builtin_inff();
+            chi[a] = ok ? x[a] : -__builtin_inff();
+            for (int d = 32; d >= 1; d >>= 1) { clo[a] = fminf(clo[a], __shfl_xor(clo[a], d)); chi[a] = fmaxf(chi[a], __shfl_xor(chi[a], d)); }
+        }
+        if (lane == 0) {
+            const int64_t co = (int64_t)p * ix.cpad + c;
+            ix.cl_lo[co] = make_float4(clo[0], clo[1], clo[2], 0.f);
+            ix.cl_hi[co] = make_float4(chi[0], chi[1], chi[2], 0.f);
+            ix.cl_rep[co] = make_float4(x[0], x[1], x[2], 0.f);       // lane 0 = first vertex of the cluster
+        }
+    }
 }
 
-__global__ __launch_bounds__(KNN_BLOCK) void k_knn_pairs(RenderArgs a, Workspace w) {
-    __shared__ float4 sv[KNN_TILE];
+__device__ __forceinline__ float aabb_dist2(float px, float py, float pz, float4 lo, float4 hi) {
+    float ex = fmaxf(fmaxf(lo.x - px, px - hi.x), 0.0f);
+    float ey = fmaxf(fmaxf(lo.y - py, py - hi.y), 0.0f);
+    float ez = fmaxf(fmaxf(lo.z - pz, pz - hi.z), 0.0f);
+    return ex * ex + ey * ey + ez * ez;
+}
+
+__device__ __forceinline__ void scan_cluster(const float4* __restrict__ sv, int n, float px, float py, float pz, Top4& t) {
+#pragma unroll 4
+    for (int j = 0; j < n; ++j) {
+        const float4 v = sv[j];                                     // wave-uniform address
+        const float dx = px - v.x, dy = py - v.y, dz = pz - v.z;
+        t.push(dx * dx + dy * dy + dz * dz, __float_as_int(v.w));   // ((p1-p2)**2).sum(-1)
+    }
+}
+
+// The index arrays are separate __restrict__ kernel parameters (not members of the by-value
+// Workspace) so that the compiler can prove them read-only and fetch the wave-uniform cluster and
+// vertex records through the scalar cache (s_load) instead of the vector memory path.
+__global__ __launch_bounds__(KNN_BLOCK) void k_knn_pairs(RenderArgs a, Workspace w,
+                                                         const float4* __restrict__ g_sverts, const float4* __restrict__ g_lo,
+                                                         const float4* __restrict__ g_hi, const float4* __restrict__ g_rep,
+                                                         const float* __restrict__ g_aabb, int mpad, int cpad) {
     const int na = w.counters[CNT_ACTIVE];
     const int lane = threadIdx.x & 63;
     for (int64_t tile = blockIdx.x; tile * KNN_BLOCK < na; tile += gridDim.x) {
-        int64_t slot = tile * KNN_BLOCK + threadIdx.x;
-        bool live = slot < na;
+        const int64_t slot = tile * KNN_BLOCK + threadIdx.x;
+        const bool live = slot < na;
         float px = 0, py = 0, pz = 0;
         if (live) sample_pose_point(a, w.active_idx[slot], px, py, pz, nullptr, nullptr);
-        unsigned flags = 0;
+        unsigned flags = 0, farflags = 0;
         for (int p = 0; p < INVR_NUM_PARTS; ++p) {
-            int len = (int)a.scene.lengths2[p];
+            const int len = min((int)a.scene.lengths2[p], PREP_MAX);
+            if (len < KNN_K) continue;                     // reference: inf distances -> NaN dist -> unflagged
+            const float* bb = g_aabb + p * 6;
+            const float lbp = aabb_dist2(px, py, pz, make_float4(bb[0], bb[1], bb[2], 0.f), make_float4(bb[3], bb[4], bb[5], 0.f));
+            if (__ballot(live && !(lbp > KNN_DFAR2)) == 0) {          // whole wave far from this part
+                if (live) farflags |= 1u << p;
+                continue;
+            }
+            const int ncl = (len + 63) >> 6;
+            const float4* __restrict__ clo = g_lo + (int64_t)p * cpad;
+            const float4* __restrict__ chi = g_hi + (int64_t)p * cpad;
+            const float4* __restrict__ crep = g_rep + (int64_t)p * cpad;
+            const float4* __restrict__ sv = g_sverts + (int64_t)p * mpad;
+            // bounds on the nearest-vertex distance from the cluster records
+            float lb2 = __builtin_inff(), ub2 = __builtin_inff();
+            int seed = 0;
+            for (int c = 0; c < ncl; ++c) {
+                const float4 r = crep[c];
+                const float dx = px - r.x, dy = py - r.y, dz = pz - r.z;
+                const float u = dx * dx + dy * dy + dz * dz;
+                if (u < ub2) { ub2 = u; seed = c; }
+                lb2 = fminf(lb2, aabb_dist2(px, py, pz, clo[c], chi[c]));
+            }
+            const bool is_far = lb2 > KNN_DFAR2;
+            const bool unflagged = lb2 >= a.scene.near_hi2 && ub2 <= a.scene.band_lo2;
+            const bool scan = live && !is_far && !unflagged;
+            if (live && is_far) farflags |= 1u << p;
+            if (__ballot(scan) == 0) continue;
+            // exact 4-NN: seed with the cluster of the wave's first scanning lane, then pruned sweep
             Top4 t;
-            knn_scan_part(a.scene.part_pts + (int64_t)p * a.scene.M * 3, len, px, py, pz, t, sv);
+            t.init();
+            const int seed_c = __builtin_amdgcn_readlane(seed, __ffsll((long long)__ballot(scan)) - 1);
+            scan_cluster(sv + seed_c * 64, min(64, len - seed_c * 64), px, py, pz, t);
+            for (int c = 0; c < ncl; ++c) {
+                if (c == seed_c) continue;
+                const bool need = scan && aabb_dist2(px, py, pz, clo[c], chi[c]) < t.d[3];
+                if (__ballot(need) == 0) continue;
+                scan_cluster(sv + c * 64, min(64, len - c * 64), px, py, pz, t);
+            }
             float wt[KNN_K];
-            float ds = knn_weights(t, wt);
-            bool flag = live && ds < a.scene.thresh;          // pflag (inb_part_network_multiassign.py:90)
-            unsigned long long m = __ballot(flag);
+            const float ds = knn_weights(t, wt);
+            const bool flag = scan && ds < a.scene.thresh;            // pflag (inb_part_network_multiassign.py:90)
+            const unsigned long long m = __ballot(flag);
             if (m) {
                 int base = 0;
-                if (lane == 0) base = atomicAdd(&w.counters[CNT_PAIRS + p], __popcll(m));
-                base = __shfl(base, 0);
+                if (lane == (__ffsll((long long)m) - 1)) base = atomicAdd(&w.counters[CNT_PAIRS + p], __popcll(m));
+                base = __shfl(base, __ffsll((long long)m) - 1);
                 if (flag) {
-                    int64_t pos = base + __popcll(m & ((1ull << lane) - 1ull));
+                    const int64_t pos = base + __popcll(m & ((1ull << lane) - 1ull));
                     w.l_slot[p][pos] = (int32_t)slot;
                     reinterpret_cast<int4*>(w.l_nn[p])[pos] = make_int4(t.i[0], t.i[1], t.i[2], t.i[3]);
                     reinterpret_cast<float4*>(w.l_w[p])[pos] = make_float4(wt[0], wt[1], wt[2], wt[3]);
@@ -163,16 +310,40 @@ __global__ __launch_bounds__(KNN_BLOCK) void k_knn_pairs(RenderArgs a, Workspace
                 }
             }
         }
-        if (live) w.pflags[slot] = (uint8_t)flags;
+        if (live) {
+            w.pflags[slot] = (uint8_t)flags;
+            w.farflags[slot] = (uint8_t)farflags;
+            if (farflags) {
+#pragma unroll
+                for (int p = 0; p < INVR_NUM_PARTS; ++p)
+                    if (farflags & (1u << p)) atomicAdd(&w.counters[CNT_FAR + p], 1);
+            }
+        }
     }
 }
 
+// one zero-weight pair per part, appended behind the real pairs: its field value is the constant
+// every far pair of that part takes (see the header comment).  It lives in the extra slot `cap`.
+__global__ void k_append_const_pairs(Workspace w) {
+    const int p = threadIdx.x;
+    if (p >= INVR_NUM_PARTS) return;
+    const int pos = w.counters[CNT_PAIRS + p];
+    w.l_slot[p][pos] = (int32_t)w.cap;
+    reinterpret_cast<int4*>(w.l_nn[p])[pos] = make_int4(0, 0, 0, 0);
+    reinterpret_cast<float4*>(w.l_w[p])[pos] = make_float4(0.f, 0.f, 0.f, 0.f);
+    w.counters[CNT_PAIRS + p] = pos + 1;
+    if (p == 0) w.active_idx[w.cap] = 0;
+}
+
 int launch_knn_pairs(const RenderArgs& a, const Workspace& w, hipStream_t st) {
-    hipLaunchKernelGGL(k_part_aabb, dim3(INVR_NUM_PARTS), dim3(64), 0, st, a.scene, w.part_aabb);
+    hipLaunchKernelGGL(k_part_prepare, dim3(INVR_NUM_PARTS), dim3(PREP_T), 0, st, a.scene, w.knn);
     INVR_LAUNCH_CHECK();
     int64_t tiles = cdiv(w.cap, KNN_BLOCK);
     unsigned grid = (unsigned)(tiles < 256 * 8 ? (tiles > 0 ? tiles : 1) : 256 * 8);
-    hipLaunchKernelGGL(k_knn_pairs, dim3(grid), dim3(KNN_BLOCK), 0, st, a, w);
+    hipLaunchKernelGGL(k_knn_pairs, dim3(grid), dim3(KNN_BLOCK), 0, st, a, w, w.knn.sverts, w.knn.cl_lo, w.knn.cl_hi,
+                       w.knn.cl_rep, w.knn.part_aabb, w.knn.mpad, w.knn.cpad);
+    INVR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_append_const_pairs, dim3(1), dim3(64), 0, st, w);
     INVR_LAUNCH_CHECK();
     return 0;
 }

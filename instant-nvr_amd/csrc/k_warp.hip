@@ -159,14 +159,14 @@ __global__ __launch_bounds__(WARP_BLOCK) void k_warp_pairs(RenderArgs a, Workspa
         }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            w.l_x[p][c * w.cap + i] = xb[c] + r[c];          // tpose = init_bigpose + resd (:111)
-            w.l_d[p][c * w.cap + i] = db[c];
+            w.l_x[p][c * w.lcap + i] = xb[c] + r[c];          // tpose = init_bigpose + resd (:111)
+            w.l_d[p][c * w.lcap + i] = db[c];
         }
     }
 }
 
 int launch_warp_pairs(const RenderArgs& a, const Workspace& w, const GridDev& dg, const MlpDev& dm, hipStream_t st) {
-    int64_t tiles = cdiv(w.cap, WARP_BLOCK);
+    int64_t tiles = cdiv(w.lcap, WARP_BLOCK);
     unsigned gx = (unsigned)(tiles < 1024 ? (tiles > 0 ? tiles : 1) : 1024);
     hipLaunchKernelGGL(k_warp_pairs, dim3(gx, INVR_NUM_PARTS), dim3(WARP_BLOCK), 0, st, a, w, dg, dm);
     INVR_LAUNCH_CHECK();

@@ -2,7 +2,7 @@
 #pragma once
 #include "common.h"
 
-enum { CNT_ACTIVE = 0, CNT_PAIRS = 1 /* ..5 */, CNT_OVERFLOW = 6, CNT_LEN = 16 };
+enum { CNT_ACTIVE = 0, CNT_PAIRS = 1 /* ..5 */, CNT_OVERFLOW = 6, CNT_FAR = 7 /* ..11 */, CNT_LEN = 16 };
 
 #define EMB_K 20            // 19-d encoder output padded to 5 MFMA k-steps
 
@@ -19,7 +19,18 @@ struct RenderArgs {
     int64_t N;               // R*S
 };
 
-// All arrays live in the caller-provided workspace (HBM).  cap = max_active.
+// per-frame KNN acceleration index built by k_part_prepare
+struct KnnIndex {
+    float4* sverts;      // P*mpad : Morton-sorted vertices {x,y,z,original row}
+    float4* cl_lo;       // P*cpad : 64-vertex cluster AABB min
+    float4* cl_hi;       // P*cpad : 64-vertex cluster AABB max
+    float4* cl_rep;      // P*cpad : first vertex of the cluster (upper bound of the nearest distance)
+    float* part_aabb;    // P*6
+    int32_t mpad, cpad;
+};
+
+// All arrays live in the caller-provided workspace (HBM).  cap = max_active; lists and the
+// per-slot arrays hold one extra entry (slot `cap`) for the per-part far-pair constant.
 struct Workspace {
     unsigned long long* mask;     // ceil(N/64): survivor bit per ray-sample
     int32_t* block_cnt;           // ceil(N/256)
@@ -27,8 +38,9 @@ struct Workspace {
     int32_t* counters;            // CNT_LEN
     int32_t* active_idx;          // cap: ray-sample index of every survivor (ordered)
     int32_t* slot_of_sample;      // N: survivor slot or -1
-    uint8_t* pflags;              // cap: bit p set if (slot, part p) is flagged
-    float* part_aabb;             // P*6: posed-vertex AABB per part
+    uint8_t* pflags;              // cap: bit p set if (slot, part p) is flagged and listed
+    uint8_t* farflags;            // cap: bit p set if (slot, part p) is a far pair (takes the part constant)
+    KnnIndex knn;
     // per-part pair lists, SoA, each of capacity cap
     int32_t* l_slot[INVR_NUM_PARTS];      // cap
     int32_t* l_nn[INVR_NUM_PARTS];        // cap*4 : neighbour rows inside part_pbw[p]
@@ -37,7 +49,8 @@ struct Workspace {
     float* l_d[INVR_NUM_PARTS];           // 3*cap : canonical view dir, SoA
     float* emb[2];                        // EMB_K*cap : encoder output, SoA [k][pair] (ping-pong)
     float4* raws;                         // cap*P : [rgb, occ] per (slot, part)
-    int64_t cap;
+    int64_t cap;                          // max survivors
+    int64_t lcap;                         // cap + 1: list / per-slot array capacity (stride of the SoA lists)
 };
 
 // ---- z / pose-space point of a ray-sample (inb_renderer.py:17-29, blend_utils.py:366-382) ----
