@@ -143,6 +143,14 @@ __device__ __forceinline__ void sample_volume_dev(const VolDev& v, int c0, float
 
 // (a ^ b*P1 ^ c*P2) mod T, exact for T < 2^31 and products < 2^52 (int64 arithmetic of
 // part_base_embedder.py:132-136) using one fp64 reciprocal multiply + correction.
+__device__ __forceinline__ uint32_t hash_mod64(uint64_t x, int64_t T, double inv_T) {
+    double xd = (double)x;
+    double q = floor(xd * inv_T);
+    double r = fma(-q, (double)T, xd);
+    if (r < 0.0) r += (double)T;
+    if (r >= (double)T) r -= (double)T;
+    return (uint32_t)r;
+}
 __device__ __forceinline__ uint32_t hash_mod(uint32_t cx, uint32_t cy, uint32_t cz, int64_t T, double inv_T) {
     uint64_t x = (uint64_t)cx ^ ((uint64_t)cy * HASH_P1) ^ ((uint64_t)cz * HASH_P2);
     double xd = (double)x;

@@ -77,23 +77,51 @@ struct LaneLevel {          // per-lane constants of "my" level
     bool hashed;
 };
 
-// issue the 8 row fetches of one point for this lane's level
-__device__ __forceinline__ void fetch_point(const GridDev& g, const LaneLevel& L, float x, float y, float z,
+template <int SRC>   // broadcast lane SRC of every quad to the whole quad (v_mov_b32_dpp quad_perm:[SRC x4])
+__device__ __forceinline__ int quad_bcast_i(int v) {
+    return __builtin_amdgcn_mov_dpp(v, SRC * 0x55, 0xF, 0xF, true);
+}
+template <int SRC>
+__device__ __forceinline__ float quad_bcast_f(float v) { return __int_as_float(quad_bcast_i<SRC>(__float_as_int(v))); }
+
+// Issue the 8 row fetches of one point for this lane's level.  The index arithmetic is shared by
+// the 4 lanes of a quad (they fetch the 4 quarters of the same rows): lane q does the division /
+// truncation / clipping of axis q (q < 3) and the row index of corners 2q and 2q+1 (the z pair);
+// everything is exchanged with quad-permute DPP moves, so the int64 hash + prime modulo is evaluated
+// exactly once per corner per level instead of four times.
+__device__ __forceinline__ void fetch_point(const GridDev& g, const LaneLevel& L, int q, float x, float y, float z,
                                             float4* v, float* wts) {
-    int c0[3], c1[3];
-    float t[3];
-    level_corners(x, L.cell, L.res, c0[0], c1[0], t[0]);
-    level_corners(y, L.cell, L.res, c0[1], c1[1], t[1]);
-    level_corners(z, L.cell, L.res, c0[2], c1[2], t[2]);
+    int c0, c1;
+    float t;
+    const float xa = q == 0 ? x : (q == 1 ? y : z);
+    level_corners(xa, L.cell, L.res, c0, c1, t);
+    const int c0x = quad_bcast_i<0>(c0), c1x = quad_bcast_i<0>(c1);
+    const int c0y = quad_bcast_i<1>(c0), c1y = quad_bcast_i<1>(c1);
+    const int c0z = quad_bcast_i<2>(c0), c1z = quad_bcast_i<2>(c1);
+    const float tx = quad_bcast_f<0>(t), ty = quad_bcast_f<1>(t), tz = quad_bcast_f<2>(t);
+    // my two corners: k = 2q (z = c0z) and k = 2q+1 (z = c1z); x bit = q>>1, y bit = q&1
+    const int cx = (q & 2) ? c1x : c0x, cy = (q & 1) ? c1y : c0y;
+    unsigned r0, r1;
+    if (L.hashed) {
+        const uint64_t hxy = (uint64_t)(uint32_t)cx ^ ((uint64_t)(uint32_t)cy * HASH_P1);
+        r0 = hash_mod64(hxy ^ ((uint64_t)(uint32_t)c0z * HASH_P2), g.T, g.inv_T);
+        r1 = hash_mod64(hxy ^ ((uint64_t)(uint32_t)c1z * HASH_P2), g.T, g.inv_T);
+    } else {
+        const unsigned rb = ((unsigned)cx * (unsigned)L.res + (unsigned)cy) * (unsigned)L.res;
+        r0 = rb + (unsigned)c0z;
+        r1 = rb + (unsigned)c1z;
+    }
+    const float ux = 1.0f - tx, uy = 1.0f - ty, uz = 1.0f - tz;
+    unsigned row[8];
+    row[0] = (unsigned)quad_bcast_i<0>((int)r0); row[1] = (unsigned)quad_bcast_i<0>((int)r1);
+    row[2] = (unsigned)quad_bcast_i<1>((int)r0); row[3] = (unsigned)quad_bcast_i<1>((int)r1);
+    row[4] = (unsigned)quad_bcast_i<2>((int)r0); row[5] = (unsigned)quad_bcast_i<2>((int)r1);
+    row[6] = (unsigned)quad_bcast_i<3>((int)r0); row[7] = (unsigned)quad_bcast_i<3>((int)r1);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const int cx = (k & 4) ? c1[0] : c0[0], cy = (k & 2) ? c1[1] : c0[1], cz = (k & 1) ? c1[2] : c0[2];
-        const float wx = (k & 4) ? t[0] : 1.0f - t[0], wy = (k & 2) ? t[1] : 1.0f - t[1], wz = (k & 1) ? t[2] : 1.0f - t[2];
-        wts[k] = wx * wy * wz;
-        int64_t row;
-        if (L.hashed) row = hash_mod((uint32_t)cx, (uint32_t)cy, (uint32_t)cz, g.T, g.inv_T);
-        else row = (int64_t)cx * L.res * L.res + (int64_t)cy * L.res + cz;
-        v[k] = L.tab[row * 4];                                  // 16 floats per row = 4 float4
+        // weight_k = prod_axis ((1-o) + (2o-1) t)  (:157-158), offsets 000,001,..,111 (x y z)
+        wts[k] = ((k & 4) ? tx : ux) * ((k & 2) ? ty : uy) * ((k & 1) ? tz : uz);
+        v[k] = L.tab[(size_t)row[k] * 4];                       // 16 floats per row = 4 float4
     }
 }
 
@@ -139,8 +167,8 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_part_encode(GridDev g, const floa
             const int j1 = min(j + 1, m - 1);
             float4 va[8], vb[8];
             float wa[8], wb[8];
-            fetch_point(g, L, rdlane(xi, j), rdlane(yi, j), rdlane(zi, j), va, wa);
-            fetch_point(g, L, rdlane(xi, j1), rdlane(yi, j1), rdlane(zi, j1), vb, wb);
+            fetch_point(g, L, q, rdlane(xi, j), rdlane(yi, j), rdlane(zi, j), va, wa);
+            fetch_point(g, L, q, rdlane(xi, j1), rdlane(yi, j1), rdlane(zi, j1), vb, wb);
             const float sa = reduce_point(va, wa);
             const float sb = reduce_point(vb, wb);
             if (q == 0) {
