@@ -42,7 +42,9 @@ __device__ __forceinline__ void grid_encode_concat(const GridDev& g, const float
     float x[3];
     grid_normalise(g, xyz, x);
     out[0] = x[0]; out[1] = x[1]; out[2] = x[2];
-#pragma unroll
+    // two levels (16 row fetches) in flight at a time: full unrolling hoists all 8*L fetches and
+    // costs > 200 VGPRs (2 waves/SIMD) for no extra memory-level parallelism that matters here
+#pragma unroll 2
     for (int l = 0; l < L; ++l) {
         int64_t rows[8];
         float wts[8];

@@ -159,9 +159,7 @@ static size_t carve(Workspace& w, void* base, int64_t N, int64_t cap) {
     w.knn.mpad = KNN_MAX_PART;
     w.knn.cpad = KNN_MAX_PART / 64;
     w.knn.sverts = c.take<float4>((size_t)INVR_NUM_PARTS * w.knn.mpad);
-    w.knn.cl_lo = c.take<float4>((size_t)INVR_NUM_PARTS * w.knn.cpad);
-    w.knn.cl_hi = c.take<float4>((size_t)INVR_NUM_PARTS * w.knn.cpad);
-    w.knn.cl_rep = c.take<float4>((size_t)INVR_NUM_PARTS * w.knn.cpad);
+    w.knn.cl = c.take<float4>((size_t)INVR_NUM_PARTS * w.knn.cpad * 3);
     w.mask = c.take<unsigned long long>(nb * 4);
     w.block_cnt = c.take<int32_t>(nb);
     w.block_off = c.take<int32_t>(nb);

@@ -215,9 +215,9 @@ __global__ __launch_bounds__(PREP_T) void k_part_prepare(SceneDev s, KnnIndex ix
         }
         if (lane == 0) {
             const int64_t co = (int64_t)p * ix.cpad + c;
-            ix.cl_lo[co] = make_float4(clo[0], clo[1], clo[2], 0.f);
-            ix.cl_hi[co] = make_float4(chi[0], chi[1], chi[2], 0.f);
-            ix.cl_rep[co] = make_float4(x[0], x[1], x[2], 0.f);       // lane 0 = first vertex of the cluster
+            ix.cl[co * 3 + 0] = make_float4(clo[0], clo[1], clo[2], 0.f);
+            ix.cl[co * 3 + 1] = make_float4(chi[0], chi[1], chi[2], 0.f);
+            ix.cl[co * 3 + 2] = make_float4(x[0], x[1], x[2], 0.f);     // lane 0 = first vertex of the cluster
         }
     }
 }
@@ -229,12 +229,23 @@ __device__ __forceinline__ float aabb_dist2(float px, float py, float pz, float4
     return ex * ex + ey * ey + ez * ez;
 }
 
+#define KNN_VB 8      // vertices per scalar-load batch
 __device__ __forceinline__ void scan_cluster(const float4* __restrict__ sv, int n, float px, float py, float pz, Top4& t) {
-#pragma unroll 4
-    for (int j = 0; j < n; ++j) {
-        const float4 v = sv[j];                                     // wave-uniform address
-        const float dx = px - v.x, dy = py - v.y, dz = pz - v.z;
-        t.push(dx * dx + dy * dy + dz * dz, __float_as_int(v.w));   // ((p1-p2)**2).sum(-1)
+    // straight-line batches: 8 wave-uniform 16-byte records are fetched together (merged into wide
+    // s_load's), then the 8 squared distances are formed branch-free, then the sorted inserts run.
+    for (int j0 = 0; j0 < n; j0 += KNN_VB) {
+        float4 v[KNN_VB];
+#pragma unroll
+        for (int k = 0; k < KNN_VB; ++k) v[k] = sv[min(j0 + k, n - 1)];      // wave-uniform addresses
+        float d2[KNN_VB];
+#pragma unroll
+        for (int k = 0; k < KNN_VB; ++k) {
+            const float dx = px - v[k].x, dy = py - v[k].y, dz = pz - v[k].z;
+            d2[k] = dx * dx + dy * dy + dz * dz;                             // ((p1-p2)**2).sum(-1)
+        }
+#pragma unroll
+        for (int k = 0; k < KNN_VB; ++k)
+            if (j0 + k < n) t.push(d2[k], __float_as_int(v[k].w));
     }
 }
 
@@ -242,8 +253,7 @@ __device__ __forceinline__ void scan_cluster(const float4* __restrict__ sv, int 
 // Workspace) so that the compiler can prove them read-only and fetch the wave-uniform cluster and
 // vertex records through the scalar cache (s_load) instead of the vector memory path.
 __global__ __launch_bounds__(KNN_BLOCK) void k_knn_pairs(RenderArgs a, Workspace w,
-                                                         const float4* __restrict__ g_sverts, const float4* __restrict__ g_lo,
-                                                         const float4* __restrict__ g_hi, const float4* __restrict__ g_rep,
+                                                         const float4* __restrict__ g_sverts, const float4* __restrict__ g_cl,
                                                          const float* __restrict__ g_aabb, int mpad, int cpad) {
     const int na = w.counters[CNT_ACTIVE];
     const int lane = threadIdx.x & 63;
@@ -263,19 +273,23 @@ __global__ __launch_bounds__(KNN_BLOCK) void k_knn_pairs(RenderArgs a, Workspace
                 continue;
             }
             const int ncl = (len + 63) >> 6;
-            const float4* __restrict__ clo = g_lo + (int64_t)p * cpad;
-            const float4* __restrict__ chi = g_hi + (int64_t)p * cpad;
-            const float4* __restrict__ crep = g_rep + (int64_t)p * cpad;
+            const float4* __restrict__ cl = g_cl + (int64_t)p * cpad * 3;      // records {lo, hi, rep}
             const float4* __restrict__ sv = g_sverts + (int64_t)p * mpad;
             // bounds on the nearest-vertex distance from the cluster records
             float lb2 = __builtin_inff(), ub2 = __builtin_inff();
             int seed = 0;
-            for (int c = 0; c < ncl; ++c) {
-                const float4 r = crep[c];
-                const float dx = px - r.x, dy = py - r.y, dz = pz - r.z;
-                const float u = dx * dx + dy * dy + dz * dz;
-                if (u < ub2) { ub2 = u; seed = c; }
-                lb2 = fminf(lb2, aabb_dist2(px, py, pz, clo[c], chi[c]));
+            for (int c0 = 0; c0 < ncl; c0 += 4) {
+                float4 rec[12];
+#pragma unroll
+                for (int k = 0; k < 12; ++k) rec[k] = cl[min(c0 + k / 3, ncl - 1) * 3 + (k % 3)];    // wave-uniform
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float4 r = rec[k * 3 + 2];
+                    const float dx = px - r.x, dy = py - r.y, dz = pz - r.z;
+                    const float u = dx * dx + dy * dy + dz * dz;
+                    if (u < ub2) { ub2 = u; seed = min(c0 + k, ncl - 1); }
+                    lb2 = fminf(lb2, aabb_dist2(px, py, pz, rec[k * 3], rec[k * 3 + 1]));
+                }
             }
             const bool is_far = lb2 > KNN_DFAR2;
             const bool unflagged = lb2 >= a.scene.near_hi2 && ub2 <= a.scene.band_lo2;
@@ -289,7 +303,7 @@ __global__ __launch_bounds__(KNN_BLOCK) void k_knn_pairs(RenderArgs a, Workspace
             scan_cluster(sv + seed_c * 64, min(64, len - seed_c * 64), px, py, pz, t);
             for (int c = 0; c < ncl; ++c) {
                 if (c == seed_c) continue;
-                const bool need = scan && aabb_dist2(px, py, pz, clo[c], chi[c]) < t.d[3];
+                const bool need = scan && aabb_dist2(px, py, pz, cl[c * 3], cl[c * 3 + 1]) < t.d[3];
                 if (__ballot(need) == 0) continue;
                 scan_cluster(sv + c * 64, min(64, len - c * 64), px, py, pz, t);
             }
@@ -340,8 +354,8 @@ int launch_knn_pairs(const RenderArgs& a, const Workspace& w, hipStream_t st) {
     INVR_LAUNCH_CHECK();
     int64_t tiles = cdiv(w.cap, KNN_BLOCK);
     unsigned grid = (unsigned)(tiles < 256 * 8 ? (tiles > 0 ? tiles : 1) : 256 * 8);
-    hipLaunchKernelGGL(k_knn_pairs, dim3(grid), dim3(KNN_BLOCK), 0, st, a, w, w.knn.sverts, w.knn.cl_lo, w.knn.cl_hi,
-                       w.knn.cl_rep, w.knn.part_aabb, w.knn.mpad, w.knn.cpad);
+    hipLaunchKernelGGL(k_knn_pairs, dim3(grid), dim3(KNN_BLOCK), 0, st, a, w, w.knn.sverts, w.knn.cl,
+                       w.knn.part_aabb, w.knn.mpad, w.knn.cpad);
     INVR_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_append_const_pairs, dim3(1), dim3(64), 0, st, w);
     INVR_LAUNCH_CHECK();

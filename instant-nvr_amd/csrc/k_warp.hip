@@ -41,11 +41,11 @@ __device__ __forceinline__ void inverse3x3(const Mat34& M, float* inv) {
     inv[6] = m02 / den;  inv[7] = -m12 / den; inv[8] = m22 / den;
 }
 
-__device__ __forceinline__ void warp_point(const SceneDev& s, const float* bw, const float* pp, const float* pd,
-                                           float* xb, float* db) {
+__device__ __forceinline__ void warp_point(const float* __restrict__ A, const float* __restrict__ big_A, const float* bw,
+                                           const float* pp, const float* pd, float* xb, float* db) {
     Mat34 Aw, Bw;
-    blend_mats(s.A, bw, Aw);
-    blend_mats(s.big_A, bw, Bw);
+    blend_mats(A, bw, Aw);
+    blend_mats(big_A, bw, Bw);
     float inv[9];
     inverse3x3(Aw, inv);
     const float x0 = pp[0] - Aw.m[3], x1 = pp[1] - Aw.m[7], x2 = pp[2] - Aw.m[11];
@@ -63,16 +63,16 @@ __device__ __forceinline__ void warp_point(const SceneDev& s, const float* bw, c
 }
 
 // Deformer.forward for one canonical point (uv_deformer.py:31-38)
-__device__ __forceinline__ void deform_point(const SceneDev& s, const GridDev& dg, const MlpDev& dm, const float* xb, float* resd) {
+__device__ __forceinline__ void deform_point(const SceneDev& s, const GridDev& dg, const float* __restrict__ W0,
+                                             const float* __restrict__ B0, const float* __restrict__ W1,
+                                             const float* __restrict__ B1, const float* __restrict__ W2,
+                                             const float* __restrict__ B2, const float* xb, float* resd) {
     float uvt[3];
     sample_volume_dev<2>(s.tuv, 0, xb[0], xb[1], xb[2], uvt);
     uvt[2] = s.frame_dim[0];
     float feat[19];
     grid_encode_concat<8, 2>(dg, uvt, feat);
     float h1[32], h2[32];
-    const float* __restrict__ W0 = dm.w[0]; const float* __restrict__ B0 = dm.b[0];
-    const float* __restrict__ W1 = dm.w[1]; const float* __restrict__ B1 = dm.b[1];
-    const float* __restrict__ W2 = dm.w[2]; const float* __restrict__ B2 = dm.b[2];
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
         float acc = B0[j];
@@ -97,7 +97,11 @@ __device__ __forceinline__ void deform_point(const SceneDev& s, const GridDev& d
 }
 
 // ---- dense variant (invr_warp_deform): every (point, part) --------------------------------------
-__global__ __launch_bounds__(WARP_BLOCK) void k_warp_dense(SceneDev s, GridDev dg, MlpDev dm, const float* pose_pts,
+__global__ __launch_bounds__(WARP_BLOCK) void k_warp_dense(SceneDev s, GridDev dg, const float* __restrict__ A,
+                                                           const float* __restrict__ big_A, const float* __restrict__ W0,
+                                                           const float* __restrict__ B0, const float* __restrict__ W1,
+                                                           const float* __restrict__ B1, const float* __restrict__ W2,
+                                                           const float* __restrict__ B2, const float* pose_pts,
                                                            const float* pose_dirs, const float* bw, const uint8_t* flag,
                                                            int64_t n, float* tpose, float* tdirs, float* resd) {
     int64_t q = (int64_t)blockIdx.x * WARP_BLOCK + threadIdx.x;     // pair index = point*P + part
@@ -107,8 +111,8 @@ __global__ __launch_bounds__(WARP_BLOCK) void k_warp_dense(SceneDev s, GridDev d
 #pragma unroll
     for (int j = 0; j < INVR_NUM_JOINTS; ++j) b[j] = bw[q * INVR_NUM_JOINTS + j];
     float xb[3], db[3], r[3] = {0.f, 0.f, 0.f};
-    warp_point(s, b, pose_pts + i * 3, pose_dirs + i * 3, xb, db);
-    if (flag[q]) deform_point(s, dg, dm, xb, r);
+    warp_point(A, big_A, b, pose_pts + i * 3, pose_dirs + i * 3, xb, db);
+    if (flag[q]) deform_point(s, dg, W0, B0, W1, B1, W2, B2, xb, r);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         tpose[q * 3 + c] = xb[c] + r[c];
@@ -122,13 +126,18 @@ int launch_warp_deform_dense(const SceneDev& s, const GridDev& dg, const MlpDev&
                              float* tpose, float* tdirs, float* resd, hipStream_t st) {
     if (n == 0) return 0;
     hipLaunchKernelGGL(k_warp_dense, dim3((unsigned)cdiv(n * INVR_NUM_PARTS, WARP_BLOCK)), dim3(WARP_BLOCK), 0, st,
-                       s, dg, dm, pose_pts, pose_dirs, bw, flag, n, tpose, tdirs, resd);
+                       s, dg, s.A, s.big_A, dm.w[0], dm.b[0], dm.w[1], dm.b[1], dm.w[2], dm.b[2], pose_pts, pose_dirs, bw, flag, n,
+                       tpose, tdirs, resd);
     INVR_LAUNCH_CHECK();
     return 0;
 }
 
 // ---- pipeline variant: walks the per-part pair lists --------------------------------------------
-__global__ __launch_bounds__(WARP_BLOCK) void k_warp_pairs(RenderArgs a, Workspace w, GridDev dg, MlpDev dm) {
+// Two kernels so that neither carries the other's live state (LBS: 24 blend weights + two 3x4
+// matrices; deformer: 19 features + two 32-wide hidden layers): each fits well under 128 VGPRs and
+// runs at >= 4 waves/SIMD instead of the 2 waves/SIMD (256 VGPRs) of the fused form.
+__global__ __launch_bounds__(WARP_BLOCK) void k_warp_pairs(RenderArgs a, Workspace w, const float* __restrict__ A,
+                                                           const float* __restrict__ big_A) {
     const int p = blockIdx.y;
     const int cnt = w.counters[CNT_PAIRS + p];
     const float* __restrict__ pb = a.scene.part_pbw + (int64_t)p * a.scene.M * INVR_NUM_JOINTS;
@@ -149,26 +158,44 @@ __global__ __launch_bounds__(WARP_BLOCK) void k_warp_pairs(RenderArgs a, Workspa
             b[j * 4 + 2] = v0.z * wt.x + v1.z * wt.y + v2.z * wt.z + v3.z * wt.w;
             b[j * 4 + 3] = v0.w * wt.x + v1.w * wt.y + v2.w * wt.z + v3.w * wt.w;
         }
-        float pp[3], pd[3], xb[3], db[3], r[3];
+        float pp[3], pd[3], xb[3], db[3];
         sample_pose_point(a, w.active_idx[slot], pp[0], pp[1], pp[2], nullptr, pd);
-        warp_point(a.scene, b, pp, pd, xb, db);
-        deform_point(a.scene, dg, dm, xb, r);
+        warp_point(A, big_A, b, pp, pd, xb, db);
         if (!a.scene.tpose_viewdir) {                       // cfg.tpose_viewdir False: world view dir
             int64_t ray = w.active_idx[slot] / a.S;
             db[0] = a.ray_d[ray * 3]; db[1] = a.ray_d[ray * 3 + 1]; db[2] = a.ray_d[ray * 3 + 2];
         }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            w.l_x[p][c * w.lcap + i] = xb[c] + r[c];          // tpose = init_bigpose + resd (:111)
+            w.l_x[p][c * w.lcap + i] = xb[c];                // init_bigpose
             w.l_d[p][c * w.lcap + i] = db[c];
         }
+    }
+}
+
+__global__ __launch_bounds__(WARP_BLOCK) void k_deform_pairs(RenderArgs a, Workspace w, GridDev dg,
+                                                             const float* __restrict__ W0, const float* __restrict__ B0,
+                                                             const float* __restrict__ W1, const float* __restrict__ B1,
+                                                             const float* __restrict__ W2, const float* __restrict__ B2) {
+    const int p = blockIdx.y;
+    const int cnt = w.counters[CNT_PAIRS + p];
+    for (int64_t i = (int64_t)blockIdx.x * WARP_BLOCK + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * WARP_BLOCK) {
+        float xb[3], r[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) xb[c] = w.l_x[p][c * w.lcap + i];
+        deform_point(a.scene, dg, W0, B0, W1, B1, W2, B2, xb, r);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) w.l_x[p][c * w.lcap + i] = xb[c] + r[c];     // tpose = init_bigpose + resd (:111)
     }
 }
 
 int launch_warp_pairs(const RenderArgs& a, const Workspace& w, const GridDev& dg, const MlpDev& dm, hipStream_t st) {
     int64_t tiles = cdiv(w.lcap, WARP_BLOCK);
     unsigned gx = (unsigned)(tiles < 1024 ? (tiles > 0 ? tiles : 1) : 1024);
-    hipLaunchKernelGGL(k_warp_pairs, dim3(gx, INVR_NUM_PARTS), dim3(WARP_BLOCK), 0, st, a, w, dg, dm);
+    hipLaunchKernelGGL(k_warp_pairs, dim3(gx, INVR_NUM_PARTS), dim3(WARP_BLOCK), 0, st, a, w, a.scene.A, a.scene.big_A);
+    INVR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_deform_pairs, dim3(gx, INVR_NUM_PARTS), dim3(WARP_BLOCK), 0, st, a, w, dg, dm.w[0], dm.b[0], dm.w[1],
+                       dm.b[1], dm.w[2], dm.b[2]);
     INVR_LAUNCH_CHECK();
     return 0;
 }

@@ -22,9 +22,8 @@ struct RenderArgs {
 // per-frame KNN acceleration index built by k_part_prepare
 struct KnnIndex {
     float4* sverts;      // P*mpad : Morton-sorted vertices {x,y,z,original row}
-    float4* cl_lo;       // P*cpad : 64-vertex cluster AABB min
-    float4* cl_hi;       // P*cpad : 64-vertex cluster AABB max
-    float4* cl_rep;      // P*cpad : first vertex of the cluster (upper bound of the nearest distance)
+    float4* cl;          // P*cpad*3 : per 64-vertex cluster {AABB min, AABB max, first vertex (an upper
+                         //            bound of the nearest distance)}
     float* part_aabb;    // P*6
     int32_t mpad, cpad;
 };
