@@ -24,6 +24,7 @@
 // writes them as float4 {x,y,z,original row} and builds 64-vertex clusters {AABB, representative}.
 // The query kernel is one thread per point; cluster records and vertices are wave-uniform reads
 // (scalar path / broadcast), pruned per wave with lb(cluster) < current 4th-best.
+#include <stdlib.h>
 #include "pipeline.h"
 
 #define KNN_BLOCK 256
@@ -40,16 +41,15 @@ struct Top4 {
 #pragma unroll
         for (int k = 0; k < KNN_K; ++k) { d[k] = __builtin_inff(); i[k] = 0; }
     }
+    // sorted insert: ONE (usually wave-skipped) branch, the shifting is predicated selects — the
+    // nested-branch form costs ~10 scalar-ALU instructions per vertex and the CU has a single SALU
     __device__ __forceinline__ void push(float v, int idx) {
         if (v < d[3]) {
-            if (v < d[2]) {
-                d[3] = d[2]; i[3] = i[2];
-                if (v < d[1]) {
-                    d[2] = d[1]; i[2] = i[1];
-                    if (v < d[0]) { d[1] = d[0]; i[1] = i[0]; d[0] = v; i[0] = idx; }
-                    else { d[1] = v; i[1] = idx; }
-                } else { d[2] = v; i[2] = idx; }
-            } else { d[3] = v; i[3] = idx; }
+            const bool c2 = v < d[2], c1 = v < d[1], c0 = v < d[0];
+            d[3] = c2 ? d[2] : v;                 i[3] = c2 ? i[2] : idx;
+            d[2] = c1 ? d[1] : (c2 ? v : d[2]);   i[2] = c1 ? i[1] : (c2 ? idx : i[2]);
+            d[1] = c0 ? d[0] : (c1 ? v : d[1]);   i[1] = c0 ? i[0] : (c1 ? idx : i[1]);
+            d[0] = c0 ? v : d[0];                 i[0] = c0 ? idx : i[0];
         }
     }
 };
@@ -194,9 +194,15 @@ __global__ __launch_bounds__(PREP_T) void k_part_prepare(SceneDev s, KnnIndex ix
         }
     // 4. sorted vertices {x,y,z,orig} and clusters of 64
     const int64_t voff = (int64_t)p * ix.mpad;
-    for (int j = threadIdx.x; j < len; j += PREP_T) {
-        int o = (int)(keys[j] & 8191u);
-        ix.sverts[voff + j] = make_float4(v[o * 3], v[o * 3 + 1], v[o * 3 + 2], __int_as_float(o));
+    const int lenp = (len + 63) & ~63;
+    for (int j = threadIdx.x; j < lenp; j += PREP_T) {
+        if (j < len) {
+            int o = (int)(keys[j] & 8191u);
+            ix.sverts[voff + j] = make_float4(v[o * 3], v[o * 3 + 1], v[o * 3 + 2], __int_as_float(o));
+        } else {
+            // sentinel: infinitely far, never enters a top-4 -> clusters are always scanned as 64
+            ix.sverts[voff + j] = make_float4(1e18f, 1e18f, 1e18f, __int_as_float(0));
+        }
     }
     const int ncl = (len + 63) >> 6;
     for (int c = wv; c < ncl; c += PREP_T / 64) {
@@ -229,14 +235,16 @@ __device__ __forceinline__ float aabb_dist2(float px, float py, float pz, float4
     return ex * ex + ey * ey + ez * ez;
 }
 
-#define KNN_VB 8      // vertices per scalar-load batch
-__device__ __forceinline__ void scan_cluster(const float4* __restrict__ sv, int n, float px, float py, float pz, Top4& t) {
-    // straight-line batches: 8 wave-uniform 16-byte records are fetched together (merged into wide
-    // s_load's), then the 8 squared distances are formed branch-free, then the sorted inserts run.
-    for (int j0 = 0; j0 < n; j0 += KNN_VB) {
+#define KNN_VB 8      // vertices per LDS read batch
+__device__ __forceinline__ void scan_cluster(const float4* sv, int n, float px, float py, float pz, Top4& t) {
+    // straight-line batches: 8 wave-uniform (broadcast) 16-byte LDS reads are issued together, the 8
+    // squared distances are formed branch-free, then the predicated sorted inserts run.
+    (void)n;
+#pragma unroll 1
+    for (int j0 = 0; j0 < 64; j0 += KNN_VB) {          // clusters are padded to 64 with far sentinels
         float4 v[KNN_VB];
 #pragma unroll
-        for (int k = 0; k < KNN_VB; ++k) v[k] = sv[min(j0 + k, n - 1)];      // wave-uniform addresses
+        for (int k = 0; k < KNN_VB; ++k) v[k] = sv[j0 + k];                   // wave-uniform addresses
         float d2[KNN_VB];
 #pragma unroll
         for (int k = 0; k < KNN_VB; ++k) {
@@ -244,37 +252,81 @@ __device__ __forceinline__ void scan_cluster(const float4* __restrict__ sv, int 
             d2[k] = dx * dx + dy * dy + dz * dz;                             // ((p1-p2)**2).sum(-1)
         }
 #pragma unroll
-        for (int k = 0; k < KNN_VB; ++k)
-            if (j0 + k < n) t.push(d2[k], __float_as_int(v[k].w));
+        for (int k = 0; k < KNN_VB; ++k) t.push(d2[k], __float_as_int(v[k].w));
     }
 }
 
-// The index arrays are separate __restrict__ kernel parameters (not members of the by-value
-// Workspace) so that the compiler can prove them read-only and fetch the wave-uniform cluster and
-// vertex records through the scalar cache (s_load) instead of the vector memory path.
-__global__ __launch_bounds__(KNN_BLOCK) void k_knn_pairs(RenderArgs a, Workspace w,
-                                                         const float4* __restrict__ g_sverts, const float4* __restrict__ g_cl,
-                                                         const float* __restrict__ g_aabb, int mpad, int cpad) {
+// The whole KNN index (Morton-sorted vertices + cluster records of all 5 parts, ~116 KB for SMPL's
+// 6890 vertices) is staged ONCE per workgroup into LDS (160 KB/CU on MI355X) by persistent
+// 1024-thread workgroups (one per CU, 4 waves/SIMD); every vertex / cluster record is then a
+// wave-uniform (broadcast) ds_read_b128.  (The scalar-cache path was tried first: with a working set
+// of ~7x the 16 KB scalar cache its miss path throttled the kernel to ~30 % VALU utilisation.)
+#define KNN_T 1024
+#define KNN_LDS_MAX_V 8960          // float4 vertices (143 KB) + records must fit 160 KB
+
+#define KNN_LDS_FLOAT4 (32 + KNN_LDS_MAX_V + KNN_LDS_MAX_V / 64 * 3 + 3 * INVR_NUM_PARTS)
+
+struct KnnLds { int voff[INVR_NUM_PARTS], coff[INVR_NUM_PARTS], len[INVR_NUM_PARTS]; };
+
+__global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w, int dbg) {
+    // all LDS is dynamic (a static __shared__ in front would misalign the float4 region, guide G17):
+    // [0,512) B: per-wave pair counts + per-part list bases; then vertices; then cluster records
+    extern __shared__ __attribute__((aligned(16))) float4 lds_raw[];
+    int (*s_cnt)[INVR_NUM_PARTS] = reinterpret_cast<int (*)[INVR_NUM_PARTS]>(lds_raw);
+    int* s_base = reinterpret_cast<int*>(lds_raw) + (KNN_T / 64) * INVR_NUM_PARTS;
+    float4* lds = lds_raw + 32;
+    const KnnIndex& ix = w.knn;
+    // LDS carve from the (device-resident) part lengths: [vertices of part 0..4 | records of part 0..4]
+    KnnLds L;
+    {
+        int off = 0;
+        for (int p = 0; p < INVR_NUM_PARTS; ++p) {
+            L.len[p] = min((int)a.scene.lengths2[p], PREP_MAX);
+            L.voff[p] = off;
+            off += (L.len[p] + 63) / 64 * 64;
+        }
+        if (off > KNN_LDS_MAX_V) {                       // does not fit the LDS-resident design
+            if (threadIdx.x == 0 && blockIdx.x == 0) w.counters[CNT_OVERFLOW] = 2;
+            return;
+        }
+        for (int p = 0; p < INVR_NUM_PARTS; ++p) { L.coff[p] = off; off += (L.len[p] + 63) / 64 * 3; }
+    }
+    // stage vertices and cluster records
+    for (int p = 0; p < INVR_NUM_PARTS; ++p) {
+        const int len = L.len[p], ncl = (len + 63) >> 6;
+        for (int j = threadIdx.x; j < ncl * 64; j += KNN_T) lds[L.voff[p] + j] = ix.sverts[(int64_t)p * ix.mpad + j];
+        for (int j = threadIdx.x; j < ncl * 3; j += KNN_T) lds[L.coff[p] + j] = ix.cl[(int64_t)p * ix.cpad * 3 + j];
+    }
+    __syncthreads();
     const int na = w.counters[CNT_ACTIVE];
     const int lane = threadIdx.x & 63;
-    for (int64_t tile = blockIdx.x; tile * KNN_BLOCK < na; tile += gridDim.x) {
-        const int64_t slot = tile * KNN_BLOCK + threadIdx.x;
+    // dynamic tile scheduling (one ticket per 1024-point tile): tile cost varies ~10x with how many
+    // clusters the points of a tile have to sweep, static striding left a long tail
+    for (;;) {
+        if (threadIdx.x == 0) s_base[INVR_NUM_PARTS] = atomicAdd(&w.counters[CNT_TICKET], 1);
+        __syncthreads();
+        const int64_t tile = s_base[INVR_NUM_PARTS];
+        if (tile * KNN_T >= na) break;
+        const int64_t slot = tile * KNN_T + threadIdx.x;
         const bool live = slot < na;
         float px = 0, py = 0, pz = 0;
         if (live) sample_pose_point(a, w.active_idx[slot], px, py, pz, nullptr, nullptr);
         unsigned flags = 0, farflags = 0;
+        int4 res_nn[INVR_NUM_PARTS];
+        float4 res_w[INVR_NUM_PARTS];
+#pragma unroll
         for (int p = 0; p < INVR_NUM_PARTS; ++p) {
-            const int len = min((int)a.scene.lengths2[p], PREP_MAX);
+            const int len = L.len[p];
             if (len < KNN_K) continue;                     // reference: inf distances -> NaN dist -> unflagged
-            const float* bb = g_aabb + p * 6;
+            const float* bb = ix.part_aabb + p * 6;
             const float lbp = aabb_dist2(px, py, pz, make_float4(bb[0], bb[1], bb[2], 0.f), make_float4(bb[3], bb[4], bb[5], 0.f));
             if (__ballot(live && !(lbp > KNN_DFAR2)) == 0) {          // whole wave far from this part
                 if (live) farflags |= 1u << p;
                 continue;
             }
             const int ncl = (len + 63) >> 6;
-            const float4* __restrict__ cl = g_cl + (int64_t)p * cpad * 3;      // records {lo, hi, rep}
-            const float4* __restrict__ sv = g_sverts + (int64_t)p * mpad;
+            const float4* cl = lds + L.coff[p];                       // records {lo, hi, rep}
+            const float4* sv = lds + L.voff[p];
             // bounds on the nearest-vertex distance from the cluster records
             float lb2 = __builtin_inff(), ub2 = __builtin_inff();
             int seed = 0;
@@ -295,13 +347,13 @@ __global__ __launch_bounds__(KNN_BLOCK) void k_knn_pairs(RenderArgs a, Workspace
             const bool unflagged = lb2 >= a.scene.near_hi2 && ub2 <= a.scene.band_lo2;
             const bool scan = live && !is_far && !unflagged;
             if (live && is_far) farflags |= 1u << p;
-            if (__ballot(scan) == 0) continue;
+            if (__ballot(scan) == 0 || (dbg & 1)) continue;
             // exact 4-NN: seed with the cluster of the wave's first scanning lane, then pruned sweep
             Top4 t;
             t.init();
             const int seed_c = __builtin_amdgcn_readlane(seed, __ffsll((long long)__ballot(scan)) - 1);
             scan_cluster(sv + seed_c * 64, min(64, len - seed_c * 64), px, py, pz, t);
-            for (int c = 0; c < ncl; ++c) {
+            for (int c = 0; c < ncl && !(dbg & 2); ++c) {
                 if (c == seed_c) continue;
                 const bool need = scan && aabb_dist2(px, py, pz, cl[c * 3], cl[c * 3 + 1]) < t.d[3];
                 if (__ballot(need) == 0) continue;
@@ -309,21 +361,38 @@ __global__ __launch_bounds__(KNN_BLOCK) void k_knn_pairs(RenderArgs a, Workspace
             }
             float wt[KNN_K];
             const float ds = knn_weights(t, wt);
-            const bool flag = scan && ds < a.scene.thresh;            // pflag (inb_part_network_multiassign.py:90)
-            const unsigned long long m = __ballot(flag);
-            if (m) {
-                int base = 0;
-                if (lane == (__ffsll((long long)m) - 1)) base = atomicAdd(&w.counters[CNT_PAIRS + p], __popcll(m));
-                base = __shfl(base, __ffsll((long long)m) - 1);
-                if (flag) {
-                    const int64_t pos = base + __popcll(m & ((1ull << lane) - 1ull));
-                    w.l_slot[p][pos] = (int32_t)slot;
-                    reinterpret_cast<int4*>(w.l_nn[p])[pos] = make_int4(t.i[0], t.i[1], t.i[2], t.i[3]);
-                    reinterpret_cast<float4*>(w.l_w[p])[pos] = make_float4(wt[0], wt[1], wt[2], wt[3]);
-                    flags |= 1u << p;
-                }
+            if (scan && ds < a.scene.thresh) {                        // pflag (inb_part_network_multiassign.py:90)
+                flags |= 1u << p;
+                res_nn[p] = make_int4(t.i[0], t.i[1], t.i[2], t.i[3]);
+                res_w[p] = make_float4(wt[0], wt[1], wt[2], wt[3]);
             }
         }
+        // list append, aggregated per workgroup-tile: 5 global atomics per 1024 points instead of one
+        // returned atomic per wave per part (whose contended latency dominated the kernel)
+        const int wv = threadIdx.x >> 6;
+        unsigned long long bal[INVR_NUM_PARTS];
+#pragma unroll
+        for (int p = 0; p < INVR_NUM_PARTS; ++p) {
+            bal[p] = __ballot((flags >> p) & 1u);
+            if (lane == 0) s_cnt[wv][p] = __popcll(bal[p]);
+        }
+        __syncthreads();
+        if (threadIdx.x < INVR_NUM_PARTS) {
+            int tot = 0;
+            for (int k = 0; k < KNN_T / 64; ++k) { int c = s_cnt[k][threadIdx.x]; s_cnt[k][threadIdx.x] = tot; tot += c; }
+            s_base[threadIdx.x] = tot ? atomicAdd(&w.counters[CNT_PAIRS + threadIdx.x], tot) : 0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < INVR_NUM_PARTS; ++p) {
+            if ((flags >> p) & 1u) {
+                const int64_t pos = s_base[p] + s_cnt[wv][p] + __popcll(bal[p] & ((1ull << lane) - 1ull));
+                w.l_slot[p][pos] = (int32_t)slot;
+                reinterpret_cast<int4*>(w.l_nn[p])[pos] = res_nn[p];
+                reinterpret_cast<float4*>(w.l_w[p])[pos] = res_w[p];
+            }
+        }
+        __syncthreads();          // s_cnt / s_base are reused by the next tile
         if (live) {
             w.pflags[slot] = (uint8_t)flags;
             w.farflags[slot] = (uint8_t)farflags;
@@ -352,10 +421,16 @@ __global__ void k_append_const_pairs(Workspace w) {
 int launch_knn_pairs(const RenderArgs& a, const Workspace& w, hipStream_t st) {
     hipLaunchKernelGGL(k_part_prepare, dim3(INVR_NUM_PARTS), dim3(PREP_T), 0, st, a.scene, w.knn);
     INVR_LAUNCH_CHECK();
-    int64_t tiles = cdiv(w.cap, KNN_BLOCK);
-    unsigned grid = (unsigned)(tiles < 256 * 8 ? (tiles > 0 ? tiles : 1) : 256 * 8);
-    hipLaunchKernelGGL(k_knn_pairs, dim3(grid), dim3(KNN_BLOCK), 0, st, a, w, w.knn.sverts, w.knn.cl,
-                       w.knn.part_aabb, w.knn.mpad, w.knn.cpad);
+    const size_t lds_bytes = (size_t)KNN_LDS_FLOAT4 * sizeof(float4);      // ~150 KB: one workgroup per CU
+    static bool attr_set = false;
+    if (!attr_set) {
+        INVR_HIP(hipFuncSetAttribute((const void*)k_knn_pairs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        attr_set = true;
+    }
+    int64_t tiles = cdiv(w.cap, KNN_T);
+    unsigned grid = (unsigned)(tiles < 256 ? (tiles > 0 ? tiles : 1) : 256);
+    static int dbg = getenv("INVR_KNN_DBG") ? atoi(getenv("INVR_KNN_DBG")) : 0;
+    hipLaunchKernelGGL(k_knn_pairs, dim3(grid), dim3(KNN_T), lds_bytes, st, a, w, dbg);
     INVR_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_append_const_pairs, dim3(1), dim3(64), 0, st, w);
     INVR_LAUNCH_CHECK();

@@ -2,7 +2,7 @@
 #pragma once
 #include "common.h"
 
-enum { CNT_ACTIVE = 0, CNT_PAIRS = 1 /* ..5 */, CNT_OVERFLOW = 6, CNT_FAR = 7 /* ..11 */, CNT_LEN = 16 };
+enum { CNT_ACTIVE = 0, CNT_PAIRS = 1 /* ..5 */, CNT_OVERFLOW = 6, CNT_FAR = 7 /* ..11 */, CNT_TICKET = 12, CNT_LEN = 16 };
 
 #define EMB_K 20            // 19-d encoder output padded to 5 MFMA k-steps
 
