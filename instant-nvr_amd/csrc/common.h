@@ -90,17 +90,40 @@ SceneDev make_scene_dev(const InvrScene* s);
 MlpDev make_mlp_dev(const InvrMlp* m);
 
 // ---- device math ------------------------------------------------------------------------------
-// torch.nn.Softplus(beta=1, threshold=20): x > 20 ? x : log1p(exp(x))
-__device__ __forceinline__ float softplus_f(float x) {
-    // max(x,0) + log1p(exp(-|x|)) is the same function, without overflow, and keeps relative
-    // accuracy for very negative x (the occupancy head needs it: occ = 1-exp(-softplus)).
-    float e = __expf(-fabsf(x));
-    float l = (e < 1e-4f) ? e * (1.0f - 0.5f * e) : __logf(1.0f + e);
-    float r = fmaxf(x, 0.0f) + l;
-    return x > 20.0f ? x : r;
-}
+// Raw transcendental pipes (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1 ulp, no denormal fix-up code).
+#define INVR_LOG2E 1.4426950408889634f
+#define INVR_LN2 0.6931471805599453f
+__device__ __forceinline__ float exp2_raw(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float log2_raw(float x) { return __builtin_amdgcn_logf(x); }
 
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// torch.nn.Softplus(beta=1, threshold=20): x > 20 ? x : log1p(exp(x)).
+// Evaluated as max(x,0) + ln2*log2(1 + exp2(-|x| log2e)): branch-free, 6 VALU ops, absolute error
+// < 1.5e-7 (1+e rounds at 6e-8; the reference keeps relative accuracy for very negative x, the
+// path only needs 1e-4 absolute at the pixel).  For x > 20 the correction is < 2.1e-9 < ulp(20)/2,
+// so the result is x exactly, as with the reference's threshold.
+__device__ __forceinline__ float softplus_f(float x) {
+    const float e = exp2_raw(-fabsf(x) * INVR_LOG2E);
+    return fmaf(log2_raw(1.0f + e), INVR_LN2, fmaxf(x, 0.0f));
+}
+// 1 - exp(-s), s >= 0
+__device__ __forceinline__ float one_minus_exp_neg(float s) { return 1.0f - exp2_raw(-s * INVR_LOG2E); }
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + exp2_raw(-x * INVR_LOG2E)); }
+
+// sin and cos of a moderate argument (|a| < ~100): Cody-Waite reduction to [-pi/4, pi/4] by
+// multiples of pi/2 (two-term constant, FMA), Cephes sinf/cosf minimax polynomials; |error| < 2e-7.
+__device__ __forceinline__ void sincos_f(float a, float* sn, float* cs) {
+    const float k = rintf(a * 0.63661977236758134f);
+    float r = fmaf(-k, 1.5707962512969971f, a);        // pi/2 high part
+    r = fmaf(-k, 7.5497894158615964e-8f, r);           // pi/2 low part
+    const float z = r * r;
+    const float s = fmaf(r * z, fmaf(z, fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f), r);
+    const float c = fmaf(z * z, fmaf(z, fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f),
+                         fmaf(-0.5f, z, 1.0f));
+    const int q = (int)k;
+    const float ss = (q & 1) ? c : s, cc = (q & 1) ? s : c;
+    *sn = (q & 2) ? -ss : ss;
+    *cs = ((q + 1) & 2) ? -cc : cc;
+}
 
 // torch.linspace(0,1,S)[i] in float32 (symmetric fill used by ATen's CPU/GPU kernels)
 __device__ __forceinline__ float linspace01(int i, int S) {

@@ -173,7 +173,7 @@ __global__ __launch_bounds__(MLP_BLOCK) void k_part_mlp(PartMlpDev pm, const flo
         for (int cb = 0; cb < MLP_CB; ++cb) {
             feat[cb] = bias4(lds + O_B_OCC2, 0, g);
             float lg = head_dot(h[cb], lds + O_V_OCC, g) + lds[O_V_OCC + 64];
-            occ[cb] = 1.0f - __expf(-softplus_f(lg));             // :52
+            occ[cb] = one_minus_exp_neg(softplus_f(lg));          // 1 - exp(-softplus(h0))  (:52)
         }
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(MLP_BLOCK) void k_part_mlp(PartMlpDev pm, const flo
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 float sn, cs;
-                sincosf(dv[cb][c] * fmul, &sn, &cs);
+                sincos_f(dv[cb][c] * fmul, &sn, &cs);
                 kb[cb][5 + 2 * c] = sn;
                 kb[cb][6 + 2 * c] = cs;
             }
