@@ -142,9 +142,9 @@ __device__ __forceinline__ void sample_volume_dev(const VolDev& v, int c0, float
     float gx = (px - b0x) / (b1x - b0x) * 2.0f - 1.0f;
     float gy = (py - b0y) / (b1y - b0y) * 2.0f - 1.0f;
     float gz = (pz - b0z) / (b1z - b0z) * 2.0f - 1.0f;
-    float ix = ((gx + 1.0f) / 2.0f) * (float)(v.dx - 1);
-    float iy = ((gy + 1.0f) / 2.0f) * (float)(v.dy - 1);
-    float iz = ((gz + 1.0f) / 2.0f) * (float)(v.dz - 1);
+    float ix = ((gx + 1.0f) * 0.5f) * (float)(v.dx - 1);          // /2 == *0.5 exactly in binary fp
+    float iy = ((gy + 1.0f) * 0.5f) * (float)(v.dy - 1);
+    float iz = ((gz + 1.0f) * 0.5f) * (float)(v.dz - 1);
     ix = fminf(fmaxf(ix, 0.0f), (float)(v.dx - 1));
     iy = fminf(fmaxf(iy, 0.0f), (float)(v.dy - 1));
     iz = fminf(fmaxf(iz, 0.0f), (float)(v.dz - 1));

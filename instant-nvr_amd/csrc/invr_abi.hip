@@ -150,7 +150,7 @@ struct Carver {
 #define KNN_MAX_PART 8192
 static size_t carve(Workspace& w, void* base, int64_t N, int64_t cap) {
     Carver c{(char*)base, 0};
-    int64_t nb = cdiv(N, 256);
+    int64_t nb = cdiv(N, 1024);          // cull tiles (k_cull.hip CULL_TILE)
     w.cap = cap;
     const int64_t lc = cap + 1;          // list / slot capacity incl. the far-constant entry
     w.lcap = lc;
@@ -160,7 +160,7 @@ static size_t carve(Workspace& w, void* base, int64_t N, int64_t cap) {
     w.knn.cpad = KNN_MAX_PART / 64;
     w.knn.sverts = c.take<float4>((size_t)INVR_NUM_PARTS * w.knn.mpad);
     w.knn.cl = c.take<float4>((size_t)INVR_NUM_PARTS * w.knn.cpad * 3);
-    w.mask = c.take<unsigned long long>(nb * 4);
+    w.mask = c.take<unsigned long long>(nb * 16);
     w.block_cnt = c.take<int32_t>(nb);
     w.block_off = c.take<int32_t>(nb);
     w.active_idx = c.take<int32_t>(lc);

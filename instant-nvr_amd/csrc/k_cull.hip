@@ -10,28 +10,37 @@
 #include "pipeline.h"
 
 #define CULL_BLOCK 256
+#define CULL_PER 4                      // ray-samples per thread
+#define CULL_TILE (CULL_BLOCK * CULL_PER)
 
+// tile of 1024 consecutive ray-samples per workgroup: sub-tile k holds samples base + k*256 + tid,
+// one 64-bit survivor mask per (sub-tile, wave): mask word index = tile*16 + k*4 + wave
 __global__ __launch_bounds__(CULL_BLOCK) void k_cull_flag(RenderArgs a, Workspace w) {
-    int64_t i = (int64_t)blockIdx.x * CULL_BLOCK + threadIdx.x;
-    bool keep = false;
-    if (i < a.N) {
-        float px, py, pz, z;
-        sample_pose_point(a, i, px, py, pz, &z, nullptr);
-        if (a.z_vals) a.z_vals[i] = z;
-        float pn;
-        sample_volume_dev<1>(a.scene.pbw, a.scene.pbw.c - 1, px, py, pz, &pn);   // distance channel
-        keep = pn < a.scene.thresh;                                               // :135
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __shared__ int cnt[CULL_PER * (CULL_BLOCK / 64)];
+#pragma unroll
+    for (int k = 0; k < CULL_PER; ++k) {
+        const int64_t i = (int64_t)blockIdx.x * CULL_TILE + k * CULL_BLOCK + threadIdx.x;
+        bool keep = false;
+        if (i < a.N) {
+            float px, py, pz, z;
+            sample_pose_point(a, i, px, py, pz, &z, nullptr);
+            if (a.z_vals) a.z_vals[i] = z;
+            float pn;
+            sample_volume_dev<1>(a.scene.pbw, a.scene.pbw.c - 1, px, py, pz, &pn);   // distance channel
+            keep = pn < a.scene.thresh;                                               // :135
+        }
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) {
+            w.mask[(int64_t)blockIdx.x * (CULL_TILE / 64) + k * (CULL_BLOCK / 64) + wv] = m;
+            cnt[k * (CULL_BLOCK / 64) + wv] = __popcll(m);
+        }
     }
-    unsigned long long m = __ballot(keep);
-    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (lane == 0) w.mask[(int64_t)blockIdx.x * (CULL_BLOCK / 64) + wv] = m;
-    __shared__ int cnt[CULL_BLOCK / 64];
-    if (lane == 0) cnt[wv] = __popcll(m);
     __syncthreads();
     if (threadIdx.x == 0) {
         int c = 0;
 #pragma unroll
-        for (int k = 0; k < CULL_BLOCK / 64; ++k) c += cnt[k];
+        for (int k = 0; k < CULL_TILE / 64; ++k) c += cnt[k];
         w.block_cnt[blockIdx.x] = c;
     }
 }
@@ -85,26 +94,31 @@ __global__ __launch_bounds__(SCAN_T) void k_scan_blocks(Workspace w, int64_t nb,
 }
 
 __global__ __launch_bounds__(CULL_BLOCK) void k_compact(RenderArgs a, Workspace w, int64_t max_active) {
-    int64_t i = (int64_t)blockIdx.x * CULL_BLOCK + threadIdx.x;
-    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const unsigned long long* mk = w.mask + (int64_t)blockIdx.x * (CULL_BLOCK / 64);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned long long* mk = w.mask + (int64_t)blockIdx.x * (CULL_TILE / 64);
     int off = w.block_off[blockIdx.x];
-    for (int k = 0; k < wv; ++k) off += __popcll(mk[k]);
-    unsigned long long m = mk[wv];
-    bool keep = (m >> lane) & 1ull;
-    int rank = off + __popcll(m & ((1ull << lane) - 1ull));
-    if (i < a.N) {
-        int slot = -1;
-        if (keep && rank < max_active) {
-            slot = rank;
-            w.active_idx[rank] = (int32_t)i;
+#pragma unroll
+    for (int k = 0; k < CULL_PER; ++k) {
+        const int64_t i = (int64_t)blockIdx.x * CULL_TILE + k * CULL_BLOCK + threadIdx.x;
+        int woff = off;
+        for (int j = 0; j < wv; ++j) woff += __popcll(mk[k * (CULL_BLOCK / 64) + j]);
+        const unsigned long long m = mk[k * (CULL_BLOCK / 64) + wv];
+        const bool keep = (m >> lane) & 1ull;
+        const int rank = woff + __popcll(m & ((1ull << lane) - 1ull));
+        if (i < a.N) {
+            int slot = -1;
+            if (keep && rank < max_active) {
+                slot = rank;
+                w.active_idx[rank] = (int32_t)i;
+            }
+            w.slot_of_sample[i] = slot;
         }
-        w.slot_of_sample[i] = slot;
+        for (int j = 0; j < CULL_BLOCK / 64; ++j) off += __popcll(mk[k * (CULL_BLOCK / 64) + j]);
     }
 }
 
 int launch_cull(const RenderArgs& a, const Workspace& w, int64_t max_active, hipStream_t st) {
-    int64_t nb = cdiv(a.N, CULL_BLOCK);
+    int64_t nb = cdiv(a.N, CULL_TILE);
     hipLaunchKernelGGL(k_cull_flag, dim3((unsigned)nb), dim3(CULL_BLOCK), 0, st, a, w);
     INVR_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(SCAN_T), 0, st, w, nb, max_active);

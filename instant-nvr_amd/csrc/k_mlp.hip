@@ -115,7 +115,7 @@ __device__ __forceinline__ float head_dot(const f32x4* h, const float* wv, int g
 }
 
 template <int NRGB>
-__global__ __launch_bounds__(MLP_BLOCK) void k_part_mlp(PartMlpDev pm, const float* __restrict__ emb,
+__global__ __launch_bounds__(MLP_BLOCK, 3) void k_part_mlp(PartMlpDev pm, const float* __restrict__ emb,
                                                         const float* __restrict__ ds, int64_t stride,
                                                         const int32_t* __restrict__ l_slot,
                                                         const int32_t* __restrict__ count, int64_t cap,
