@@ -136,6 +136,27 @@ int invr_render_fwd(const InvrScene* scene, const InvrModel* model,
                     float* z_vals, int32_t* stats,
                     void* workspace, size_t workspace_bytes, int64_t max_active, void* stream);
 
+/* Byte offsets of the arrays invr_render_fwd leaves in the workspace (for callers that need the
+ * intermediate pair lists: the train-time outputs resd / tpts / tocc of
+ * inb_part_network_multiassign.py:162-165 and the backward pass).  Lists are SoA with stride `lcap`
+ * (= max_active + 1; entry / slot `max_active` is the per-part far-pair constant). */
+typedef struct InvrWsLayout {
+    int64_t cap, lcap;
+    int64_t counters;                      /* int32[16]: INVR_STAT_* layout                        */
+    int64_t active_idx;                    /* int32[lcap]: ray-sample index of each survivor slot  */
+    int64_t slot_of_sample;                /* int32[n_rays*n_samples]: survivor slot or -1         */
+    int64_t pflags, farflags;              /* uint8[lcap]: bit p = (slot, part p) listed / far     */
+    int64_t l_slot[INVR_NUM_PARTS];        /* int32[lcap]: survivor slot of each listed pair       */
+    int64_t l_nn[INVR_NUM_PARTS];          /* int32[lcap*4]                                        */
+    int64_t l_w[INVR_NUM_PARTS];           /* float[lcap*4]                                        */
+    int64_t l_x[INVR_NUM_PARTS];           /* float[3*lcap] SoA: canonical point incl. residual    */
+    int64_t l_d[INVR_NUM_PARTS];           /* float[3*lcap] SoA: canonical view direction          */
+    int64_t l_r[INVR_NUM_PARTS];           /* float[3*lcap] SoA: residual (resd)                   */
+    int64_t emb[2];                        /* float[20*lcap] SoA: encoder output of the last parts */
+    int64_t raws;                          /* float4[lcap*5]: [rgb, occ] per (slot, part)          */
+} InvrWsLayout;
+int invr_workspace_layout(int64_t n_rays, int32_t n_samples, int64_t max_active, InvrWsLayout* out);
+
 /* ---- per-stage timing with HIP events on the caller's stream ----------------------------------
  * invr_profile_enable(1) makes every following invr_render_fwd record a hipEvent before/after each
  * stage (on the stream the kernels are launched on).  invr_profile_read() waits for the recorded
@@ -179,6 +200,16 @@ size_t invr_part_field_workspace(int64_t n);
 int invr_part_field_fwd(const InvrModel* model, int32_t pid, const int64_t* latent_index,
                         const float* tpts, const float* tdirs, int64_t n, float* raw,
                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* Deformer.forward without flag (uv_deformer.py:31-38; Network.resd, inb_part_network_multiassign.py:122-124):
+ * canonical points (n,3) -> residual (n,3).  Uses scene->tuv/tbounds/frame_dim only. */
+int invr_deform_fwd(const InvrScene* scene, const InvrModel* model, const float* pts, int64_t n, float* resd,
+                    void* stream);
+
+/* Distortion regulariser of inb_renderer.py:96-103: sum_ij w_i w_j |m_i - m_j| with
+ * m = (z_i + z_{i+1})/2 (last repeated).  weights, z_vals (n_rays,n_samples) -> out (n_rays). */
+int invr_distortion_fwd(const float* weights, const float* z_vals, int64_t n_rays, int32_t n_samples,
+                        float* out, void* stream);
 
 /* volume_rendering (net_utils.py:18-44) with epsilon 0: raw (n_rays,n_samples,4) ->
  * weights (n_rays,n_samples) [optional], rgb_map (n_rays,3), acc_map (n_rays). */

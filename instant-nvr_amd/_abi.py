@@ -52,10 +52,19 @@ class InvrScene(C.Structure):
                 ('latent_index', C.c_void_p), ('smpl_thresh', C.c_float), ('tpose_viewdir', C.c_int32)]
 
 
+class InvrWsLayout(C.Structure):
+    _fields_ = [('cap', C.c_int64), ('lcap', C.c_int64), ('counters', C.c_int64), ('active_idx', C.c_int64),
+                ('slot_of_sample', C.c_int64), ('pflags', C.c_int64), ('farflags', C.c_int64),
+                ('l_slot', C.c_int64 * NUM_PARTS), ('l_nn', C.c_int64 * NUM_PARTS), ('l_w', C.c_int64 * NUM_PARTS),
+                ('l_x', C.c_int64 * NUM_PARTS), ('l_d', C.c_int64 * NUM_PARTS), ('l_r', C.c_int64 * NUM_PARTS),
+                ('emb', C.c_int64 * 2), ('raws', C.c_int64)]
+
+
 EXPORTS = ['invr_last_error', 'invr_version', 'invr_sizeof', 'invr_workspace_bytes', 'invr_render_fwd',
            'invr_grid_encode_fwd', 'invr_sample_volume', 'invr_knn_blend', 'invr_warp_deform',
            'invr_part_field_workspace', 'invr_part_field_fwd', 'invr_composite_fwd',
-           'invr_profile_enable', 'invr_profile_read']
+           'invr_profile_enable', 'invr_profile_read', 'invr_workspace_layout', 'invr_deform_fwd',
+           'invr_distortion_fwd']
 NUM_STAGES = 14
 STAGE_NAMES = ['cull', 'knn', 'warp'] + ['encode_%d' % p for p in range(5)] + ['mlp_%d' % p for p in range(5)] + ['composite']
 
@@ -90,6 +99,11 @@ def lib():
         L.invr_warp_deform.argtypes = [C.POINTER(InvrScene), C.POINTER(InvrModel), vp, vp, vp, vp, C.c_int64, vp, vp, vp, vp]
         L.invr_part_field_fwd.argtypes = [C.POINTER(InvrModel), C.c_int32, vp, vp, vp, C.c_int64, vp, vp, C.c_size_t, vp]
         L.invr_composite_fwd.argtypes = [vp, C.c_int64, C.c_int32, vp, vp, vp, vp]
+        L.invr_workspace_layout.argtypes = [C.c_int64, C.c_int32, C.c_int64, C.POINTER(InvrWsLayout)]
+        L.invr_deform_fwd.argtypes = [C.POINTER(InvrScene), C.POINTER(InvrModel), vp, C.c_int64, vp, vp]
+        L.invr_distortion_fwd.argtypes = [vp, vp, C.c_int64, C.c_int32, vp, vp]
+        for n in ('invr_workspace_layout', 'invr_deform_fwd', 'invr_distortion_fwd'):
+            getattr(L, n).restype = C.c_int
         L.invr_profile_enable.argtypes = [C.c_int32]
         L.invr_profile_read.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int32)]
         for n in ('invr_render_fwd', 'invr_grid_encode_fwd', 'invr_sample_volume', 'invr_knn_blend',
@@ -114,6 +128,30 @@ def profile_read():
 def check(status):
     if status != 0:
         raise RuntimeError('libinvr: ' + lib().invr_last_error().decode())
+
+
+def ws_views(ws, n_rays, S, max_active, n_active=None):
+    """Zero-copy tensor views of the arrays invr_render_fwd left in the workspace `ws` (uint8 tensor)."""
+    lay = InvrWsLayout()
+    check(lib().invr_workspace_layout(n_rays, S, max_active, C.byref(lay)))
+    lc = lay.lcap
+
+    def view(off, count, dtype):
+        nbytes = count * torch.empty((), dtype=dtype).element_size()
+        return ws[off:off + nbytes].view(dtype)
+    v = {'cap': lay.cap, 'lcap': lc,
+         'counters': view(lay.counters, 16, torch.int32),
+         'active_idx': view(lay.active_idx, lc, torch.int32),
+         'slot_of_sample': view(lay.slot_of_sample, n_rays * S, torch.int32),
+         'pflags': view(lay.pflags, lc, torch.uint8), 'farflags': view(lay.farflags, lc, torch.uint8),
+         'raws': view(lay.raws, lc * NUM_PARTS * 4, torch.float32).view(lc, NUM_PARTS, 4)}
+    for k in ('l_slot', 'l_x', 'l_d', 'l_r'):
+        offs = getattr(lay, k)
+        if k == 'l_slot':
+            v[k] = [view(offs[p], lc, torch.int32) for p in range(NUM_PARTS)]
+        else:
+            v[k] = [view(offs[p], 3 * lc, torch.float32).view(3, lc) for p in range(NUM_PARTS)]
+    return v
 
 
 def stream_ptr():

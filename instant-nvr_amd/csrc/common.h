@@ -203,4 +203,6 @@ int launch_knn_blend_dense(const SceneDev& s, const float* pose_pts, int64_t n, 
 int launch_warp_deform_dense(const SceneDev& s, const GridDev& dg, const MlpDev& dm, const float* pose_pts,
                              const float* pose_dirs, const float* bw, const uint8_t* flag, int64_t n,
                              float* tpose, float* tdirs, float* resd, hipStream_t st);
+int launch_deform_points(const SceneDev& s, const GridDev& dg, const MlpDev& dm, const float* pts, int64_t n, float* out, hipStream_t st);
+int launch_distortion(const float* weights, const float* z, int64_t n_rays, int S, float* out, hipStream_t st);
 int launch_composite(const float* raw, int64_t n_rays, int S, float* weights, float* rgb_map, float* acc_map, hipStream_t st);

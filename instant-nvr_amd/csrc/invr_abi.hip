@@ -173,11 +173,32 @@ static size_t carve(Workspace& w, void* base, int64_t N, int64_t cap) {
         w.l_w[p] = c.take<float>(lc * 4);
         w.l_x[p] = c.take<float>(lc * 3);
         w.l_d[p] = c.take<float>(lc * 3);
+        w.l_r[p] = c.take<float>(lc * 3);
     }
     w.emb[0] = c.take<float>(lc * EMB_K);
     w.emb[1] = c.take<float>(lc * EMB_K);
     w.raws = c.take<float4>(lc * INVR_NUM_PARTS);
     return align_up(c.off, 256);
+}
+
+extern "C" int invr_workspace_layout(int64_t n_rays, int32_t n_samples, int64_t max_active, InvrWsLayout* o) {
+    INVR_CHECK(o != nullptr, "invr_workspace_layout: null output");
+    Workspace w;
+    int64_t N = n_rays * (int64_t)n_samples;
+    if (max_active <= 0 || max_active > N) max_active = N;
+    if (max_active < 1) max_active = 1;
+    char* base = reinterpret_cast<char*>(uintptr_t(1) << 40);        // dummy non-null base: only offsets are used
+    carve(w, base, N > 0 ? N : 1, max_active);
+    auto off = [&](const void* p) { return (int64_t)(reinterpret_cast<const char*>(p) - base); };
+    o->cap = w.cap; o->lcap = w.lcap;
+    o->counters = off(w.counters); o->active_idx = off(w.active_idx); o->slot_of_sample = off(w.slot_of_sample);
+    o->pflags = off(w.pflags); o->farflags = off(w.farflags);
+    for (int p = 0; p < INVR_NUM_PARTS; ++p) {
+        o->l_slot[p] = off(w.l_slot[p]); o->l_nn[p] = off(w.l_nn[p]); o->l_w[p] = off(w.l_w[p]);
+        o->l_x[p] = off(w.l_x[p]); o->l_d[p] = off(w.l_d[p]); o->l_r[p] = off(w.l_r[p]);
+    }
+    o->emb[0] = off(w.emb[0]); o->emb[1] = off(w.emb[1]); o->raws = off(w.raws);
+    return 0;
 }
 
 extern "C" size_t invr_workspace_bytes(int64_t n_rays, int32_t n_samples, int64_t max_active) {
@@ -337,6 +358,23 @@ extern "C" int invr_part_field_fwd(const InvrModel* model, int32_t pid, const in
     if (launch_part_encode(make_grid_dev(&model->part[pid].grid), xs, n, count, n, emb, st)) return 1;
     PartMlpDev pm = make_part_mlp(model, pid, latent_index);
     return launch_part_mlp(pm, emb, ds, n, nullptr, count, n, nullptr, pid, reinterpret_cast<float4*>(raw), st);
+}
+
+extern "C" int invr_deform_fwd(const InvrScene* scene, const InvrModel* model, const float* pts, int64_t n, float* resd,
+                               void* stream) {
+    INVR_CHECK(scene && model && (n == 0 || (pts && resd)), "invr_deform_fwd: null pointer");
+    if (check_grid(&model->deform_grid, "deformer grid") || check_mlp_deform(&model->deform_mlp)) return 1;
+    INVR_CHECK(model->deform_grid.n_levels == 8 && model->deform_grid.n_features == 2 && !model->deform_grid.sum &&
+               model->deform_grid.include_input, "deformer grid must be 8 levels x 2 features, sum=False, include_input");
+    return launch_deform_points(make_scene_dev(scene), make_grid_dev(&model->deform_grid), make_mlp_dev(&model->deform_mlp),
+                                pts, n, resd, (hipStream_t)stream);
+}
+
+extern "C" int invr_distortion_fwd(const float* weights, const float* z_vals, int64_t n_rays, int32_t n_samples,
+                                   float* out, void* stream) {
+    INVR_CHECK(n_rays == 0 || (weights && z_vals && out), "invr_distortion_fwd: null pointer");
+    INVR_CHECK(n_samples >= 1, "invr_distortion_fwd: n_samples must be >= 1");
+    return launch_distortion(weights, z_vals, n_rays, n_samples, out, (hipStream_t)stream);
 }
 
 extern "C" int invr_composite_fwd(const float* raw, int64_t n_rays, int32_t n_samples, float* weights,

@@ -103,3 +103,36 @@ int launch_merge_composite(const RenderArgs& a, const Workspace& w, float* rgb_m
     INVR_LAUNCH_CHECK();
     return 0;
 }
+
+// ---- distortion regulariser (inb_renderer.py:96-103), O(S) per ray with running prefix sums -------
+// sum_ij w_i w_j |m_i - m_j| = 2 * sum_i w_i (m_i * W_<i - M_<i) for ascending m (z is ascending);
+// evaluated in the reference's O(S^2) form when S <= 64 is not needed: both agree to fp32 rounding.
+__global__ __launch_bounds__(CMP_BLOCK) void k_distortion(const float* __restrict__ weights, const float* __restrict__ z,
+                                                          int64_t R, int S, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t ray = (int64_t)blockIdx.x * (CMP_BLOCK / 64) + (threadIdx.x >> 6);
+    if (ray >= R) return;
+    const float* wr = weights + ray * S;
+    const float* zr = z + ray * S;
+    // direct double loop split over lanes (S is 64..128 in practice): lane i accumulates row i
+    float acc = 0.0f;
+    for (int i = lane; i < S; i += 64) {
+        const float mi = (zr[i] + zr[min(i + 1, S - 1)]) / 2.0f;
+        const float wi = wr[i];
+        float row = 0.0f;
+        for (int j = 0; j < S; ++j) {
+            const float mj = (zr[j] + zr[min(j + 1, S - 1)]) / 2.0f;
+            row += (wi * wr[j]) * fabsf(mi - mj);
+        }
+        acc += row;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) out[ray] = acc;
+}
+
+int launch_distortion(const float* weights, const float* z, int64_t n_rays, int S, float* out, hipStream_t st) {
+    if (n_rays == 0) return 0;
+    hipLaunchKernelGGL(k_distortion, dim3((unsigned)cdiv(n_rays, CMP_BLOCK / 64)), dim3(CMP_BLOCK), 0, st, weights, z, n_rays, S, out);
+    INVR_LAUNCH_CHECK();
+    return 0;
+}

@@ -185,7 +185,10 @@ __global__ __launch_bounds__(WARP_BLOCK) void k_deform_pairs(RenderArgs a, Works
         for (int c = 0; c < 3; ++c) xb[c] = w.l_x[p][c * w.lcap + i];
         deform_point(a.scene, dg, W0, B0, W1, B1, W2, B2, xb, r);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) w.l_x[p][c * w.lcap + i] = xb[c] + r[c];     // tpose = init_bigpose + resd (:111)
+        for (int c = 0; c < 3; ++c) {
+            w.l_x[p][c * w.lcap + i] = xb[c] + r[c];     // tpose = init_bigpose + resd (:111)
+            w.l_r[p][c * w.lcap + i] = r[c];
+        }
     }
 }
 
@@ -196,6 +199,27 @@ int launch_warp_pairs(const RenderArgs& a, const Workspace& w, const GridDev& dg
     INVR_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_deform_pairs, dim3(gx, INVR_NUM_PARTS), dim3(WARP_BLOCK), 0, st, a, w, dg, dm.w[0], dm.b[0], dm.w[1],
                        dm.b[1], dm.w[2], dm.b[2]);
+    INVR_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- stand-alone deformer on arbitrary canonical points (invr_deform_fwd) ------------------------
+__global__ __launch_bounds__(WARP_BLOCK) void k_deform_points(SceneDev s, GridDev dg, const float* __restrict__ W0,
+                                                              const float* __restrict__ B0, const float* __restrict__ W1,
+                                                              const float* __restrict__ B1, const float* __restrict__ W2,
+                                                              const float* __restrict__ B2, const float* __restrict__ pts,
+                                                              int64_t n, float* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * WARP_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    float xb[3] = {pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2]}, r[3];
+    deform_point(s, dg, W0, B0, W1, B1, W2, B2, xb, r);
+    out[i * 3] = r[0]; out[i * 3 + 1] = r[1]; out[i * 3 + 2] = r[2];
+}
+
+int launch_deform_points(const SceneDev& s, const GridDev& dg, const MlpDev& dm, const float* pts, int64_t n, float* out, hipStream_t st) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_deform_points, dim3((unsigned)cdiv(n, WARP_BLOCK)), dim3(WARP_BLOCK), 0, st, s, dg, dm.w[0], dm.b[0],
+                       dm.w[1], dm.b[1], dm.w[2], dm.b[2], pts, n, out);
     INVR_LAUNCH_CHECK();
     return 0;
 }

@@ -46,6 +46,7 @@ struct Workspace {
     float* l_w[INVR_NUM_PARTS];           // cap*4 : normalised gaussian weights
     float* l_x[INVR_NUM_PARTS];           // 3*cap : canonical (big-pose + residual) xyz, SoA
     float* l_d[INVR_NUM_PARTS];           // 3*cap : canonical view dir, SoA
+    float* l_r[INVR_NUM_PARTS];           // 3*cap : residual deformation (resd), SoA
     float* emb[2];                        // EMB_K*cap : encoder output, SoA [k][pair] (ping-pong)
     float4* raws;                         // cap*P : [rgb, occ] per (slot, part)
     int64_t cap;                          // max survivors

@@ -166,6 +166,17 @@ class Network(nn.Module):
         keep = []
         return RenderContext(self.model_struct(keep), _abi.make_scene(batch, self.cfg, keep), keep)
 
+    def resd(self, tpts, batch):
+        """Network.resd (inb_part_network_multiassign.py:122-124): deformer residual of canonical
+        points (B,N,3) -> (B,N,3), through invr_deform_fwd."""
+        B, N, D = tpts.shape
+        ctx = batch if isinstance(batch, RenderContext) else self.prepare(batch)
+        x = tpts.detach().reshape(-1, 3).to(torch.float32).contiguous()
+        out = torch.empty_like(x)
+        _abi.check(_abi.lib().invr_deform_fwd(C.byref(ctx.scene), C.byref(ctx.model), _abi.ptr(x), x.shape[0],
+                                              _abi.ptr(out), _abi.stream_ptr()))
+        return out.view(B, N, D)
+
     def render_rays(self, batch, ray_o, ray_d, near, far, n_samples, jitter=None, want_raw=True,
                     want_weights=False, max_active=0):
         """One invr_render_fwd call over a ray list (n,3)/(n,).  `batch` is the collated batch dict
@@ -197,4 +208,5 @@ class Network(nn.Module):
             _abi.ptr(out.get('z_vals')), _abi.ptr(out['stats'], torch.int32),
             C.c_void_p(ws.data_ptr()), nbytes, max_active, _abi.stream_ptr()))
         out['_keep'] = keep
+        out['_ws'] = (ws, n, S, max_active)
         return out

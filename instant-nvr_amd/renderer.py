@@ -5,9 +5,12 @@ dict; the per-chunk Python loop, ``get_wsampling_points``, ``get_density_color``
 forward and ``volume_rendering`` are one stream-ordered libinvr call over the whole ray list
 (chunk-free: HBM holds the full frame's intermediates).
 """
+import ctypes as C
+
 import torch
 
-from .config import cfg as global_cfg
+from . import _abi
+from .config import cfg as global_cfg, NUM_PARTS
 
 MAX_SAMPLES_PER_CALL = (1 << 31) - 1
 
@@ -32,9 +35,9 @@ class Renderer:
         training = self.net.training
         jitter = None
         if cfg.perturb > 0. and training:
-            jitter = torch.rand((n_pixel, S), device=ray_o.device, dtype=torch.float32)    # :24
+            jitter = self._jitter((n_pixel, S), ray_o.device)                              # :24
         if training:
-            raise NotImplementedError('train-mode render (backward kernels) is the next row of SURVEY.md §8(f)')
+            return self._render_train(batch, jitter)
         per_call = max(1, MAX_SAMPLES_PER_CALL // S)
         outs = []
         for i in range(0, n_pixel, per_call):
@@ -49,4 +52,70 @@ class Renderer:
         self.last_stats = outs[-1]['stats']
         if self.eval_to_cpu:
             ret = {k: v.detach().cpu() for k, v in ret.items()}
+        return ret
+
+    def _jitter(self, shape, device):
+        return torch.rand(shape, device=device, dtype=torch.float32)
+
+    # ---- train-mode forward (inb_renderer.py:78-103, inb_part_network_multiassign.py:162-165) ------
+    def _pair_noise(self, like):
+        return torch.rand_like(like)                       # compute_val_pair_around_range (:41)
+
+    def _render_train(self, batch, jitter):
+        """Forward quantities of a training step: rgb_map/acc_map/raw/occ plus the train-only outputs
+        resd, tpts, tocc (dense (Na*P, .) layouts in the reference's row order), oresd (pair
+        regulariser) and reg_distortion_loss.  Gradients: see DESIGN.md (backward kernels = next row)."""
+        cfg, net = self.cfg, self.net
+        S = int(cfg.N_samples)
+        ray_o, ray_d, near, far = batch['ray_o'][0], batch['ray_d'][0], batch['near'][0], batch['far'][0]
+        n = ray_o.shape[0]
+        ctx = net.prepare(batch)
+        out = net.render_rays(ctx, ray_o, ray_d, near, far, S, jitter=jitter, want_raw=True, want_weights=True)
+        stats = out['stats'].cpu()                          # host sync, as the reference's nonzero()s
+        assert int(stats[6]) == 0, 'invr workspace overflow'
+        Na = int(stats[0])
+        ws, _, _, max_active = out['_ws']
+        v = _abi.ws_views(ws, n, S, max_active)
+        cap, dev = v['cap'], ray_o.device
+        P = NUM_PARTS
+        resd = torch.zeros(Na + 1, P, 3, device=dev)
+        tpts = torch.zeros(Na + 1, P, 3, device=dev)
+        tocc = torch.zeros(Na + 1, P, device=dev)
+        raws = v['raws']
+        far = v['farflags'][:Na].to(torch.int32)
+        for p in range(P):
+            cnt = int(stats[1 + p])
+            slots = v['l_slot'][p][:cnt].long()
+            rows = torch.where(slots == cap, torch.full_like(slots, Na), slots)       # const pair -> extra row
+            r = v['l_r'][p][:, :cnt].t()
+            resd[rows, p] = r
+            tpts[rows, p] = v['l_x'][p][:, :cnt].t() - r                                 # init_bigpose
+            tocc[rows, p] = raws[slots, p, 3]
+            fr = ((far >> p) & 1).nonzero(as_tuple=True)[0]                              # far pairs take the constant
+            if fr.numel():
+                resd[fr, p] = resd[Na, p]
+                tpts[fr, p] = tpts[Na, p]
+                tocc[fr, p] = tocc[Na, p]
+        resd, tpts, tocc = resd[:Na], tpts[:Na], tocc[:Na]
+        ret = {'rgb_map': out['rgb_map'][None], 'acc_map': out['acc_map'][None], 'raw': out['raw'][None],
+               'occ': out['occ'][None, :, None], 'resd': resd.reshape(1, -1, 3), 'tpts': tpts.reshape(1, -1, 3),
+               'tocc': tocc.reshape(1, -1, 1)}
+        if cfg.use_pair_reg:                                                             # inb_renderer.py:78-94
+            tflat = tocc.reshape(-1)
+            reg = ((tflat - 0.5).abs() < 0.02).nonzero(as_tuple=True)[0]
+            if reg.numel():
+                reg_tpts = tpts.reshape(-1, 3)[reg][None]
+                reg_resd = resd.reshape(-1, 3)[reg][None]
+                neighbor = reg_tpts + (self._pair_noise(reg_tpts) - 0.5) * 0.01
+                nei = net.resd(neighbor, ctx)
+                ret['oresd'] = torch.cat([reg_resd, nei], dim=1)
+            else:
+                ret['oresd'] = torch.zeros(1, 0, 3, device=dev)
+        if cfg.use_reg_distortion:                                                       # :96-103
+            dl = torch.empty(n, device=dev)
+            _abi.check(_abi.lib().invr_distortion_fwd(_abi.ptr(out['weights']), _abi.ptr(out['z_vals']), n, S,
+                                                      _abi.ptr(dl), _abi.stream_ptr()))
+            ret['reg_distortion_loss'] = dl[None]
+        self.last_stats = out['stats']
+        self.last_train = {'weights': out['weights'], 'z_vals': out['z_vals']}
         return ret

@@ -217,3 +217,36 @@ def test_render_64x64x32_vs_reference_golden(gpu_setup, golden):
     mask = np.ones(raw.shape[0], bool)
     mask[nz] = False
     assert np.abs(raw[mask]).max() == 0.0                                 # untouched samples are exact zeros
+
+
+def test_train_mode_forward_vs_reference_golden(gpu_setup, golden):
+    """Train-mode forward (fixed jitter / pair noise): rgb_map, dense resd/tocc layouts, oresd and the
+    distortion regulariser against the reference, and NetworkWrapper's loss assembly."""
+    from invr.trainer import NetworkWrapper
+    cfg, sd, batch, gb, net = gpu_setup
+    tsel = torch.from_numpy(golden['train_rays'].astype(np.int64)).to(DEV)
+    tb = dict(gb)
+    for k in ('ray_o', 'ray_d', 'near', 'far', 'rgb', 'occupancy'):
+        tb[k] = gb[k][:, tsel]
+    net.train()
+    try:
+        wrap = NetworkWrapper(net)
+        r = wrap.renderer
+        r._jitter = lambda shape, device: cu(golden['train_jitter'][0])
+        r._pair_noise = lambda like: cu(golden['train_pair_u'])
+        with torch.no_grad():
+            ret, loss, stats, _ = wrap(tb, split='train')
+    finally:
+        net.eval()
+    assert maxerr(ret['rgb_map'], golden['train_rgb_map']) < 1e-4
+    assert maxerr(ret['acc_map'], golden['train_acc_map']) < 1e-4
+    assert ret['resd'].shape == golden['train_resd'].shape and ret['tocc'].shape == golden['train_tocc'].shape
+    assert maxerr(ret['resd'], golden['train_resd']) < 5e-6
+    assert maxerr(ret['tocc'], golden['train_tocc']) < 1e-3        # far pairs are extrapolated (see test_part_fields)
+    assert ret['oresd'].shape == golden['train_oresd'].shape
+    assert maxerr(ret['oresd'], golden['train_oresd']) < 5e-6
+    assert maxerr(ret['reg_distortion_loss'], golden['train_reg_distortion_loss']) < 1e-5
+    # golden loss = mse + 0.1*dist + 0.1*offset (make_golden.py); ours adds pair_loss_weight*pair
+    pair = float(stats['pair_loss'])
+    mine = float(loss) - cfg.pair_loss_weight * pair
+    assert abs(mine - float(golden['train_loss'])) < 1e-5
