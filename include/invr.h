@@ -177,6 +177,12 @@ int invr_profile_read(float* ms, int32_t* n_renders);
 /* HashEmbedder.forward (part_base_embedder.py:106-174).  xyz (n,3) -> out (n,out_dim). */
 int invr_grid_encode_fwd(const InvrGrid* grid, const float* xyz, int64_t n, float* out, void* stream);
 
+/* Backward of invr_grid_encode_fwd (autograd of part_base_embedder.py:106-174): g_out (n,out_dim) ->
+ * ACCUMULATES (atomic float adds) into g_dense (dense_rows,F) / g_hash (same shape as grid->hash), both
+ * caller-zeroed, and writes g_xyz (n,3) (gradient w.r.t. the un-normalised input; NULL to skip). */
+int invr_grid_encode_bwd(const InvrGrid* grid, const float* xyz, const float* g_out, int64_t n,
+                         float* g_dense, float* g_hash, float* g_xyz, void* stream);
+
 /* pts_sample_blend_weights / pts_sample_uv (lib/utils/blend_utils.py:501-555): trilinear,
  * border, align_corners.  vol (Dx,Dy,Dz,C) sampled at channels [c0, c0+nc) -> out (n,nc). */
 int invr_sample_volume(const float* vol, const int32_t dims[3], int32_t channels, int32_t c0, int32_t nc,
@@ -215,6 +221,11 @@ int invr_distortion_fwd(const float* weights, const float* z_vals, int64_t n_ray
  * weights (n_rays,n_samples) [optional], rgb_map (n_rays,3), acc_map (n_rays). */
 int invr_composite_fwd(const float* raw, int64_t n_rays, int32_t n_samples, float* weights,
                        float* rgb_map, float* acc_map, void* stream);
+
+/* Backward of invr_composite_fwd: g_rgb_map (n_rays,3), g_acc_map (n_rays) or NULL, g_weights
+ * (n_rays,n_samples) or NULL (e.g. from the distortion regulariser) -> g_raw (n_rays,n_samples,4). */
+int invr_composite_bwd(const float* raw, const float* g_rgb_map, const float* g_acc_map, const float* g_weights,
+                       int64_t n_rays, int32_t n_samples, float* g_raw, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,197 @@
+"""Differentiable training forward.
+
+Geometry (sampling, cull, KNN skinning, LBS warp, pair lists, far/near classification) carries
+no gradient in the reference (``torch.no_grad`` blocks, inb_part_network_multiassign.py:87-90,
+132-140) and comes from the HIP render pipeline.  The differentiable remainder is recomputed on the
+pair lists with autograd:
+
+    HIP  GridEncodeFn   hash-grid encoder fwd/bwd (invr_grid_encode_fwd / _bwd): table gradients by
+                        atomic adds, gradient w.r.t. the canonical point (feeds the deformer)
+    HIP  CompositeFn    alpha compositing fwd/bwd (invr_composite_fwd / _bwd)
+    torch               the tiny Softplus MLPs (rocBLAS GEMMs), tanh/sigmoid, the (Na,P) merge, the
+                        distortion regulariser — interim: fused HIP backward kernels for these are the
+                        next step
+"""
+import ctypes as C
+
+import torch
+import torch.nn.functional as F
+
+from . import _abi
+from .config import NUM_PARTS
+
+
+class GridEncodeFn(torch.autograd.Function):
+    """HashEmbedder.forward under autograd (part_base_embedder.py:106-174)."""
+
+    @staticmethod
+    def forward(ctx, xyz, dense, hsh, bounds, spec):
+        keep = []
+        g = _abi.make_grid(spec, dense, hsh, bounds, keep)
+        x = xyz.detach().to(torch.float32).contiguous()
+        out = torch.empty(x.shape[0], spec['out_dim'], device=x.device, dtype=torch.float32)
+        _abi.check(_abi.lib().invr_grid_encode_fwd(C.byref(g), _abi.ptr(x), x.shape[0], _abi.ptr(out), _abi.stream_ptr()))
+        ctx.save_for_backward(x, dense, hsh, bounds)
+        ctx.spec = spec
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        x, dense, hsh, bounds = ctx.saved_tensors
+        spec = ctx.spec
+        keep = []
+        g = _abi.make_grid(spec, dense, hsh, bounds, keep)
+        g_out = g_out.to(torch.float32).contiguous()
+        g_hash = torch.zeros_like(hsh)
+        g_dense = torch.zeros_like(dense) if dense is not None else None
+        g_xyz = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        _abi.check(_abi.lib().invr_grid_encode_bwd(C.byref(g), _abi.ptr(x), _abi.ptr(g_out), x.shape[0], _abi.ptr(g_dense),
+                                                   _abi.ptr(g_hash), _abi.ptr(g_xyz), _abi.stream_ptr()))
+        return g_xyz, g_dense, g_hash, None, None
+
+
+class CompositeFn(torch.autograd.Function):
+    """volume_rendering with epsilon 0 (net_utils.py:12-44): raw (R,S,4) -> weights, rgb_map, acc_map."""
+
+    @staticmethod
+    def forward(ctx, raw):
+        raw = raw.detach().to(torch.float32).contiguous()
+        R, S = raw.shape[:2]
+        w = torch.empty(R, S, device=raw.device)
+        rgb = torch.empty(R, 3, device=raw.device)
+        acc = torch.empty(R, device=raw.device)
+        _abi.check(_abi.lib().invr_composite_fwd(_abi.ptr(raw), R, S, _abi.ptr(w), _abi.ptr(rgb), _abi.ptr(acc), _abi.stream_ptr()))
+        ctx.save_for_backward(raw)
+        return w, rgb, acc
+
+    @staticmethod
+    def backward(ctx, g_w, g_rgb, g_acc):
+        (raw,) = ctx.saved_tensors
+        R, S = raw.shape[:2]
+        c = lambda t: None if t is None else t.to(torch.float32).contiguous()
+        g_rgb = c(g_rgb) if g_rgb is not None else torch.zeros(R, 3, device=raw.device)
+        g_raw = torch.empty_like(raw)
+        _abi.check(_abi.lib().invr_composite_bwd(_abi.ptr(raw), _abi.ptr(g_rgb), _abi.ptr(c(g_acc)), _abi.ptr(c(g_w)), R, S,
+                                                 _abi.ptr(g_raw), _abi.stream_ptr()))
+        return g_raw
+
+
+def sample_volume(vol, bounds, pts, c0, nc):
+    """pts_sample_uv / pts_sample_blend_weights (blend_utils.py:501-555), no gradient."""
+    vol = vol.contiguous()
+    dims = (C.c_int32 * 3)(*vol.shape[:3])
+    pts = pts.detach().to(torch.float32).contiguous()
+    out = torch.empty(pts.shape[0], nc, device=pts.device)
+    _abi.check(_abi.lib().invr_sample_volume(_abi.ptr(vol), dims, vol.shape[3], c0, nc, _abi.ptr(bounds.contiguous()),
+                                             _abi.ptr(pts), pts.shape[0], _abi.ptr(out), _abi.stream_ptr()))
+    return out
+
+
+def mlp_forward(mlp, x):
+    """part_base_network.MLP.forward (:18-24)."""
+    for l in mlp.linears[:-1]:
+        x = F.softplus(l(x))
+    return mlp.linears[-1](x)
+
+
+def dir_encode(d, n_freq):
+    """freq_embedder.PosEnc.forward (:20-31)."""
+    out = [d]
+    for k in range(n_freq):
+        out += [torch.sin(d * (2.0 ** k)), torch.cos(d * (2.0 ** k))]
+    return torch.cat(out, -1)
+
+
+def deform(net, batch, pts):
+    """Deformer.forward (uv_deformer.py:31-38) with gradients to the deformer's tables and MLP."""
+    dfm = net.tpose_deformer
+    uv = sample_volume(batch['tuv'][0], batch['tbounds'][0], pts, 0, 2)
+    t = batch['frame_dim'].reshape(1, 1).expand(uv.shape[0], 1).float()
+    uvt = torch.cat([uv, t], -1)
+    e = dfm.embedder
+    feat = GridEncodeFn.apply(uvt, e.dense if e.separate_dense else None, e.hash, e.bounds, e.spec)
+    return 0.05 * torch.tanh(dfm.mlp(feat))
+
+
+def part_field(pn, tpts, tdirs, latent_index, n_freq):
+    """part_base_network.Network.forward (:44-63) with gradients."""
+    e = pn.embedder
+    emb = GridEncodeFn.apply(tpts, e.dense if e.separate_dense else None, e.hash, e.bounds, e.spec)
+    h = mlp_forward(pn.occ, emb)
+    occ = 1 - torch.exp(-F.softplus(h[..., :1]))
+    lat = pn.rgb_latent[latent_index.reshape(-1)[0]][None].expand(tpts.shape[0], -1)
+    x = torch.cat([emb, dir_encode(tdirs, n_freq), h[..., 1:], lat], -1)
+    rgb = torch.sigmoid(mlp_forward(pn.rgb, x))
+    return torch.cat([rgb, occ], -1)
+
+
+def distortion(weights, z):
+    """inb_renderer.py:96-103."""
+    nz = torch.cat([z[:, 1:], z[:, -1:]], -1)
+    mid = (z + nz) / 2
+    return ((weights[:, :, None] * weights[:, None, :]) * (mid[:, :, None] - mid[:, None, :]).abs()).sum(-1).sum(-1)
+
+
+def render_train(net, batch, geo, views, stats, n_rays, S, pair_noise):
+    """Differentiable recomputation of one training forward on the pair lists `views` left by the HIP
+    geometry pass `geo` (= Network.render_rays output).  Returns the reference's train-mode dict."""
+    cfg = net.cfg
+    P = NUM_PARTS
+    dev = geo['rgb_map'].device
+    Na, cap = int(stats[0]), views['cap']
+    n_freq = cfg.viewdir_embedder.kwargs['res']
+    cnts = [int(stats[1 + p]) for p in range(P)]
+    xb, dirs, rows = [], [], []
+    for p in range(P):
+        c = cnts[p]
+        r = views['l_r'][p][:, :c].t()
+        xb.append((views['l_x'][p][:, :c].t() - r).contiguous())                       # init_bigpose (no grad)
+        dirs.append(views['l_d'][p][:, :c].t().contiguous())
+        slots = views['l_slot'][p][:c].long()
+        rows.append(torch.where(slots == cap, torch.full_like(slots, Na), slots))   # the far constant -> row Na
+    resd_all = deform(net, batch, torch.cat(xb, 0))
+    resd_p = torch.split(resd_all, cnts, 0)
+    far = views['farflags'][:Na].to(torch.int32)
+    raws_flat = torch.zeros((Na + 1) * P, 4, device=dev)
+    resd_flat = torch.zeros((Na + 1) * P, 3, device=dev)
+    tpts_flat = torch.zeros((Na + 1) * P, 3, device=dev)
+    for p in range(P):
+        if cnts[p] == 0:
+            continue
+        pn = net.tpose_human.part_networks[p]
+        tpose = xb[p] + resd_p[p]                                                        # :111
+        raw = part_field(pn, tpose, dirs[p], batch['latent_index'], n_freq)
+        flat = rows[p] * P + p
+        raws_flat = raws_flat.index_copy(0, flat, raw)
+        resd_flat = resd_flat.index_copy(0, flat, resd_p[p])
+        tpts_flat = tpts_flat.index_copy(0, flat, xb[p])
+        fr = ((far >> p) & 1).nonzero(as_tuple=True)[0]
+        if fr.numel():                                   # far pairs share the part constant (last list entry)
+            ff = fr * P + p
+            raws_flat = raws_flat.index_copy(0, ff, raw[-1:].expand(fr.numel(), 4))
+            resd_flat = resd_flat.index_copy(0, ff, resd_p[p][-1:].expand(fr.numel(), 3))
+            tpts_flat = tpts_flat.index_copy(0, ff, xb[p][-1:].expand(fr.numel(), 3))
+    raws = raws_flat.view(Na + 1, P, 4)[:Na]
+    resd = resd_flat.view(Na + 1, P, 3)[:Na]
+    tpts = tpts_flat.view(Na + 1, P, 3)[:Na]
+    tocc = raws[..., 3]
+    ind = tocc.argmax(dim=1)                                                             # :253
+    merged = raws[torch.arange(Na, device=dev), ind]
+    act = views['active_idx'][:Na].long()
+    raw_full = torch.zeros(n_rays * S, 4, device=dev).index_copy(0, act, merged)        # :156-159
+    weights, rgb_map, acc_map = CompositeFn.apply(raw_full.view(n_rays, S, 4))
+    ret = {'rgb_map': rgb_map[None], 'acc_map': acc_map[None], 'raw': raw_full[None], 'occ': raw_full[None, :, 3:],
+           'resd': resd.reshape(1, -1, 3), 'tpts': tpts.reshape(1, -1, 3).detach(), 'tocc': tocc.reshape(1, -1, 1)}
+    if cfg.use_pair_reg:                                                                 # inb_renderer.py:78-94
+        reg = ((tocc.detach().reshape(-1) - 0.5).abs() < 0.02).nonzero(as_tuple=True)[0]
+        if reg.numel():
+            reg_tpts = ret['tpts'].reshape(-1, 3)[reg]
+            reg_resd = resd.reshape(-1, 3)[reg]
+            neighbor = reg_tpts + (pair_noise(reg_tpts[None])[0] - 0.5) * 0.01
+            nei = deform(net, batch, neighbor)
+            ret['oresd'] = torch.cat([reg_resd[None], nei[None]], dim=1)
+        else:
+            ret['oresd'] = torch.zeros(1, 0, 3, device=dev)
+    if cfg.use_reg_distortion:
+        ret['reg_distortion_loss'] = distortion(weights, geo['z_vals'])[None]
+    return ret

@@ -198,6 +198,10 @@ __device__ __forceinline__ void level_corners(float x, float cell, int res, int&
 
 // ---- kernel launchers (defined in the .hip files) ---------------------------------------------
 int launch_grid_encode_generic(const GridDev& g, const float* xyz, int64_t n, float* out, hipStream_t st);
+int launch_grid_encode_bwd_generic(const GridDev& g, const float* xyz, const float* gout, int64_t n, float* g_dense,
+                                   float* g_hash, float* g_xyz, hipStream_t st);
+int launch_composite_bwd(const float* raw, const float* g_rgb, const float* g_acc, const float* g_w, int64_t n_rays, int S,
+                         float* g_raw, hipStream_t st);
 int launch_sample_volume(const VolDev& v, int c0, int nc, const float* pts, int64_t n, float* out, hipStream_t st);
 int launch_knn_blend_dense(const SceneDev& s, const float* pose_pts, int64_t n, float* bw, float* dist, hipStream_t st);
 int launch_warp_deform_dense(const SceneDev& s, const GridDev& dg, const MlpDev& dm, const float* pose_pts,

@@ -303,6 +303,14 @@ extern "C" int invr_grid_encode_fwd(const InvrGrid* grid, const float* xyz, int6
     return launch_grid_encode_generic(make_grid_dev(grid), xyz, n, out, (hipStream_t)stream);
 }
 
+extern "C" int invr_grid_encode_bwd(const InvrGrid* grid, const float* xyz, const float* g_out, int64_t n,
+                                    float* g_dense, float* g_hash, float* g_xyz, void* stream) {
+    INVR_CHECK(grid && (n == 0 || (xyz && g_out)) && g_hash, "invr_grid_encode_bwd: null pointer");
+    if (check_grid(grid, "grid")) return 1;
+    INVR_CHECK(!grid->separate_dense || g_dense, "invr_grid_encode_bwd: g_dense required for a separate dense table");
+    return launch_grid_encode_bwd_generic(make_grid_dev(grid), xyz, g_out, n, g_dense, g_hash, g_xyz, (hipStream_t)stream);
+}
+
 extern "C" int invr_sample_volume(const float* vol, const int32_t dims[3], int32_t channels, int32_t c0, int32_t nc,
                                   const float* bounds, const float* pts, int64_t n, float* out, void* stream) {
     INVR_CHECK(vol && dims && bounds && (n == 0 || (pts && out)), "invr_sample_volume: null pointer");
@@ -382,4 +390,11 @@ extern "C" int invr_composite_fwd(const float* raw, int64_t n_rays, int32_t n_sa
     INVR_CHECK(n_rays == 0 || (raw && rgb_map && acc_map), "invr_composite_fwd: null pointer");
     INVR_CHECK(n_samples >= 1, "invr_composite_fwd: n_samples must be >= 1");
     return launch_composite(raw, n_rays, n_samples, weights, rgb_map, acc_map, (hipStream_t)stream);
+}
+
+extern "C" int invr_composite_bwd(const float* raw, const float* g_rgb_map, const float* g_acc_map, const float* g_weights,
+                                  int64_t n_rays, int32_t n_samples, float* g_raw, void* stream) {
+    INVR_CHECK(n_rays == 0 || (raw && g_rgb_map && g_raw), "invr_composite_bwd: null pointer");
+    INVR_CHECK(n_samples >= 1, "invr_composite_bwd: n_samples must be >= 1");
+    return launch_composite_bwd(raw, g_rgb_map, g_acc_map, g_weights, n_rays, n_samples, g_raw, (hipStream_t)stream);
 }

@@ -56,6 +56,59 @@ int launch_grid_encode_generic(const GridDev& g, const float* xyz, int64_t n, fl
     return 0;
 }
 
+// ---- generic backward: table gradients (atomic adds) + input gradient ------------------------------
+__global__ void k_grid_encode_bwd_rt(GridDev g, const float* __restrict__ xyz, const float* __restrict__ gout, int64_t n,
+                                     int out_dim, float* g_dense, float* g_hash, float* __restrict__ g_xyz) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float x[3];
+    grid_normalise(g, xyz + i * 3, x);
+    const float* go = gout + i * out_dim;
+    const int off = g.include_input ? 3 : 0;
+    float gx[3] = {0.f, 0.f, 0.f};                 // gradient w.r.t. the normalised coordinate
+    if (g.include_input) { gx[0] = go[0]; gx[1] = go[1]; gx[2] = go[2]; }
+    for (int l = 0; l < g.L; ++l) {
+        int64_t rows[8];
+        float wts[8];
+        const float* tab = grid_level_lookup(g, l, x, rows, wts);
+        float* gtab;                                // gradient table aligned with `tab`
+        if (g.separate_dense) gtab = (l >= g.start_hash) ? g_hash + (tab - g.hash) : g_dense + (tab - g.dense);
+        else gtab = g_hash + (tab - g.hash);
+        // per-axis fractional offsets again (for d weight / d t)
+        int c0, c1;
+        float t[3];
+        for (int a = 0; a < 3; ++a) level_corners(x[a], g.cell[l], g.res[l], c0, c1, t[a]);
+        float gt[3] = {0.f, 0.f, 0.f};
+        for (int k = 0; k < 8; ++k) {
+            const float wx = (k & 4) ? t[0] : 1.0f - t[0], wy = (k & 2) ? t[1] : 1.0f - t[1], wz = (k & 1) ? t[2] : 1.0f - t[2];
+            float dot = 0.0f;                       // sum_f g_f * v_kf
+            for (int f = 0; f < g.F; ++f) {
+                float gf;
+                if (!g.sum) gf = go[off + l * g.F + f];
+                else if (g.sum_over_features) gf = go[off + l];
+                else gf = go[off + f];
+                dot = fmaf(gf, tab[rows[k] * g.F + f], dot);
+                unsafeAtomicAdd(gtab + rows[k] * g.F + f, wts[k] * gf);
+            }
+            gt[0] += ((k & 4) ? 1.0f : -1.0f) * wy * wz * dot;
+            gt[1] += ((k & 2) ? 1.0f : -1.0f) * wx * wz * dot;
+            gt[2] += ((k & 1) ? 1.0f : -1.0f) * wx * wy * dot;
+        }
+        for (int a = 0; a < 3; ++a) gx[a] += gt[a] / g.cell[l];      // f = x / cell, t = f - const
+    }
+    if (g_xyz)
+        for (int a = 0; a < 3; ++a) g_xyz[i * 3 + a] = gx[a] / (g.bounds[3 + a] - g.bounds[a]);
+}
+
+int launch_grid_encode_bwd_generic(const GridDev& g, const float* xyz, const float* gout, int64_t n, float* g_dense,
+                                   float* g_hash, float* g_xyz, hipStream_t st) {
+    if (n == 0) return 0;
+    int od = (g.sum ? (g.sum_over_features ? g.L : g.F) : g.L * g.F) + (g.include_input ? 3 : 0);
+    hipLaunchKernelGGL(k_grid_encode_bwd_rt, dim3((unsigned)cdiv(n, 128)), dim3(128), 0, st, g, xyz, gout, n, od, g_dense, g_hash, g_xyz);
+    INVR_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---- wave-cooperative 16x16 part encoder ----------------------------------------------------------
 #define ENC_BLOCK 256
 #define ENC_WAVES (ENC_BLOCK / 64)

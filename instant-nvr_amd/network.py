@@ -92,6 +92,12 @@ class MLP(nn.Module):
                                      + [nn.Linear(d_hidden, outdim)])
         self.actvn = nn.Softplus()
 
+    def forward(self, x):
+        """torch path (training autograd only; inference runs in k_part_mlp)."""
+        for l in self.linears[:-1]:
+            x = self.actvn(l(x))
+        return self.linears[-1](x)
+
 
 ColorNetwork = MLP
 

@@ -78,6 +78,13 @@ class Renderer:
         v = _abi.ws_views(ws, n, S, max_active)
         cap, dev = v['cap'], ray_o.device
         P = NUM_PARTS
+        self.last_stats = out['stats']
+        self.last_train = {'weights': out['weights'], 'z_vals': out['z_vals']}
+        if torch.is_grad_enabled():
+            # differentiable recomputation on the pair lists (autograd.py): HIP encoder / compositing
+            # forward+backward kernels, torch for the tiny MLPs
+            from . import autograd as ag
+            return ag.render_train(net, batch, out, v, stats, n, S, self._pair_noise)
         resd = torch.zeros(Na + 1, P, 3, device=dev)
         tpts = torch.zeros(Na + 1, P, 3, device=dev)
         tocc = torch.zeros(Na + 1, P, device=dev)

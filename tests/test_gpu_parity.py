@@ -250,3 +250,65 @@ def test_train_mode_forward_vs_reference_golden(gpu_setup, golden):
     pair = float(stats['pair_loss'])
     mine = float(loss) - cfg.pair_loss_weight * pair
     assert abs(mine - float(golden['train_loss'])) < 1e-5
+
+
+def _golden_grads(golden):
+    out = {}
+    for k in golden:
+        if k.startswith('grad::'):
+            out[k[6:]] = ('full', golden[k])
+        elif k.startswith('grad_rows::'):
+            name = k[11:]
+            out[name] = ('rows', golden[k], golden['grad_vals::' + name], bool(golden['grad_full_equal::' + name]))
+    return out
+
+
+def test_train_step_gradients_vs_reference_golden(gpu_setup, golden):
+    """loss.backward() through the differentiable training forward: every parameter gradient of the
+    reference (autograd of the PyTorch path, 256 rays, fixed jitter) to fp32 tolerance."""
+    cfg, sd, batch, gb, net = gpu_setup
+    tsel = torch.from_numpy(golden['train_rays'].astype(np.int64)).to(DEV)
+    tb = dict(gb)
+    for k in ('ray_o', 'ray_d', 'near', 'far', 'rgb', 'occupancy'):
+        tb[k] = gb[k][:, tsel]
+    net.train()
+    try:
+        r = Renderer(net)
+        r._jitter = lambda shape, device: cu(golden['train_jitter'][0])
+        r._pair_noise = lambda like: cu(golden['train_pair_u'])
+        net.zero_grad(set_to_none=True)
+        ret = r.render(tb)
+        assert maxerr(ret['rgb_map'], golden['train_rgb_map']) < 1e-4
+        assert maxerr(ret['resd'], golden['train_resd']) < 5e-6
+        assert maxerr(ret['oresd'], golden['train_oresd']) < 5e-6
+        assert maxerr(ret['reg_distortion_loss'], golden['train_reg_distortion_loss']) < 1e-5
+        loss = ((ret['rgb_map'] - tb['rgb']) ** 2).mean() + 0.1 * ret['reg_distortion_loss'].mean() \
+            + 0.1 * torch.norm(ret['resd'], dim=2).mean()          # the loss make_golden.py differentiated
+        assert abs(float(loss.detach()) - float(golden['train_loss'])) < 1e-5
+        loss.backward()
+    finally:
+        net.eval()
+    ref = _golden_grads(golden)
+    params = dict(net.named_parameters())
+    checked = 0
+    for name, entry in ref.items():
+        g = params[name].grad
+        assert g is not None, name
+        g = g.detach().cpu().numpy()
+        if entry[0] == 'full':
+            scale = max(float(np.abs(entry[1]).max()), 1e-6)
+            assert np.abs(g - entry[1]).max() <= 2e-4 * scale + 2e-7, (name, float(np.abs(g - entry[1]).max()), scale)
+        else:
+            _, rows, vals, equal = entry
+            flat = g.reshape(-1, g.shape[-1])
+            scale = max(float(np.abs(vals).max()), 1e-6)
+            got = flat[rows][:, :1] if equal else flat[rows]
+            assert np.abs(got - vals).max() <= 2e-4 * scale + 2e-7, (name, float(np.abs(got - vals).max()), scale)
+            mask = np.ones(flat.shape[0], bool)
+            mask[rows] = False
+            assert not mask.any() or np.abs(flat[mask]).max() <= 1e-6 * scale + 1e-9, name   # untouched rows stay ~0
+        checked += 1
+    assert checked >= 60
+    for name, p in params.items():                           # nothing else got a gradient the reference lacks
+        if p.grad is not None and name not in ref:
+            assert float(p.grad.abs().max()) == 0.0, name
