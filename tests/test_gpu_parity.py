@@ -312,3 +312,32 @@ def test_train_step_gradients_vs_reference_golden(gpu_setup, golden):
     for name, p in params.items():                           # nothing else got a gradient the reference lacks
         if p.grad is not None and name not in ref:
             assert float(p.grad.abs().max()) == 0.0, name
+
+
+def test_network_wrapper_optimisation_steps(gpu_setup, golden):
+    """Trainer.train's inner step (trainer.py:108-149) on the drop-in wrapper: forward, loss.mean(),
+    zero_grad(set_to_none), backward, Adam step (one param group per tensor, eps 1e-15: optimizer.py:15-31);
+    the loss must go down on a fixed patch."""
+    import copy
+    from invr.trainer import NetworkWrapper
+    cfg, sd, batch, gb, net0 = gpu_setup
+    net = copy.deepcopy(net0).train()
+    tsel = torch.from_numpy(golden['train_rays'].astype(np.int64)).to(DEV)
+    tb = dict(gb)
+    for k in ('ray_o', 'ray_d', 'near', 'far', 'rgb', 'occupancy'):
+        tb[k] = gb[k][:, tsel]
+    wrap = NetworkWrapper(net)
+    wrap.renderer._jitter = lambda shape, device: cu(golden['train_jitter'][0])
+    groups = [{'params': [p], 'lr': 5e-3, 'weight_decay': 0} for p in net.parameters() if p.requires_grad]
+    opt = torch.optim.Adam(groups, lr=5e-3, eps=1e-15)
+    losses = []
+    for it in range(6):
+        tb['iter_step'] = it + 2                      # (iter_step == 1 would re-create the bounds, embedder :107-109)
+        ret, loss, stats, _ = wrap(tb, split='train')
+        loss = loss.mean()
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+        assert set(['reg_dist', 'offset_loss', 'img_loss', 'psnr', 'loss']) <= set(stats.keys())   # pair_loss only when pairs qualify
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
