@@ -34,23 +34,34 @@
 #define KNN_TWO_R2 ((float)(2.0 * 0.075 * 0.075))
 #define KNN_DFAR2 0.64f          // (0.8 m)^2
 
+// Sorted 4-best list on 64-bit keys (squared distance bits << 32 | vertex row): non-negative floats
+// order like their bit patterns, so one unsigned compare orders by (distance, row) and the result
+// does not depend on the order in which vertices are visited (exact distance ties do occur at
+// ~1e-7 per pair).  +inf / row 0 is both the empty marker and the cluster padding sentinel.
 struct Top4 {
+    unsigned long long k[KNN_K];
     float d[KNN_K];
     int i[KNN_K];
     __device__ __forceinline__ void init() {
 #pragma unroll
-        for (int k = 0; k < KNN_K; ++k) { d[k] = __builtin_inff(); i[k] = 0; }
+        for (int j = 0; j < KNN_K; ++j) k[j] = 0x7F80000000000000ull;
     }
-    // sorted insert: ONE (usually wave-skipped) branch, the shifting is predicated selects — the
-    // nested-branch form costs ~10 scalar-ALU instructions per vertex and the CU has a single SALU
+    // ONE (usually wave-skipped) branch, the shifting is predicated selects — a nested-branch insert
+    // costs ~10 scalar-ALU instructions per vertex and the CU has a single SALU
     __device__ __forceinline__ void push(float v, int idx) {
-        if (v < d[3]) {
-            const bool c2 = v < d[2], c1 = v < d[1], c0 = v < d[0];
-            d[3] = c2 ? d[2] : v;                 i[3] = c2 ? i[2] : idx;
-            d[2] = c1 ? d[1] : (c2 ? v : d[2]);   i[2] = c1 ? i[1] : (c2 ? idx : i[2]);
-            d[1] = c0 ? d[0] : (c1 ? v : d[1]);   i[1] = c0 ? i[0] : (c1 ? idx : i[1]);
-            d[0] = c0 ? v : d[0];                 i[0] = c0 ? idx : i[0];
+        const unsigned long long key = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)idx;
+        if (key < k[3]) {
+            const bool c2 = key < k[2], c1 = key < k[1], c0 = key < k[0];
+            k[3] = c2 ? k[2] : key;
+            k[2] = c1 ? k[1] : (c2 ? key : k[2]);
+            k[1] = c0 ? k[0] : (c1 ? key : k[1]);
+            k[0] = c0 ? key : k[0];
         }
+    }
+    __device__ __forceinline__ float worst() const { return __uint_as_float((unsigned)(k[3] >> 32)); }
+    __device__ __forceinline__ void finish() {
+#pragma unroll
+        for (int j = 0; j < KNN_K; ++j) { d[j] = __uint_as_float((unsigned)(k[j] >> 32)); i[j] = (int)(unsigned)k[j]; }
     }
 };
 
@@ -101,6 +112,7 @@ __global__ __launch_bounds__(KNN_BLOCK) void k_knn_dense(SceneDev s, const float
             }
         }
         if (!live) continue;
+        t.finish();
         float w[KNN_K];
         float ds = knn_weights(t, w);
         dist[i * INVR_NUM_PARTS + p] = ds;
@@ -201,7 +213,7 @@ __global__ __launch_bounds__(PREP_T) void k_part_prepare(SceneDev s, KnnIndex ix
             ix.sverts[voff + j] = make_float4(v[o * 3], v[o * 3 + 1], v[o * 3 + 2], __int_as_float(o));
         } else {
             // sentinel: infinitely far, never enters a top-4 -> clusters are always scanned as 64
-            ix.sverts[voff + j] = make_float4(1e18f, 1e18f, 1e18f, __int_as_float(0));
+            ix.sverts[voff + j] = make_float4(1e30f, 1e30f, 1e30f, __int_as_float(0));   // squared distance overflows to +inf
         }
     }
     const int ncl = (len + 63) >> 6;
@@ -355,10 +367,11 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w, 
             scan_cluster(sv + seed_c * 64, min(64, len - seed_c * 64), px, py, pz, t);
             for (int c = 0; c < ncl && !(dbg & 2); ++c) {
                 if (c == seed_c) continue;
-                const bool need = scan && aabb_dist2(px, py, pz, cl[c * 3], cl[c * 3 + 1]) < t.d[3];
+                const bool need = scan && aabb_dist2(px, py, pz, cl[c * 3], cl[c * 3 + 1]) <= t.worst();
                 if (__ballot(need) == 0) continue;
                 scan_cluster(sv + c * 64, min(64, len - c * 64), px, py, pz, t);
             }
+            t.finish();
             float wt[KNN_K];
             const float ds = knn_weights(t, wt);
             if (scan && ds < a.scene.thresh) {                        // pflag (inb_part_network_multiassign.py:90)
