@@ -92,10 +92,17 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)' % (args.gpus, world)
     assert torch.cuda.is_available(), 'bench.py needs a GPU'
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    # debugging aids for a 1-GPU box: INVR_FORCE_DEVICE pins every rank to one GPU and
+    # INVR_DIST_BACKEND=gloo replaces RCCL (which refuses two ranks on one device)
+    dev_index = int(os.environ.get('INVR_FORCE_DEVICE', local_rank))
+    backend = os.environ.get('INVR_DIST_BACKEND', 'nccl')
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
     if world > 1:
-        dist.init_process_group('nccl', device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     kw = dict(N_samples=args.samples)
     if args.table_log2:

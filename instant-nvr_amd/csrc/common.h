@@ -46,6 +46,9 @@ struct GridDev {
     int32_t L, F, start_hash, separate_dense;
     int64_t T;
     double inv_T;
+    // T = 2^mod_k + mod_c with a small mod_c (nextprime(2^k)): 32-bit reduction is valid (host-checked)
+    int32_t mod_k, mod32;
+    uint32_t mod_c;
     int32_t res[INVR_MAX_LEVELS];
     float cell[INVR_MAX_LEVELS];
     int64_t dense_off[INVR_MAX_LEVELS];
@@ -174,6 +177,24 @@ __device__ __forceinline__ uint32_t hash_mod64(uint64_t x, int64_t T, double inv
     if (r >= (double)T) r -= (double)T;
     return (uint32_t)r;
 }
+// x mod T for T = 2^k + c (c small, x < 2^41) with 32-bit integer ops only: 2^k == -c (mod T), so
+// x = h*2^k + a == a - c*h; three folding rounds bring the value into (-2T, 2T).  The bounds that make
+// three rounds sufficient are verified on the host (make_grid_dev); otherwise the fp64 path is used.
+__device__ __forceinline__ uint32_t hash_mod32(uint64_t x, int k, uint32_t c, uint32_t T) {
+    const uint32_t mask = (1u << k) - 1u, lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    const uint32_t a0 = lo & mask, h0 = (hi << (32 - k)) | (lo >> k);
+    const uint32_t y1 = c * h0, a1 = y1 & mask, h1 = y1 >> k;
+    const uint32_t y2 = c * h1, a2 = y2 & mask, h2 = y2 >> k;
+    const uint32_t y3 = c * h2;
+    int32_t v = (int32_t)(a0 + a2) - (int32_t)(a1 + y3);
+    v += (v < 0) ? (int32_t)T : 0;
+    v += (v < 0) ? (int32_t)T : 0;
+    v -= (v >= (int32_t)T) ? (int32_t)T : 0;
+    return (uint32_t)v;
+}
+struct GridDev;
+__device__ __forceinline__ uint32_t grid_hash_mod(uint64_t x, const GridDev& g);
+
 __device__ __forceinline__ uint32_t hash_mod(uint32_t cx, uint32_t cy, uint32_t cz, int64_t T, double inv_T) {
     uint64_t x = (uint64_t)cx ^ ((uint64_t)cy * HASH_P1) ^ ((uint64_t)cz * HASH_P2);
     double xd = (double)x;
@@ -194,6 +215,10 @@ __device__ __forceinline__ void level_corners(float x, float cell, int res, int&
     c0 = min(max(a, 0), res - 1);
     c1 = min(max(b, 0), res - 1);
     t = f - (float)c0;
+}
+
+__device__ __forceinline__ uint32_t grid_hash_mod(uint64_t x, const GridDev& g) {
+    return g.mod32 ? hash_mod32(x, g.mod_k, g.mod_c, (uint32_t)g.T) : hash_mod64(x, g.T, g.inv_T);
 }
 
 // ---- kernel launchers (defined in the .hip files) ---------------------------------------------

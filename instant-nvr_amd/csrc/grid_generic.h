@@ -21,7 +21,7 @@ __device__ __forceinline__ const float* grid_level_lookup(const GridDev& g, int 
         // weight_k = prod_axis ((1-o) + (2o-1) t)  (:157-158)
         const float wx = (k & 4) ? t[0] : 1.0f - t[0], wy = (k & 2) ? t[1] : 1.0f - t[1], wz = (k & 1) ? t[2] : 1.0f - t[2];
         wts[k] = wx * wy * wz;
-        if (hashed) rows[k] = hash_mod((uint32_t)cx, (uint32_t)cy, (uint32_t)cz, g.T, g.inv_T);
+        if (hashed) rows[k] = grid_hash_mod((uint64_t)(uint32_t)cx ^ ((uint64_t)(uint32_t)cy * HASH_P1) ^ ((uint64_t)(uint32_t)cz * HASH_P2), g);
         else rows[k] = (int64_t)cx * res * res + (int64_t)cy * res + cz;
     }
     if (g.separate_dense) {

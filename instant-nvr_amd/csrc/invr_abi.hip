@@ -36,6 +36,19 @@ GridDev make_grid_dev(const InvrGrid* g) {
     d.dense = g->dense; d.hash = g->hash; d.bounds = g->bounds;
     d.L = g->n_levels; d.F = g->n_features; d.start_hash = g->start_hash; d.separate_dense = g->separate_dense;
     d.T = g->table_len; d.inv_T = 1.0 / (double)g->table_len;
+    {   // 32-bit modulo eligibility: T = 2^k + c, x < 2^41 (res <= 8192, prime factor < 2^27)
+        int k = 0;
+        while ((1ll << (k + 1)) <= d.T) ++k;
+        const uint64_t c = (uint64_t)(d.T - (1ll << k));
+        d.mod_k = k; d.mod_c = (uint32_t)c; d.mod32 = 0;
+        if (k >= 10 && k <= 30 && c > 0) {
+            const uint64_t y1 = c * ((1ull << 41) >> k);                  // bound of round 1
+            const uint64_t y2 = c * (y1 >> k), y3 = c * (y2 >> k);
+            if (y1 < (1ull << 32) && y2 < (1ull << 32) && y3 < (uint64_t)d.T && (y3 >> k) == 0 &&
+                (uint64_t)d.T < (1ull << 30))
+                d.mod32 = 1;
+        }
+    }
     for (int l = 0; l < INVR_MAX_LEVELS; ++l) { d.res[l] = g->res[l]; d.cell[l] = g->cell[l]; d.dense_off[l] = g->dense_off[l]; }
     d.sum = g->sum; d.sum_over_features = g->sum_over_features; d.include_input = g->include_input;
     return d;

@@ -157,8 +157,8 @@ __device__ __forceinline__ void fetch_point(const GridDev& g, const LaneLevel& L
     unsigned r0, r1;
     if (L.hashed) {
         const uint64_t hxy = (uint64_t)(uint32_t)cx ^ ((uint64_t)(uint32_t)cy * HASH_P1);
-        r0 = hash_mod64(hxy ^ ((uint64_t)(uint32_t)c0z * HASH_P2), g.T, g.inv_T);
-        r1 = hash_mod64(hxy ^ ((uint64_t)(uint32_t)c1z * HASH_P2), g.T, g.inv_T);
+        r0 = grid_hash_mod(hxy ^ ((uint64_t)(uint32_t)c0z * HASH_P2), g);
+        r1 = grid_hash_mod(hxy ^ ((uint64_t)(uint32_t)c1z * HASH_P2), g);
     } else {
         const unsigned rb = ((unsigned)cx * (unsigned)L.res + (unsigned)cy) * (unsigned)L.res;
         r0 = rb + (unsigned)c0z;

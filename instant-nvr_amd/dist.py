@@ -24,22 +24,44 @@ def shard_counts(n_rays, world, tile=DEFAULT_TILE):
     return [int(tile_indices(n_rays, r, world, tile).numel()) for r in range(world)]
 
 
+_plan_cache = {}
+
+
+def gather_plan(n_rays, world, tile, device):
+    """(max shard size, src_index): ray i of the full frame sits at row src_index[i] of the gathered
+    (world*mx, 4) buffer.  Cached: the plan only depends on the frame size and the world size."""
+    key = (n_rays, world, tile, str(device))
+    if key not in _plan_cache:
+        counts = shard_counts(n_rays, world, tile)
+        mx = max(counts)
+        src = torch.empty(n_rays, dtype=torch.int64)
+        for r in range(world):
+            idx = tile_indices(n_rays, r, world, tile)
+            src[idx] = r * mx + torch.arange(idx.numel())
+        _plan_cache[key] = (mx, src.to(device))
+    return _plan_cache[key]
+
+
 def gather_maps(local_rgba, n_rays, rank, world, tile=DEFAULT_TILE, group=None):
-    """All-gather the per-rank [r,g,b,acc] rows (n_local,4) into the full (n_rays,4) map."""
+    """All-gather the per-rank [r,g,b,acc] rows (n_local,4) into the full (n_rays,4) map:
+    one padded all_gather_into_tensor + one index_select."""
     if world == 1:
         return local_rgba
     dev = local_rgba.device
-    counts = shard_counts(n_rays, world, tile)
-    mx = max(counts)
-    send = torch.zeros(mx, 4, device=dev, dtype=local_rgba.dtype)
-    send[:local_rgba.shape[0]] = local_rgba
+    mx, src = gather_plan(n_rays, world, tile, dev)
+    if local_rgba.shape[0] == mx:
+        send = local_rgba.contiguous()
+    else:
+        send = torch.zeros(mx, 4, device=dev, dtype=local_rgba.dtype)
+        send[:local_rgba.shape[0]] = local_rgba
     recv = torch.empty(world * mx, 4, device=dev, dtype=local_rgba.dtype)
-    dist.all_gather_into_tensor(recv, send, group=group)
-    full = torch.empty(n_rays, 4, device=dev, dtype=local_rgba.dtype)
-    recv = recv.view(world, mx, 4)
-    for r in range(world):
-        full[tile_indices(n_rays, r, world, tile, device=dev)] = recv[r, :counts[r]]
-    return full
+    if dist.get_backend(group) == 'gloo' and send.is_cuda:      # gloo (tests) gathers through host memory
+        host = torch.empty(world * mx, 4, dtype=local_rgba.dtype)
+        dist.all_gather_into_tensor(host, send.cpu(), group=group)
+        recv.copy_(host)
+    else:
+        dist.all_gather_into_tensor(recv, send, group=group)
+    return recv.index_select(0, src)
 
 
 def render_frame(render_fn, batch, rank, world, tile=DEFAULT_TILE, group=None):
