@@ -136,6 +136,14 @@ int invr_render_fwd(const InvrScene* scene, const InvrModel* model,
                     float* z_vals, int32_t* stats,
                     void* workspace, size_t workspace_bytes, int64_t max_active, void* stream);
 
+/* Network.forward (inb_part_network_multiassign.py:126-168) on arbitrary world points: wpts, viewdir
+ * (n,3) -> raw (n,4) = [sigmoid rgb, occ] and occ (n) (NULL to skip), zeros where the point is culled or
+ * no part is flagged.  Same pipeline as invr_render_fwd with one sample per "ray". */
+size_t invr_field_workspace_bytes(int64_t n_points, int64_t max_active);
+int invr_field_fwd(const InvrScene* scene, const InvrModel* model, const float* wpts, const float* viewdir,
+                   int64_t n_points, float* raw, float* occ, int32_t* stats,
+                   void* workspace, size_t workspace_bytes, int64_t max_active, void* stream);
+
 /* Byte offsets of the arrays invr_render_fwd leaves in the workspace (for callers that need the
  * intermediate pair lists: the train-time outputs resd / tpts / tocc of
  * inb_part_network_multiassign.py:162-165 and the backward pass).  Lists are SoA with stride `lcap`

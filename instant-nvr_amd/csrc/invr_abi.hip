@@ -239,17 +239,17 @@ static PartMlpDev make_part_mlp(const InvrModel* m, int p, const int64_t* latent
     return pm;
 }
 
-extern "C" int invr_render_fwd(const InvrScene* scene, const InvrModel* model,
-                               const float* ray_o, const float* ray_d, const float* near, const float* far,
-                               const float* jitter, int64_t n_rays, int32_t n_samples,
-                               float* rgb_map, float* acc_map, float* raw, float* occ, float* weights,
-                               float* z_vals, int32_t* stats,
-                               void* workspace, size_t workspace_bytes, int64_t max_active, void* stream) {
+static int render_impl(const InvrScene* scene, const InvrModel* model,
+                       const float* ray_o, const float* ray_d, const float* near, const float* far,
+                       const float* jitter, const float* wpts, const float* wdirs, int64_t n_rays, int32_t n_samples,
+                       float* rgb_map, float* acc_map, float* raw, float* occ, float* weights,
+                       float* z_vals, int32_t* stats,
+                       void* workspace, size_t workspace_bytes, int64_t max_active, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     INVR_CHECK(scene && model, "invr_render_fwd: null scene/model");
-    INVR_CHECK(n_rays >= 0 && n_samples >= 2, "invr_render_fwd: need n_rays >= 0 and n_samples >= 2");
+    INVR_CHECK(n_rays >= 0 && (n_samples >= 2 || (wpts && n_samples == 1)), "invr_render_fwd: need n_rays >= 0 and n_samples >= 2");
     if (n_rays == 0) return 0;
-    INVR_CHECK(ray_o && ray_d && near && far && rgb_map && acc_map, "invr_render_fwd: null ray/output pointer");
+    INVR_CHECK(((ray_o && ray_d && near && far) || (wpts && wdirs)) && rgb_map && acc_map, "invr_render_fwd: null ray/output pointer");
     const int64_t N = n_rays * (int64_t)n_samples;
     INVR_CHECK(N < (1ll << 31), "invr_render_fwd: n_rays*n_samples must be < 2^31 (got %lld); split the ray list", (long long)N);
     if (max_active <= 0 || max_active > N) max_active = N;
@@ -267,6 +267,7 @@ extern "C" int invr_render_fwd(const InvrScene* scene, const InvrModel* model,
     RenderArgs a;
     a.scene = make_scene_dev(scene);
     a.ray_o = ray_o; a.ray_d = ray_d; a.near = near; a.far = far; a.jitter = jitter; a.z_vals = z_vals;
+    a.wpts = wpts; a.wdirs = wdirs;
     a.R = n_rays; a.S = n_samples; a.N = N;
 
     {
@@ -307,6 +308,32 @@ extern "C" int invr_render_fwd(const InvrScene* scene, const InvrModel* model,
         INVR_LAUNCH_CHECK();
     }
     return 0;
+}
+
+extern "C" int invr_render_fwd(const InvrScene* scene, const InvrModel* model,
+                               const float* ray_o, const float* ray_d, const float* near, const float* far,
+                               const float* jitter, int64_t n_rays, int32_t n_samples,
+                               float* rgb_map, float* acc_map, float* raw, float* occ, float* weights,
+                               float* z_vals, int32_t* stats,
+                               void* workspace, size_t workspace_bytes, int64_t max_active, void* stream) {
+    return render_impl(scene, model, ray_o, ray_d, near, far, jitter, nullptr, nullptr, n_rays, n_samples, rgb_map, acc_map,
+                       raw, occ, weights, z_vals, stats, workspace, workspace_bytes, max_active, stream);
+}
+
+extern "C" size_t invr_field_workspace_bytes(int64_t n_points, int64_t max_active) {
+    return invr_workspace_bytes(n_points, 1, max_active) + align_up((size_t)(n_points > 0 ? n_points : 1) * 4 * sizeof(float), 256);
+}
+
+extern "C" int invr_field_fwd(const InvrScene* scene, const InvrModel* model, const float* wpts, const float* viewdir,
+                              int64_t n_points, float* raw, float* occ, int32_t* stats,
+                              void* workspace, size_t workspace_bytes, int64_t max_active, void* stream) {
+    INVR_CHECK(n_points == 0 || (wpts && viewdir && raw), "invr_field_fwd: null pointer");
+    if (n_points == 0) return 0;
+    const size_t inner = invr_workspace_bytes(n_points, 1, max_active);
+    INVR_CHECK(workspace && workspace_bytes >= invr_field_workspace_bytes(n_points, max_active), "invr_field_fwd: workspace too small");
+    float* scratch = reinterpret_cast<float*>(static_cast<char*>(workspace) + inner);     // rgb_map (n,3) + acc_map (n)
+    return render_impl(scene, model, nullptr, nullptr, nullptr, nullptr, nullptr, wpts, viewdir, n_points, 1,
+                       scratch, scratch + 3 * n_points, raw, occ, nullptr, nullptr, stats, workspace, inner, max_active, stream);
 }
 
 // ---- stage-level entry points -------------------------------------------------------------------

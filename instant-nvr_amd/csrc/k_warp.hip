@@ -163,7 +163,8 @@ __global__ __launch_bounds__(WARP_BLOCK) void k_warp_pairs(RenderArgs a, Workspa
         warp_point(A, big_A, b, pp, pd, xb, db);
         if (!a.scene.tpose_viewdir) {                       // cfg.tpose_viewdir False: world view dir
             int64_t ray = w.active_idx[slot] / a.S;
-            db[0] = a.ray_d[ray * 3]; db[1] = a.ray_d[ray * 3 + 1]; db[2] = a.ray_d[ray * 3 + 2];
+            const float* vd = a.wpts ? a.wdirs : a.ray_d;
+            db[0] = vd[ray * 3]; db[1] = vd[ray * 3 + 1]; db[2] = vd[ray * 3 + 2];
         }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {

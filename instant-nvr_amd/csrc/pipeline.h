@@ -13,6 +13,8 @@ struct RenderArgs {
     const float* near;
     const float* far;
     const float* jitter;     // (R,S) or null
+    const float* wpts;       // points mode (Network.forward): (N,3) world points, S == 1; else null
+    const float* wdirs;      // points mode: (N,3) world view directions
     float* z_vals;           // (R,S) or null
     int64_t R;               // rays
     int32_t S;               // samples per ray
@@ -69,14 +71,21 @@ __device__ __forceinline__ float sample_z(float near, float far, int s, int S, c
 
 __device__ __forceinline__ void sample_pose_point(const RenderArgs& a, int64_t i, float& px, float& py,
                                                   float& pz, float* zout, float* pdir) {
-    int64_t ray = i / a.S;
-    int s = (int)(i - ray * a.S);
-    float near = a.near[ray], far = a.far[ray];
-    float z = sample_z(near, far, s, a.S, a.jitter ? a.jitter + ray * a.S : nullptr);
-    if (zout) *zout = z;
-    float ox = a.ray_o[ray * 3 + 0], oy = a.ray_o[ray * 3 + 1], oz = a.ray_o[ray * 3 + 2];
-    float dx = a.ray_d[ray * 3 + 0], dy = a.ray_d[ray * 3 + 1], dz = a.ray_d[ray * 3 + 2];
-    float wx = ox + dx * z, wy = oy + dy * z, wz = oz + dz * z;          // pts = o + d*z
+    float wx, wy, wz, dx, dy, dz;
+    if (a.wpts) {                                                        // Network.forward(wpts, viewdir, ...)
+        wx = a.wpts[i * 3]; wy = a.wpts[i * 3 + 1]; wz = a.wpts[i * 3 + 2];
+        dx = a.wdirs[i * 3]; dy = a.wdirs[i * 3 + 1]; dz = a.wdirs[i * 3 + 2];
+        if (zout) *zout = 0.0f;
+    } else {
+        int64_t ray = i / a.S;
+        int s = (int)(i - ray * a.S);
+        float near = a.near[ray], far = a.far[ray];
+        float z = sample_z(near, far, s, a.S, a.jitter ? a.jitter + ray * a.S : nullptr);
+        if (zout) *zout = z;
+        float ox = a.ray_o[ray * 3 + 0], oy = a.ray_o[ray * 3 + 1], oz = a.ray_o[ray * 3 + 2];
+        dx = a.ray_d[ray * 3 + 0]; dy = a.ray_d[ray * 3 + 1]; dz = a.ray_d[ray * 3 + 2];
+        wx = ox + dx * z; wy = oy + dy * z; wz = oz + dz * z;            // pts = o + d*z
+    }
     const float* R = a.scene.R;
     const float* Th = a.scene.Th;
     float qx = wx - Th[0], qy = wy - Th[1], qz = wz - Th[2];             // (p - Th) @ R

@@ -172,6 +172,25 @@ class Network(nn.Module):
         keep = []
         return RenderContext(self.model_struct(keep), _abi.make_scene(batch, self.cfg, keep), keep)
 
+    def forward(self, wpts, viewdir, dists, batch):
+        """Network.forward (inb_part_network_multiassign.py:126-168), eval outputs: world points
+        (N,3), view directions (N,3) -> {'raw': (1,N,4), 'occ': (1,N,1)}.  `dists` is unused, as in the
+        reference.  Training gradients flow through Renderer.render (autograd.py), not through here."""
+        L = _abi.lib()
+        ctx = batch if isinstance(batch, RenderContext) else self.prepare(batch)
+        x = wpts.detach().to(torch.float32).contiguous()
+        d = viewdir.detach().to(torch.float32).contiguous()
+        n = x.shape[0]
+        raw = torch.empty(n, 4, device=x.device)
+        occ = torch.empty(n, device=x.device)
+        stats = torch.zeros(_abi.STATS_LEN, dtype=torch.int32, device=x.device)
+        nbytes = L.invr_field_workspace_bytes(n, 0)
+        ws = self.workspace(nbytes, x.device)
+        _abi.check(L.invr_field_fwd(C.byref(ctx.scene), C.byref(ctx.model), _abi.ptr(x), _abi.ptr(d), n, _abi.ptr(raw),
+                                    _abi.ptr(occ), _abi.ptr(stats, torch.int32), C.c_void_p(ws.data_ptr()), nbytes, 0,
+                                    _abi.stream_ptr()))
+        return {'raw': raw[None], 'occ': occ[None, :, None]}
+
     def resd(self, tpts, batch):
         """Network.resd (inb_part_network_multiassign.py:122-124): deformer residual of canonical
         points (B,N,3) -> (B,N,3), through invr_deform_fwd."""

@@ -341,3 +341,22 @@ def test_network_wrapper_optimisation_steps(gpu_setup, golden):
         losses.append(float(loss.detach()))
         assert set(['reg_dist', 'offset_loss', 'img_loss', 'psnr', 'loss']) <= set(stats.keys())   # pair_loss only when pairs qualify
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
+def test_network_forward_on_points(gpu_setup, golden):
+    """Network.forward(wpts, viewdir, dists, batch) on arbitrary world points == the per-sample raw/occ of
+    the rendered frame (and therefore the reference's, see the render test)."""
+    cfg, sd, batch, gb, net = gpu_setup
+    S = cfg.N_samples
+    pts, z = O.sample_points(batch['ray_o'], batch['ray_d'], batch['near'], batch['far'], S)
+    wpts = pts.reshape(-1, 3)
+    vd = batch['ray_d'][:, :, None].expand(-1, -1, S, -1).reshape(-1, 3)
+    ret = net(cu(wpts), cu(vd.contiguous()), None, gb)
+    assert ret['raw'].shape == (1, wpts.shape[0], 4) and ret['occ'].shape == (1, wpts.shape[0], 1)
+    raw = ret['raw'][0].cpu().numpy()
+    nz = golden['render_raw_nz_idx']
+    assert np.abs(raw[nz] - golden['render_raw_nz']).max() < 1e-4
+    mask = np.ones(raw.shape[0], bool)
+    mask[nz] = False
+    assert np.abs(raw[mask]).max() == 0.0
+    assert maxerr(ret['occ'][0, :, 0], raw[:, 3]) == 0.0
