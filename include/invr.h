@@ -136,6 +136,15 @@ int invr_render_fwd(const InvrScene* scene, const InvrModel* model,
                     float* z_vals, int32_t* stats,
                     void* workspace, size_t workspace_bytes, int64_t max_active, void* stream);
 
+/* The gradient-free front half of invr_render_fwd only (sampling, cull, KNN skinning, LBS warp,
+ * deformer): fills the pair lists / flags / counters in the workspace (invr_workspace_layout) and
+ * z_vals (n_rays,n_samples) (optional).  Used by the training forward, which recomputes the
+ * differentiable part on those lists. */
+int invr_geometry_fwd(const InvrScene* scene, const InvrModel* model,
+                      const float* ray_o, const float* ray_d, const float* near, const float* far,
+                      const float* jitter, int64_t n_rays, int32_t n_samples, float* z_vals, int32_t* stats,
+                      void* workspace, size_t workspace_bytes, int64_t max_active, void* stream);
+
 /* Network.forward (inb_part_network_multiassign.py:126-168) on arbitrary world points: wpts, viewdir
  * (n,3) -> raw (n,4) = [sigmoid rgb, occ] and occ (n) (NULL to skip), zeros where the point is culled or
  * no part is flagged.  Same pipeline as invr_render_fwd with one sample per "ray". */

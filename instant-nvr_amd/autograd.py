@@ -137,7 +137,7 @@ def render_train(net, batch, geo, views, stats, n_rays, S, pair_noise):
     geometry pass `geo` (= Network.render_rays output).  Returns the reference's train-mode dict."""
     cfg = net.cfg
     P = NUM_PARTS
-    dev = geo['rgb_map'].device
+    dev = geo['z_vals'].device
     Na, cap = int(stats[0]), views['cap']
     n_freq = cfg.viewdir_embedder.kwargs['res']
     cnts = [int(stats[1 + p]) for p in range(P)]

@@ -244,12 +244,13 @@ static int render_impl(const InvrScene* scene, const InvrModel* model,
                        const float* jitter, const float* wpts, const float* wdirs, int64_t n_rays, int32_t n_samples,
                        float* rgb_map, float* acc_map, float* raw, float* occ, float* weights,
                        float* z_vals, int32_t* stats,
-                       void* workspace, size_t workspace_bytes, int64_t max_active, void* stream) {
+                       void* workspace, size_t workspace_bytes, int64_t max_active, void* stream,
+                       bool geometry_only = false) {
     hipStream_t st = (hipStream_t)stream;
     INVR_CHECK(scene && model, "invr_render_fwd: null scene/model");
     INVR_CHECK(n_rays >= 0 && (n_samples >= 2 || (wpts && n_samples == 1)), "invr_render_fwd: need n_rays >= 0 and n_samples >= 2");
     if (n_rays == 0) return 0;
-    INVR_CHECK(((ray_o && ray_d && near && far) || (wpts && wdirs)) && rgb_map && acc_map, "invr_render_fwd: null ray/output pointer");
+    INVR_CHECK(((ray_o && ray_d && near && far) || (wpts && wdirs)) && (geometry_only || (rgb_map && acc_map)), "invr_render_fwd: null ray/output pointer");
     const int64_t N = n_rays * (int64_t)n_samples;
     INVR_CHECK(N < (1ll << 31), "invr_render_fwd: n_rays*n_samples must be < 2^31 (got %lld); split the ray list", (long long)N);
     if (max_active <= 0 || max_active > N) max_active = N;
@@ -285,7 +286,7 @@ static int render_impl(const InvrScene* scene, const InvrModel* model,
         MlpDev dm = make_mlp_dev(&model->deform_mlp);
         if (launch_warp_pairs(a, w, dg, dm, st)) return 1;
     }
-    for (int p = 0; p < INVR_NUM_PARTS; ++p) {
+    for (int p = 0; p < INVR_NUM_PARTS && !geometry_only; ++p) {
         float* emb = w.emb[p & 1];
         {
             ProfStage ps(INVR_STAGE_ENCODE + p, st);
@@ -298,7 +299,7 @@ static int render_impl(const InvrScene* scene, const InvrModel* model,
             if (launch_part_mlp(pm, emb, w.l_d[p], w.lcap, w.l_slot[p], w.counters + CNT_PAIRS + p, w.lcap, w.raws, p, nullptr, st)) return 1;
         }
     }
-    {
+    if (!geometry_only) {
         ProfStage ps(INVR_STAGE_COMPOSITE, st);
         if (launch_merge_composite(a, w, rgb_map, acc_map, raw, occ, weights, st)) return 1;
     }
@@ -318,6 +319,14 @@ extern "C" int invr_render_fwd(const InvrScene* scene, const InvrModel* model,
                                void* workspace, size_t workspace_bytes, int64_t max_active, void* stream) {
     return render_impl(scene, model, ray_o, ray_d, near, far, jitter, nullptr, nullptr, n_rays, n_samples, rgb_map, acc_map,
                        raw, occ, weights, z_vals, stats, workspace, workspace_bytes, max_active, stream);
+}
+
+extern "C" int invr_geometry_fwd(const InvrScene* scene, const InvrModel* model,
+                                 const float* ray_o, const float* ray_d, const float* near, const float* far,
+                                 const float* jitter, int64_t n_rays, int32_t n_samples, float* z_vals, int32_t* stats,
+                                 void* workspace, size_t workspace_bytes, int64_t max_active, void* stream) {
+    return render_impl(scene, model, ray_o, ray_d, near, far, jitter, nullptr, nullptr, n_rays, n_samples, nullptr, nullptr,
+                       nullptr, nullptr, nullptr, z_vals, stats, workspace, workspace_bytes, max_active, stream, true);
 }
 
 extern "C" size_t invr_field_workspace_bytes(int64_t n_points, int64_t max_active) {

@@ -202,6 +202,27 @@ class Network(nn.Module):
                                               _abi.ptr(out), _abi.stream_ptr()))
         return out.view(B, N, D)
 
+    def geometry_pass(self, batch, ray_o, ray_d, near, far, n_samples, jitter=None, max_active=0):
+        """invr_geometry_fwd: the no-grad front half (pair lists in the workspace) for the training forward."""
+        L = _abi.lib()
+        dev = ray_o.device
+        ctx = batch if isinstance(batch, RenderContext) else self.prepare(batch)
+        f = lambda t: t.detach().to(torch.float32).contiguous()
+        ray_o, ray_d, near, far = f(ray_o), f(ray_d), f(near), f(far)
+        n, S = ray_o.shape[0], int(n_samples)
+        out = {'z_vals': torch.empty(n, S, device=dev), 'stats': torch.zeros(_abi.STATS_LEN, dtype=torch.int32, device=dev)}
+        if jitter is not None:
+            jitter = f(jitter)
+        nbytes = L.invr_workspace_bytes(n, S, max_active)
+        ws = self.workspace(nbytes, dev)
+        _abi.check(L.invr_geometry_fwd(C.byref(ctx.scene), C.byref(ctx.model), _abi.ptr(ray_o), _abi.ptr(ray_d), _abi.ptr(near),
+                                       _abi.ptr(far), _abi.ptr(jitter), n, S, _abi.ptr(out['z_vals']),
+                                       _abi.ptr(out['stats'], torch.int32), C.c_void_p(ws.data_ptr()), nbytes, max_active,
+                                       _abi.stream_ptr()))
+        out['_keep'] = ctx.keep
+        out['_ws'] = (ws, n, S, max_active)
+        return out
+
     def render_rays(self, batch, ray_o, ray_d, near, far, n_samples, jitter=None, want_raw=True,
                     want_weights=False, max_active=0):
         """One invr_render_fwd call over a ray list (n,3)/(n,).  `batch` is the collated batch dict

@@ -70,7 +70,10 @@ class Renderer:
         ray_o, ray_d, near, far = batch['ray_o'][0], batch['ray_d'][0], batch['near'][0], batch['far'][0]
         n = ray_o.shape[0]
         ctx = net.prepare(batch)
-        out = net.render_rays(ctx, ray_o, ray_d, near, far, S, jitter=jitter, want_raw=True, want_weights=True)
+        if torch.is_grad_enabled():       # geometry only: the differentiable part is recomputed on the pair lists
+            out = net.geometry_pass(ctx, ray_o, ray_d, near, far, S, jitter=jitter)
+        else:
+            out = net.render_rays(ctx, ray_o, ray_d, near, far, S, jitter=jitter, want_raw=True, want_weights=True)
         stats = out['stats'].cpu()                          # host sync, as the reference's nonzero()s
         assert int(stats[6]) == 0, 'invr workspace overflow'
         Na = int(stats[0])
@@ -79,7 +82,6 @@ class Renderer:
         cap, dev = v['cap'], ray_o.device
         P = NUM_PARTS
         self.last_stats = out['stats']
-        self.last_train = {'weights': out['weights'], 'z_vals': out['z_vals']}
         if torch.is_grad_enabled():
             # differentiable recomputation on the pair lists (autograd.py): HIP encoder / compositing
             # forward+backward kernels, torch for the tiny MLPs
