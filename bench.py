@@ -83,7 +83,7 @@ def main():
     ap.add_argument('--dense', action='store_true', help='stress variant: smpl_thresh=+inf (every sample active)')
     ap.add_argument('--no-raw', action='store_true', help='do not materialise raw/occ (N x 20 B)')
     ap.add_argument('--cam-dist', type=float, default=1.8, help='camera distance (m); 1.8 -> 97.6%% of the 512x512 pixels hit the body AABB')
-    ap.add_argument('--cpu-rays', type=int, default=192, help='rays in the bounded CPU-baseline sample')
+    ap.add_argument('--cpu-rays', type=int, default=128, help='rays in the bounded CPU-baseline sample')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 

@@ -263,6 +263,8 @@ static int render_impl(const InvrScene* scene, const InvrModel* model,
                model->deform_grid.include_input, "deformer grid must be 8 levels x 2 features, sum=False, include_input");
     for (int p = 0; p < INVR_NUM_PARTS; ++p) if (check_grid(&model->part[p].grid, "part grid")) return 1;
     INVR_CHECK(scene->pbw_channels >= 1 && scene->part_stride >= 1, "invr_render_fwd: bad scene dims");
+    INVR_CHECK(scene->tpose_viewdir, "invr_render_fwd: tpose_viewdir=False is not supported (the reference cannot run it either: "
+               "TPoseHuman.forward indexes the (Na,3) view directions per part)");
     INVR_CHECK(scene->part_stride <= KNN_MAX_PART, "invr_render_fwd: part_stride %d > %d vertices per part", scene->part_stride, KNN_MAX_PART);
 
     RenderArgs a;

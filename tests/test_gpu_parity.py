@@ -360,3 +360,55 @@ def test_network_forward_on_points(gpu_setup, golden):
     mask[nz] = False
     assert np.abs(raw[mask]).max() == 0.0
     assert maxerr(ret['occ'][0, :, 0], raw[:, 3]) == 0.0
+
+
+@pytest.mark.parametrize('over', [dict(smpl_thresh=0.1, N_samples=24),            # inb_lan.yaml threshold
+                                  dict(smpl_thresh=1e9, N_samples=8),              # dense stress: every sample active
+                                  dict(smpl_thresh=0.02, N_samples=40)])
+def test_render_config_variants_vs_oracle(small_setup, over):
+    """Hot-path flags other than the inb_377 defaults, against the (reference-pinned) oracle."""
+    from invr.config import make_cfg
+    _, _, batch, _ = small_setup
+    cfg = make_cfg(table_log2=12, **over)
+    sd = params.init_state_dict(cfg, seed=11)
+    net = Network(cfg=cfg)
+    net.load_state_dict(sd, strict=True)
+    net = net.to(DEV).eval()
+    sel = torch.arange(0, batch['ray_o'].shape[1], 7)
+    b = dict(batch)
+    for k in ('ray_o', 'ray_d', 'near', 'far'):
+        b[k] = batch[k][:, sel]
+    gb = {k: v.to(DEV) for k, v in b.items()}
+    r = Renderer(net)
+    ret = r.render(dict(gb))
+    with torch.no_grad():
+        ref = O.render(O.Model(sd, cfg), b)
+    stats = r.last_stats.cpu().numpy()
+    assert stats[6] == 0
+    nz_ref = (ref['raw'][0, :, 3] != 0).numpy()
+    nz = (ret['raw'][0, :, 3] != 0).numpy()
+    assert (nz == nz_ref).all()
+    # values: 1e-4, except pixels whose reference arithmetic is itself ill-conditioned (extrapolated far pairs);
+    # arbitrated by a float64 run of the oracle, as in test_gpu_fullsize.py
+    with torch.no_grad():
+        sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+        b64 = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in b.items()}
+        ref64 = O.render(O.Model(sd64, cfg), b64)
+    exact = ref64['rgb_map'][0]
+    err_gpu = (ret['rgb_map'][0].double() - exact).abs().max(1)[0]
+    err_ref = (ref['rgb_map'][0].double() - exact).abs().max(1)[0]
+    assert bool((err_gpu <= 1e-4 + 4 * err_ref).all()), (float(err_gpu.max()), float(err_ref.max()))
+    assert float(err_gpu.median()) < 5e-6
+
+
+def test_tpose_viewdir_false_is_rejected(gpu_setup):
+    """cfg.tpose_viewdir=False cannot run in the reference either (TPoseHuman.forward indexes the (Na,3)
+    view-dir tensor per part, inb_part_network_multiassign.py:216); the library reports it instead of
+    silently rendering something else."""
+    import copy
+    cfg, sd, batch, gb, net = gpu_setup
+    net2 = copy.deepcopy(net)
+    net2.cfg = copy.deepcopy(cfg)
+    net2.cfg.tpose_viewdir = False
+    with pytest.raises(RuntimeError, match='tpose_viewdir'):
+        net2.render_rays(gb, gb['ray_o'][0][:64], gb['ray_d'][0][:64], gb['near'][0][:64], gb['far'][0][:64], 16)
