@@ -57,55 +57,113 @@ int launch_grid_encode_generic(const GridDev& g, const float* xyz, int64_t n, fl
 }
 
 // ---- generic backward: table gradients (atomic adds) + input gradient ------------------------------
-__global__ void k_grid_encode_bwd_rt(GridDev g, const float* __restrict__ xyz, const float* __restrict__ gout, int64_t n,
-                                     int out_dim, float* g_dense, float* g_hash, float* __restrict__ g_xyz) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float x[3];
-    grid_normalise(g, xyz + i * 3, x);
-    const float* go = gout + i * out_dim;
+// Contention control (a 64x64 training patch sends ~1e5 pairs through 8-row coarse levels):
+//  * sum-over-features grids (the part grids): d out_l / d table[row][f] = w_k * g_l for EVERY f, so
+//    only ONE scalar per row is accumulated (into column 0 of the gradient row) and k_expand_rows
+//    copies it to the other F-1 columns afterwards: 16x fewer atomics;
+//  * levels whose whole table slice fits 16 KB of LDS are accumulated per workgroup in LDS
+//    (ds_add_f32) and flushed with one global atomic per touched entry.
+#define BWD_BLOCK 256
+#define BWD_LDS_FLOATS 4096
+
+__global__ __launch_bounds__(BWD_BLOCK) void k_grid_encode_bwd_rt(GridDev g, const float* __restrict__ xyz,
+                                                                  const float* __restrict__ gout, int64_t n, int out_dim,
+                                                                  float* g_dense, float* g_hash, float* __restrict__ g_xyz) {
+    __shared__ float sacc[BWD_LDS_FLOATS];
+    const int64_t i = (int64_t)blockIdx.x * BWD_BLOCK + threadIdx.x;
+    const bool live = i < n;
+    float x[3] = {0.f, 0.f, 0.f};
+    if (live) grid_normalise(g, xyz + i * 3, x);
+    const float* go = gout + (live ? i : 0) * out_dim;
     const int off = g.include_input ? 3 : 0;
-    float gx[3] = {0.f, 0.f, 0.f};                 // gradient w.r.t. the normalised coordinate
-    if (g.include_input) { gx[0] = go[0]; gx[1] = go[1]; gx[2] = go[2]; }
+    const bool rowscalar = g.sum && g.sum_over_features;
+    const int Fe = rowscalar ? 1 : g.F;                         // accumulated floats per row
+    float gx[3] = {0.f, 0.f, 0.f};
+    if (live && g.include_input) { gx[0] = go[0]; gx[1] = go[1]; gx[2] = go[2]; }
     for (int l = 0; l < g.L; ++l) {
+        const bool hashed = l >= g.start_hash;
+        const int64_t level_rows = hashed ? g.T : (int64_t)g.res[l] * g.res[l] * g.res[l];
+        const bool use_lds = level_rows * Fe <= BWD_LDS_FLOATS;             // workgroup-uniform
+        if (use_lds) {
+            for (int j = threadIdx.x; j < (int)(level_rows * Fe); j += BWD_BLOCK) sacc[j] = 0.0f;
+            __syncthreads();
+        }
         int64_t rows[8];
         float wts[8];
         const float* tab = grid_level_lookup(g, l, x, rows, wts);
-        float* gtab;                                // gradient table aligned with `tab`
-        if (g.separate_dense) gtab = (l >= g.start_hash) ? g_hash + (tab - g.hash) : g_dense + (tab - g.dense);
+        float* gtab;                                                        // gradient table aligned with `tab`
+        if (g.separate_dense) gtab = hashed ? g_hash + (tab - g.hash) : g_dense + (tab - g.dense);
         else gtab = g_hash + (tab - g.hash);
-        // per-axis fractional offsets again (for d weight / d t)
-        int c0, c1;
-        float t[3];
-        for (int a = 0; a < 3; ++a) level_corners(x[a], g.cell[l], g.res[l], c0, c1, t[a]);
-        float gt[3] = {0.f, 0.f, 0.f};
-        for (int k = 0; k < 8; ++k) {
-            const float wx = (k & 4) ? t[0] : 1.0f - t[0], wy = (k & 2) ? t[1] : 1.0f - t[1], wz = (k & 1) ? t[2] : 1.0f - t[2];
-            float dot = 0.0f;                       // sum_f g_f * v_kf
-            for (int f = 0; f < g.F; ++f) {
-                float gf;
-                if (!g.sum) gf = go[off + l * g.F + f];
-                else if (g.sum_over_features) gf = go[off + l];
-                else gf = go[off + f];
-                dot = fmaf(gf, tab[rows[k] * g.F + f], dot);
-                unsafeAtomicAdd(gtab + rows[k] * g.F + f, wts[k] * gf);
+        if (live) {
+            int c0, c1;
+            float t[3];
+            for (int a = 0; a < 3; ++a) level_corners(x[a], g.cell[l], g.res[l], c0, c1, t[a]);
+            float gt[3] = {0.f, 0.f, 0.f};
+            for (int k = 0; k < 8; ++k) {
+                const float wx = (k & 4) ? t[0] : 1.0f - t[0], wy = (k & 2) ? t[1] : 1.0f - t[1], wz = (k & 1) ? t[2] : 1.0f - t[2];
+                float dot = 0.0f;                                           // sum_f g_f * v_kf
+                for (int f = 0; f < g.F; ++f) {
+                    float gf;
+                    if (!g.sum) gf = go[off + l * g.F + f];
+                    else if (g.sum_over_features) gf = go[off + l];
+                    else gf = go[off + f];
+                    dot = fmaf(gf, tab[rows[k] * g.F + f], dot);
+                    if (!rowscalar) {
+                        if (use_lds) atomicAdd(&sacc[rows[k] * g.F + f], wts[k] * gf);
+                        else unsafeAtomicAdd(gtab + rows[k] * g.F + f, wts[k] * gf);
+                    }
+                }
+                if (rowscalar) {
+                    const float v = wts[k] * go[off + l];
+                    if (use_lds) atomicAdd(&sacc[rows[k]], v);
+                    else unsafeAtomicAdd(gtab + rows[k] * g.F, v);          // column 0 carries the row scalar
+                }
+                gt[0] += ((k & 4) ? 1.0f : -1.0f) * wy * wz * dot;
+                gt[1] += ((k & 2) ? 1.0f : -1.0f) * wx * wz * dot;
+                gt[2] += ((k & 1) ? 1.0f : -1.0f) * wx * wy * dot;
             }
-            gt[0] += ((k & 4) ? 1.0f : -1.0f) * wy * wz * dot;
-            gt[1] += ((k & 2) ? 1.0f : -1.0f) * wx * wz * dot;
-            gt[2] += ((k & 1) ? 1.0f : -1.0f) * wx * wy * dot;
+            for (int a = 0; a < 3; ++a) gx[a] += gt[a] / g.cell[l];         // f = x / cell, t = f - const
         }
-        for (int a = 0; a < 3; ++a) gx[a] += gt[a] / g.cell[l];      // f = x / cell, t = f - const
+        if (use_lds) {
+            __syncthreads();
+            for (int j = threadIdx.x; j < (int)(level_rows * Fe); j += BWD_BLOCK) {
+                const float v = sacc[j];
+                if (v != 0.0f) unsafeAtomicAdd(gtab + (rowscalar ? (int64_t)j * g.F : (int64_t)j), v);
+            }
+            __syncthreads();
+        }
     }
-    if (g_xyz)
+    if (live && g_xyz)
         for (int a = 0; a < 3; ++a) g_xyz[i * 3 + a] = gx[a] / (g.bounds[3 + a] - g.bounds[a]);
+}
+
+// copy the row scalar in column 0 to the other columns (sum-over-features grids)
+__global__ void k_expand_rows(float* __restrict__ gtab, int64_t rows, int F) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float v = gtab[r * F];
+    if (v != 0.0f)
+        for (int f = 1; f < F; ++f) gtab[r * F + f] = v;
 }
 
 int launch_grid_encode_bwd_generic(const GridDev& g, const float* xyz, const float* gout, int64_t n, float* g_dense,
                                    float* g_hash, float* g_xyz, hipStream_t st) {
     if (n == 0) return 0;
     int od = (g.sum ? (g.sum_over_features ? g.L : g.F) : g.L * g.F) + (g.include_input ? 3 : 0);
-    hipLaunchKernelGGL(k_grid_encode_bwd_rt, dim3((unsigned)cdiv(n, 128)), dim3(128), 0, st, g, xyz, gout, n, od, g_dense, g_hash, g_xyz);
+    hipLaunchKernelGGL(k_grid_encode_bwd_rt, dim3((unsigned)cdiv(n, BWD_BLOCK)), dim3(BWD_BLOCK), 0, st, g, xyz, gout, n, od,
+                       g_dense, g_hash, g_xyz);
     INVR_LAUNCH_CHECK();
+    if (g.sum && g.sum_over_features && g.F > 1) {
+        int64_t hrows = (int64_t)(g.separate_dense ? g.L - g.start_hash : g.L) * g.T;
+        hipLaunchKernelGGL(k_expand_rows, dim3((unsigned)cdiv(hrows, 256)), dim3(256), 0, st, g_hash, hrows, g.F);
+        INVR_LAUNCH_CHECK();
+        if (g.separate_dense) {
+            int64_t drows = 0;
+            for (int l = 0; l < g.start_hash; ++l) drows += (int64_t)g.res[l] * g.res[l] * g.res[l];
+            hipLaunchKernelGGL(k_expand_rows, dim3((unsigned)cdiv(drows, 256)), dim3(256), 0, st, g_dense, drows, g.F);
+            INVR_LAUNCH_CHECK();
+        }
+    }
     return 0;
 }
 
