@@ -412,3 +412,15 @@ def test_tpose_viewdir_false_is_rejected(gpu_setup):
     net2.cfg.tpose_viewdir = False
     with pytest.raises(RuntimeError, match='tpose_viewdir'):
         net2.render_rays(gb, gb['ray_o'][0][:64], gb['ray_d'][0][:64], gb['near'][0][:64], gb['far'][0][:64], 16)
+
+
+def test_run_evaluate_psnr_within_0p1_db(gpu_setup, golden):
+    """The eval loop of run.py:61-90 on the drop-in classes: PSNR (Evaluator.psnr_metric, whole HxW image)
+    of our render vs the PSNR of the reference's render of the same frame: BASELINE asks for 0.1 dB."""
+    from invr import driver
+    cfg, sd, batch, gb, net = gpu_setup
+    res = driver.run_evaluate(net, [batch], device=DEV)
+    gt = driver.assemble_image(batch['rgb'][0].numpy(), batch)
+    ref = driver.assemble_image(golden['render_rgb_map'][0], batch)
+    ref_psnr = driver.psnr_metric(ref.reshape(-1, 3), gt.reshape(-1, 3))
+    assert abs(res['psnr'][0] - ref_psnr) < 1e-3, (res['psnr'][0], ref_psnr)
