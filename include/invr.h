@@ -239,6 +239,15 @@ int invr_distortion_fwd(const float* weights, const float* z_vals, int64_t n_ray
 int invr_composite_fwd(const float* raw, int64_t n_rays, int32_t n_samples, float* weights,
                        float* rgb_map, float* acc_map, void* stream);
 
+/* get_rays + get_near_far (lib/utils/if_nerf/if_nerf_data_utils.py:24-38, 92-107): pinhole rays of an
+ * H x W image and their near/far against the world AABB.  HOST inputs (read during the call): k_inv =
+ * inv(K) (3x3, row-major float64), R (3x3), T (3), cam_o = -R^T T (3), bounds (2,3 float32).  DEVICE
+ * outputs over all H*W pixels: ray_d (H*W,3), near, far (H*W), mask (H*W uint8 = mask_at_box; near/far are
+ * meaningful where it is 1).  ray_o is cam_o cast to float32 for every ray. */
+int invr_generate_rays(const double* k_inv, const double* R, const double* T, const double* cam_o,
+                       const float* bounds, int32_t H, int32_t W, float* ray_d, float* near, float* far,
+                       uint8_t* mask, void* stream);
+
 /* Backward of invr_composite_fwd: g_rgb_map (n_rays,3), g_acc_map (n_rays) or NULL, g_weights
  * (n_rays,n_samples) or NULL (e.g. from the distortion regulariser) -> g_raw (n_rays,n_samples,4). */
 int invr_composite_bwd(const float* raw, const float* g_rgb_map, const float* g_acc_map, const float* g_weights,

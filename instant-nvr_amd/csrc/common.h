@@ -234,4 +234,6 @@ int launch_warp_deform_dense(const SceneDev& s, const GridDev& dg, const MlpDev&
                              float* tpose, float* tdirs, float* resd, hipStream_t st);
 int launch_deform_points(const SceneDev& s, const GridDev& dg, const MlpDev& dm, const float* pts, int64_t n, float* out, hipStream_t st);
 int launch_distortion(const float* weights, const float* z, int64_t n_rays, int S, float* out, hipStream_t st);
+int launch_generate_rays(const double* kinv, const double* r, const double* t, const double* o, const float* bounds,
+                         int H, int W, float* ray_d, float* near, float* far, uint8_t* mask, hipStream_t st);
 int launch_composite(const float* raw, int64_t n_rays, int S, float* weights, float* rgb_map, float* acc_map, hipStream_t st);

@@ -449,3 +449,11 @@ extern "C" int invr_composite_bwd(const float* raw, const float* g_rgb_map, cons
     INVR_CHECK(n_samples >= 1, "invr_composite_bwd: n_samples must be >= 1");
     return launch_composite_bwd(raw, g_rgb_map, g_acc_map, g_weights, n_rays, n_samples, g_raw, (hipStream_t)stream);
 }
+
+extern "C" int invr_generate_rays(const double* k_inv, const double* R, const double* T, const double* cam_o,
+                                  const float* bounds, int32_t H, int32_t W, float* ray_d, float* near, float* far,
+                                  uint8_t* mask, void* stream) {
+    INVR_CHECK(k_inv && R && T && cam_o && bounds, "invr_generate_rays: null camera pointer");
+    INVR_CHECK(H >= 0 && W >= 0 && (H * (int64_t)W == 0 || (ray_d && near && far && mask)), "invr_generate_rays: bad size / null output");
+    return launch_generate_rays(k_inv, R, T, cam_o, bounds, H, W, ray_d, near, far, mask, (hipStream_t)stream);
+}

@@ -114,3 +114,20 @@ def test_edge_cases(full):
     # a too-small max_active is reported, not silently wrong
     o = net.render_rays(ctx, *rays(gb, torch.arange(20000, device=DEV)), 128, max_active=1000)
     assert int(o['stats'][6]) == 1
+
+
+def test_generate_rays_full_frame(full):
+    """512x512: device ray generation vs the NumPy restatement of the reference's get_rays_within_bounds
+    (itself asserted bit-equal to the reference in tests/golden/make_golden_rays.py)."""
+    from invr import rays
+    cfg, net, bc, gb = full
+    _, ex = scene.make_scene(512, 512, seed=0, cam_dist=1.8)
+    ro, rd, near, far, mask = rays.rays_within_bounds(512, 512, ex['K'], ex['Rc'], ex['Tc'], bc['wbounds'][0].numpy(), DEV)
+    assert np.array_equal(mask.cpu().numpy().reshape(-1), bc['mask_at_box'][0].numpy())      # byte result: exact
+    assert torch.equal(ro.cpu(), bc['ray_o'][0])
+    for a, b in ((rd, bc['ray_d'][0]), (near, bc['near'][0]), (far, bc['far'][0])):
+        a = a.cpu()
+        assert a.shape == b.shape
+        # float64 products may be fused differently by the host BLAS: allow a handful of 1-ulp float32 flips
+        bad = (a != b)
+        assert int(bad.sum()) <= 8 and float((a - b).abs().max()) <= 3e-7

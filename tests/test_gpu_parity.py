@@ -424,3 +424,18 @@ def test_run_evaluate_psnr_within_0p1_db(gpu_setup, golden):
     ref = driver.assemble_image(golden['render_rgb_map'][0], batch)
     ref_psnr = driver.psnr_metric(ref.reshape(-1, 3), gt.reshape(-1, 3))
     assert abs(res['psnr'][0] - ref_psnr) < 1e-3, (res['psnr'][0], ref_psnr)
+
+
+def test_generate_rays_vs_reference_golden():
+    """invr_generate_rays against the reference's get_rays_within_bounds (tests/golden/rays_small.npz):
+    integer/byte results (mask) exact; float32 rays/near/far bit-exact."""
+    import os
+    from invr import rays
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'rays_small.npz'))
+    for tag in ('a', 'b'):
+        H, W = (int(v) for v in g[tag + '_HW'])
+        ro, rd, near, far, mask = rays.rays_within_bounds(H, W, g[tag + '_K'], g[tag + '_R'], g[tag + '_T'], g[tag + '_bounds'], DEV)
+        assert np.array_equal(mask.cpu().numpy(), g[tag + '_mask'])
+        assert np.array_equal(ro.cpu().numpy(), g[tag + '_ray_o'])
+        assert np.array_equal(rd.cpu().numpy(), g[tag + '_ray_d'])
+        assert np.array_equal(near.cpu().numpy(), g[tag + '_near']) and np.array_equal(far.cpu().numpy(), g[tag + '_far'])
