@@ -56,6 +56,9 @@ int launch_grid_encode_generic(const GridDev& g, const float* xyz, int64_t n, fl
     return 0;
 }
 
+int launch_part_encode_bwd(const GridDev& g, const float* xyz, const float* gout, int64_t n, float* g_dense, float* g_hash,
+                           float* g_xyz, hipStream_t st);
+
 // ---- generic backward: table gradients (atomic adds) + input gradient ------------------------------
 // Contention control (a 64x64 training patch sends ~1e5 pairs through 8-row coarse levels):
 //  * sum-over-features grids (the part grids): d out_l / d table[row][f] = w_k * g_l for EVERY f, so
@@ -150,7 +153,9 @@ int launch_grid_encode_bwd_generic(const GridDev& g, const float* xyz, const flo
                                    float* g_hash, float* g_xyz, hipStream_t st) {
     if (n == 0) return 0;
     int od = (g.sum ? (g.sum_over_features ? g.L : g.F) : g.L * g.F) + (g.include_input ? 3 : 0);
-    hipLaunchKernelGGL(k_grid_encode_bwd_rt, dim3((unsigned)cdiv(n, BWD_BLOCK)), dim3(BWD_BLOCK), 0, st, g, xyz, gout, n, od,
+    const bool fast = g.L == 16 && g.F == 16 && g.sum && g.sum_over_features && g.include_input;
+    if (fast) { if (launch_part_encode_bwd(g, xyz, gout, n, g_dense, g_hash, g_xyz, st)) return 1; }
+    else hipLaunchKernelGGL(k_grid_encode_bwd_rt, dim3((unsigned)cdiv(n, BWD_BLOCK)), dim3(BWD_BLOCK), 0, st, g, xyz, gout, n, od,
                        g_dense, g_hash, g_xyz);
     INVR_LAUNCH_CHECK();
     if (g.sum && g.sum_over_features && g.F > 1) {
@@ -293,6 +298,134 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_part_encode(GridDev g, const floa
             for (int k = 0; k < EMB_K; ++k) emb[(int64_t)k * cap + base + lane] = semb[wv][k][lane];
         }
     }
+}
+
+// ---- wave-cooperative backward of the 16x16 sum-over-features grids ----------------------------------
+// Same lane mapping as k_part_encode (lane = level*4 + quarter-row).  For one point and level l:
+//   d out_l / d table[row_k][f] = w_k          (all 16 f)  -> ONE scalar per row, accumulated into column 0
+//                                                             of the gradient row (k_expand_rows copies it)
+//   d out_l / d t_a             = sum_k (+-)(w_b w_c) S_k,  S_k = sum_f table[row_k][f]   (needs the rows again)
+// Small dense levels (<= BWD_SMALL_ROWS rows) are accumulated per workgroup in LDS: a training patch
+// sends ~1e5 pairs through 8..1000-row coarse levels and would serialise on global atomics.
+#define BWD_SMALL_ROWS 1100
+#define BWD_SMALL_FLOATS 6144
+
+__global__ __launch_bounds__(ENC_BLOCK) void k_part_encode_bwd(GridDev g, const float* __restrict__ xyz,
+                                                               const float* __restrict__ gout, int64_t n,
+                                                               float* g_dense, float* g_hash, float* __restrict__ g_xyz) {
+    __shared__ float sgo[ENC_WAVES][64][20];          // g_out tile of the wave
+    __shared__ float sgx[ENC_WAVES][64][3];           // per point: gradient w.r.t. the normalised coordinate
+    __shared__ float ssmall[BWD_SMALL_FLOATS];        // per-workgroup accumulators of the small dense levels
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int level = lane >> 2, q = lane & 3;
+    LaneLevel L;
+    L.res = g.res[level];
+    L.cell = g.cell[level];
+    L.hashed = level >= g.start_hash;
+    const float* tb = g.separate_dense
+        ? (L.hashed ? g.hash + (int64_t)(level - g.start_hash) * g.T * 16 : g.dense + g.dense_off[level] * 16)
+        : g.hash + (int64_t)level * g.T * 16;
+    float* gtb = g.separate_dense ? (L.hashed ? g_hash + (tb - g.hash) : g_dense + (tb - g.dense)) : g_hash + (tb - g.hash);
+    L.tab = reinterpret_cast<const float4*>(tb) + q;
+    // LDS slot of my level (small dense levels only), laid out back to back
+    int small_off = -1, small_total = 0;
+    for (int l = 0; l < 16; ++l) {
+        const int64_t rows = (int64_t)g.res[l] * g.res[l] * g.res[l];
+        const bool small = l < (g.separate_dense ? g.start_hash : 0) && rows <= BWD_SMALL_ROWS && small_total + rows <= BWD_SMALL_FLOATS;
+        if (l == level && small) small_off = small_total;
+        if (small) small_total += (int)rows;
+    }
+    for (int j = threadIdx.x; j < small_total; j += ENC_BLOCK) ssmall[j] = 0.0f;
+    __syncthreads();
+    const float b0x = g.bounds[0], b0y = g.bounds[1], b0z = g.bounds[2];
+    const float ex = g.bounds[3] - b0x, ey = g.bounds[4] - b0y, ez = g.bounds[5] - b0z;
+
+    for (int64_t tile = (int64_t)blockIdx.x * ENC_WAVES + wv; tile * 64 < n; tile += (int64_t)gridDim.x * ENC_WAVES) {
+        const int64_t base = tile * 64;
+        const int m = (int)min((int64_t)64, n - base);
+        const int64_t pi = base + min(lane, m - 1);
+        const float xi = (xyz[pi * 3] - b0x) / ex, yi = (xyz[pi * 3 + 1] - b0y) / ey, zi = (xyz[pi * 3 + 2] - b0z) / ez;
+        for (int e = lane; e < m * 19; e += 64) sgo[wv][e / 19][e % 19] = gout[base * 19 + e];      // coalesced tile copy
+        for (int j = 0; j < m; ++j) {
+            const float x = rdlane(xi, j), y = rdlane(yi, j), z = rdlane(zi, j);
+            int c0, c1;
+            float t;
+            const float xa = q == 0 ? x : (q == 1 ? y : z);
+            level_corners(xa, L.cell, L.res, c0, c1, t);
+            const int c0x = quad_bcast_i<0>(c0), c1x = quad_bcast_i<0>(c1);
+            const int c0y = quad_bcast_i<1>(c0), c1y = quad_bcast_i<1>(c1);
+            const int c0z = quad_bcast_i<2>(c0), c1z = quad_bcast_i<2>(c1);
+            const float tx = quad_bcast_f<0>(t), ty = quad_bcast_f<1>(t), tz = quad_bcast_f<2>(t);
+            const int cx = (q & 2) ? c1x : c0x, cy = (q & 1) ? c1y : c0y;
+            unsigned r0, r1;
+            if (L.hashed) {
+                const uint64_t hxy = (uint64_t)(uint32_t)cx ^ ((uint64_t)(uint32_t)cy * HASH_P1);
+                r0 = grid_hash_mod(hxy ^ ((uint64_t)(uint32_t)c0z * HASH_P2), g);
+                r1 = grid_hash_mod(hxy ^ ((uint64_t)(uint32_t)c1z * HASH_P2), g);
+            } else {
+                const unsigned rb = ((unsigned)cx * (unsigned)L.res + (unsigned)cy) * (unsigned)L.res;
+                r0 = rb + (unsigned)c0z;
+                r1 = rb + (unsigned)c1z;
+            }
+            unsigned row[8];
+            row[0] = (unsigned)quad_bcast_i<0>((int)r0); row[1] = (unsigned)quad_bcast_i<0>((int)r1);
+            row[2] = (unsigned)quad_bcast_i<1>((int)r0); row[3] = (unsigned)quad_bcast_i<1>((int)r1);
+            row[4] = (unsigned)quad_bcast_i<2>((int)r0); row[5] = (unsigned)quad_bcast_i<2>((int)r1);
+            row[6] = (unsigned)quad_bcast_i<3>((int)r0); row[7] = (unsigned)quad_bcast_i<3>((int)r1);
+            const float ux = 1.0f - tx, uy = 1.0f - ty, uz = 1.0f - tz;
+            const float gl = sgo[wv][j][3 + level];
+            float4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = L.tab[(size_t)row[k] * 4];
+            float gtx = 0.f, gty = 0.f, gtz = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float wx = (k & 4) ? tx : ux, wy = (k & 2) ? ty : uy, wz = (k & 1) ? tz : uz;
+                const float S = quad_sum((v[k].x + v[k].y) + (v[k].z + v[k].w));
+                gtx += ((k & 4) ? 1.0f : -1.0f) * wy * wz * S;
+                gty += ((k & 2) ? 1.0f : -1.0f) * wx * wz * S;
+                gtz += ((k & 1) ? 1.0f : -1.0f) * wx * wy * S;
+                if (q == 0) {
+                    const float val = (wx * wy * wz) * gl;
+                    if (small_off >= 0) atomicAdd(&ssmall[small_off + row[k]], val);
+                    else unsafeAtomicAdd(gtb + (size_t)row[k] * 16, val);               // column 0 = row scalar
+                }
+            }
+            // d out / d x_norm of this level, then summed over the 16 levels (lanes 4 apart)
+            float ax = gtx * gl / L.cell, ay = gty * gl / L.cell, az = gtz * gl / L.cell;
+#pragma unroll
+            for (int d = 4; d < 64; d <<= 1) { ax += __shfl_xor(ax, d); ay += __shfl_xor(ay, d); az += __shfl_xor(az, d); }
+            if (lane == 0) { sgx[wv][j][0] = ax; sgx[wv][j][1] = ay; sgx[wv][j][2] = az; }
+        }
+        if (g_xyz && lane < m) {
+            g_xyz[(base + lane) * 3 + 0] = (sgx[wv][lane][0] + sgo[wv][lane][0]) / ex;
+            g_xyz[(base + lane) * 3 + 1] = (sgx[wv][lane][1] + sgo[wv][lane][1]) / ey;
+            g_xyz[(base + lane) * 3 + 2] = (sgx[wv][lane][2] + sgo[wv][lane][2]) / ez;
+        }
+    }
+    __syncthreads();
+    // flush the small-level accumulators (dense levels are contiguous in g_dense from dense_off[l])
+    int off = 0;
+    for (int l = 0; l < 16; ++l) {
+        const int64_t rows = (int64_t)g.res[l] * g.res[l] * g.res[l];
+        const bool small = l < (g.separate_dense ? g.start_hash : 0) && rows <= BWD_SMALL_ROWS && off + rows <= BWD_SMALL_FLOATS;
+        if (!small) continue;
+        float* gl_tab = g_dense + g.dense_off[l] * 16;
+        for (int j = threadIdx.x; j < (int)rows; j += ENC_BLOCK) {
+            const float vv = ssmall[off + j];
+            if (vv != 0.0f) unsafeAtomicAdd(gl_tab + (size_t)j * 16, vv);
+        }
+        off += (int)rows;
+    }
+}
+
+int launch_part_encode_bwd(const GridDev& g, const float* xyz, const float* gout, int64_t n, float* g_dense, float* g_hash,
+                           float* g_xyz, hipStream_t st) {
+    int64_t tiles = cdiv(n, 64 * ENC_WAVES);
+    unsigned grid = (unsigned)(tiles < 1024 ? (tiles > 0 ? tiles : 1) : 1024);
+    hipLaunchKernelGGL(k_part_encode_bwd, dim3(grid), dim3(ENC_BLOCK), 0, st, g, xyz, gout, n, g_dense, g_hash, g_xyz);
+    INVR_LAUNCH_CHECK();
+    return 0;
 }
 
 int launch_part_encode(const GridDev& g, const float* x_soa, int64_t stride, const int32_t* count, int64_t cap,
