@@ -66,38 +66,40 @@ int launch_part_encode_bwd(const GridDev& g, const float* xyz, const float* gout
 //    copies it to the other F-1 columns afterwards: 16x fewer atomics;
 //  * levels whose whole table slice fits 16 KB of LDS are accumulated per workgroup in LDS
 //    (ds_add_f32) and flushed with one global atomic per touched entry.
-#define BWD_BLOCK 256
-#define BWD_LDS_FLOATS 4096
+#define BWD_BLOCK 1024
+#define BWD_LDS_FLOATS 33792           // 132 KB dynamic LDS: one level slice of up to 16.9k rows x 2 features
 
+// Persistent workgroups, LEVEL-outer / tile-inner: for each level the workgroup accumulates the
+// gradients of ALL its points in LDS (when the level slice fits) and flushes once, so a level that is
+// hammered by every point (the deformer's (u,v,t) input has a constant t: a 2-D slice of each level
+// receives everything) costs one global atomic per touched entry per workgroup.
 __global__ __launch_bounds__(BWD_BLOCK) void k_grid_encode_bwd_rt(GridDev g, const float* __restrict__ xyz,
                                                                   const float* __restrict__ gout, int64_t n, int out_dim,
                                                                   float* g_dense, float* g_hash, float* __restrict__ g_xyz) {
-    __shared__ float sacc[BWD_LDS_FLOATS];
-    const int64_t i = (int64_t)blockIdx.x * BWD_BLOCK + threadIdx.x;
-    const bool live = i < n;
-    float x[3] = {0.f, 0.f, 0.f};
-    if (live) grid_normalise(g, xyz + i * 3, x);
-    const float* go = gout + (live ? i : 0) * out_dim;
+    extern __shared__ __attribute__((aligned(16))) float sacc[];
     const int off = g.include_input ? 3 : 0;
     const bool rowscalar = g.sum && g.sum_over_features;
     const int Fe = rowscalar ? 1 : g.F;                         // accumulated floats per row
-    float gx[3] = {0.f, 0.f, 0.f};
-    if (live && g.include_input) { gx[0] = go[0]; gx[1] = go[1]; gx[2] = go[2]; }
     for (int l = 0; l < g.L; ++l) {
         const bool hashed = l >= g.start_hash;
         const int64_t level_rows = hashed ? g.T : (int64_t)g.res[l] * g.res[l] * g.res[l];
-        const bool use_lds = level_rows * Fe <= BWD_LDS_FLOATS;             // workgroup-uniform
+        const bool use_lds = level_rows * Fe <= BWD_LDS_FLOATS;             // uniform
         if (use_lds) {
             for (int j = threadIdx.x; j < (int)(level_rows * Fe); j += BWD_BLOCK) sacc[j] = 0.0f;
             __syncthreads();
         }
-        int64_t rows[8];
-        float wts[8];
-        const float* tab = grid_level_lookup(g, l, x, rows, wts);
-        float* gtab;                                                        // gradient table aligned with `tab`
-        if (g.separate_dense) gtab = hashed ? g_hash + (tab - g.hash) : g_dense + (tab - g.dense);
-        else gtab = g_hash + (tab - g.hash);
-        if (live) {
+        float* gtab_level = nullptr;
+        for (int64_t i = (int64_t)blockIdx.x * BWD_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BWD_BLOCK) {
+            float x[3];
+            grid_normalise(g, xyz + i * 3, x);
+            const float* go = gout + i * out_dim;
+            int64_t rows[8];
+            float wts[8];
+            const float* tab = grid_level_lookup(g, l, x, rows, wts);
+            float* gtab;                                                    // gradient table aligned with `tab`
+            if (g.separate_dense) gtab = hashed ? g_hash + (tab - g.hash) : g_dense + (tab - g.dense);
+            else gtab = g_hash + (tab - g.hash);
+            gtab_level = gtab;
             int c0, c1;
             float t[3];
             for (int a = 0; a < 3; ++a) level_corners(x[a], g.cell[l], g.res[l], c0, c1, t[a]);
@@ -125,19 +127,28 @@ __global__ __launch_bounds__(BWD_BLOCK) void k_grid_encode_bwd_rt(GridDev g, con
                 gt[1] += ((k & 2) ? 1.0f : -1.0f) * wx * wz * dot;
                 gt[2] += ((k & 1) ? 1.0f : -1.0f) * wx * wy * dot;
             }
-            for (int a = 0; a < 3; ++a) gx[a] += gt[a] / g.cell[l];         // f = x / cell, t = f - const
+            if (g_xyz)                                                       // same thread owns point i at every level
+                for (int a = 0; a < 3; ++a) {
+                    const float prev = l == 0 ? (g.include_input ? go[a] : 0.0f) : g_xyz[i * 3 + a];
+                    float v = prev + gt[a] / g.cell[l];                      // f = x / cell, t = f - const
+                    if (l == g.L - 1) v = v / (g.bounds[3 + a] - g.bounds[a]);
+                    g_xyz[i * 3 + a] = v;
+                }
         }
         if (use_lds) {
             __syncthreads();
+            // all points of a level share the table slice: recompute its base from the level (no point needed)
+            float* base;
+            if (g.separate_dense) base = hashed ? g_hash + (int64_t)(l - g.start_hash) * g.T * g.F : g_dense + g.dense_off[l] * g.F;
+            else base = g_hash + (int64_t)l * g.T * g.F;
+            (void)gtab_level;
             for (int j = threadIdx.x; j < (int)(level_rows * Fe); j += BWD_BLOCK) {
                 const float v = sacc[j];
-                if (v != 0.0f) unsafeAtomicAdd(gtab + (rowscalar ? (int64_t)j * g.F : (int64_t)j), v);
+                if (v != 0.0f) unsafeAtomicAdd(base + (rowscalar ? (int64_t)j * g.F : (int64_t)j), v);
             }
             __syncthreads();
         }
     }
-    if (live && g_xyz)
-        for (int a = 0; a < 3; ++a) g_xyz[i * 3 + a] = gx[a] / (g.bounds[3 + a] - g.bounds[a]);
 }
 
 // copy the row scalar in column 0 to the other columns (sum-over-features grids)
@@ -155,8 +166,20 @@ int launch_grid_encode_bwd_generic(const GridDev& g, const float* xyz, const flo
     int od = (g.sum ? (g.sum_over_features ? g.L : g.F) : g.L * g.F) + (g.include_input ? 3 : 0);
     const bool fast = g.L == 16 && g.F == 16 && g.sum && g.sum_over_features && g.include_input;
     if (fast) { if (launch_part_encode_bwd(g, xyz, gout, n, g_dense, g_hash, g_xyz, st)) return 1; }
-    else hipLaunchKernelGGL(k_grid_encode_bwd_rt, dim3((unsigned)cdiv(n, BWD_BLOCK)), dim3(BWD_BLOCK), 0, st, g, xyz, gout, n, od,
-                       g_dense, g_hash, g_xyz);
+    else {
+        static bool attr_set = false;
+        const size_t lds = (size_t)BWD_LDS_FLOATS * sizeof(float);
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void*)k_grid_encode_bwd_rt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+                invr_set_error("hipFuncSetAttribute(k_grid_encode_bwd_rt) failed");
+                return 1;
+            }
+            attr_set = true;
+        }
+        int64_t nb = cdiv(n, BWD_BLOCK);
+        hipLaunchKernelGGL(k_grid_encode_bwd_rt, dim3((unsigned)(nb < 256 ? nb : 256)), dim3(BWD_BLOCK), lds, st, g, xyz, gout, n, od,
+                           g_dense, g_hash, g_xyz);
+    }
     INVR_LAUNCH_CHECK();
     if (g.sum && g.sum_over_features && g.F > 1) {
         int64_t hrows = (int64_t)(g.separate_dense ? g.L - g.start_hash : g.L) * g.T;
