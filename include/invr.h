@@ -248,6 +248,19 @@ int invr_generate_rays(const double* k_inv, const double* R, const double* T, co
                        const float* bounds, int32_t H, int32_t W, float* ray_d, float* near, float* far,
                        uint8_t* mask, void* stream);
 
+/* batch_rodrigues + get_rigid_transformation (lib/utils/if_nerf/if_nerf_data_utils.py:523-577): DEVICE inputs
+ * poses (24,3) float64 axis-angle, joints (24,3) float64, parents (24) int32 -> DEVICE A (24,4,4) float32. */
+int invr_rigid_transformation(const double* poses, const double* joints, const int32_t* parents, float* A, void* stream);
+
+/* Per-part KNN reference sets of the dataset (lib/datasets/h36m/tpose_dataset.py:570-600), all DEVICE
+ * pointers: ppts (V,3) posed vertices, weights (V,n_weights), parts (V) int64 part id, tpose (V,3) canonical
+ * vertices -> part_pts (5,stride,3), part_pbw (5,stride,n_weights) (zero padded), lengths2 (5) int64,
+ * bounds (5,2,3) = min/max of tpose per part -/+ bbox_overlap.  stride >= V; the caller may then narrow the
+ * arrays to max(lengths2) as the reference does. */
+int invr_pack_parts(const float* ppts, const float* weights, const int64_t* parts, const float* tpose,
+                    int32_t n_verts, int32_t n_weights, int32_t stride, float bbox_overlap,
+                    float* part_pts, float* part_pbw, int64_t* lengths2, float* bounds, void* stream);
+
 /* Backward of invr_composite_fwd: g_rgb_map (n_rays,3), g_acc_map (n_rays) or NULL, g_weights
  * (n_rays,n_samples) or NULL (e.g. from the distortion regulariser) -> g_raw (n_rays,n_samples,4). */
 int invr_composite_bwd(const float* raw, const float* g_rgb_map, const float* g_acc_map, const float* g_weights,

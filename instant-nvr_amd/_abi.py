@@ -65,7 +65,8 @@ EXPORTS = ['invr_last_error', 'invr_version', 'invr_sizeof', 'invr_workspace_byt
            'invr_part_field_workspace', 'invr_part_field_fwd', 'invr_composite_fwd',
            'invr_profile_enable', 'invr_profile_read', 'invr_workspace_layout', 'invr_deform_fwd',
            'invr_distortion_fwd', 'invr_grid_encode_bwd', 'invr_composite_bwd',
-           'invr_field_workspace_bytes', 'invr_field_fwd', 'invr_geometry_fwd', 'invr_generate_rays']
+           'invr_field_workspace_bytes', 'invr_field_fwd', 'invr_geometry_fwd', 'invr_generate_rays',
+           'invr_rigid_transformation', 'invr_pack_parts']
 NUM_STAGES = 14
 STAGE_NAMES = ['cull', 'knn', 'warp'] + ['encode_%d' % p for p in range(5)] + ['mlp_%d' % p for p in range(5)] + ['composite']
 
@@ -113,6 +114,10 @@ def lib():
         dp = C.POINTER(C.c_double)
         L.invr_generate_rays.argtypes = [dp, dp, dp, dp, C.POINTER(C.c_float), C.c_int32, C.c_int32, vp, vp, vp, vp, vp]
         L.invr_generate_rays.restype = C.c_int
+        L.invr_rigid_transformation.argtypes = [vp, vp, vp, vp, vp]
+        L.invr_rigid_transformation.restype = C.c_int
+        L.invr_pack_parts.argtypes = [vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_float, vp, vp, vp, vp, vp]
+        L.invr_pack_parts.restype = C.c_int
         L.invr_field_workspace_bytes.restype = C.c_size_t
         L.invr_field_workspace_bytes.argtypes = [C.c_int64, C.c_int64]
         L.invr_field_fwd.argtypes = [C.POINTER(InvrScene), C.POINTER(InvrModel), vp, vp, C.c_int64, vp, vp, vp, vp, C.c_size_t, C.c_int64, vp]

@@ -236,4 +236,7 @@ int launch_deform_points(const SceneDev& s, const GridDev& dg, const MlpDev& dm,
 int launch_distortion(const float* weights, const float* z, int64_t n_rays, int S, float* out, hipStream_t st);
 int launch_generate_rays(const double* kinv, const double* r, const double* t, const double* o, const float* bounds,
                          int H, int W, float* ray_d, float* near, float* far, uint8_t* mask, hipStream_t st);
+int launch_rigid_transformation(const double* poses, const double* joints, const int32_t* parents, float* A, hipStream_t st);
+int launch_pack_parts(const float* ppts, const float* weights, const int64_t* parts, const float* tpose, int n_verts, int n_w,
+                      int stride, float overlap, float* part_pts, float* part_pbw, int64_t* lengths2, float* bounds, hipStream_t st);
 int launch_composite(const float* raw, int64_t n_rays, int S, float* weights, float* rgb_map, float* acc_map, hipStream_t st);

@@ -457,3 +457,17 @@ extern "C" int invr_generate_rays(const double* k_inv, const double* R, const do
     INVR_CHECK(H >= 0 && W >= 0 && (H * (int64_t)W == 0 || (ray_d && near && far && mask)), "invr_generate_rays: bad size / null output");
     return launch_generate_rays(k_inv, R, T, cam_o, bounds, H, W, ray_d, near, far, mask, (hipStream_t)stream);
 }
+
+extern "C" int invr_rigid_transformation(const double* poses, const double* joints, const int32_t* parents, float* A, void* stream) {
+    INVR_CHECK(poses && joints && parents && A, "invr_rigid_transformation: null pointer");
+    return launch_rigid_transformation(poses, joints, parents, A, (hipStream_t)stream);
+}
+
+extern "C" int invr_pack_parts(const float* ppts, const float* weights, const int64_t* parts, const float* tpose,
+                               int32_t n_verts, int32_t n_weights, int32_t stride, float bbox_overlap,
+                               float* part_pts, float* part_pbw, int64_t* lengths2, float* bounds, void* stream) {
+    INVR_CHECK(ppts && weights && parts && tpose && part_pts && part_pbw && lengths2 && bounds, "invr_pack_parts: null pointer");
+    INVR_CHECK(n_verts >= 0 && n_weights >= 1 && stride >= n_verts, "invr_pack_parts: stride must be >= n_verts");
+    return launch_pack_parts(ppts, weights, parts, tpose, n_verts, n_weights, stride, bbox_overlap, part_pts, part_pbw, lengths2,
+                             bounds, (hipStream_t)stream);
+}

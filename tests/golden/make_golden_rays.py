@@ -38,5 +38,27 @@ def main():
     print('wrote', path, os.path.getsize(path))
 
 
+def main_f4():
+    """Row f4: get_rigid_transformation (if_nerf_data_utils.py:545-577, batch_rodrigues :523-542) goldens."""
+    for name in ('cv2', 'trimesh'):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    if 'lib.config' not in sys.modules:
+        mg.import_reference(16)
+    from lib.utils.if_nerf import if_nerf_data_utils as du
+    from invr import scene
+    out = {}
+    rng = np.random.RandomState(4)
+    for tag in ('p', 'q', 'z'):
+        poses = rng.uniform(-1.2, 1.2, (24, 3)) * (0 if tag == 'z' else 1)
+        joints = (scene._J + rng.uniform(-0.02, 0.02, (24, 3))).astype(np.float64)
+        A = du.get_rigid_transformation(poses, joints, scene.PARENTS)
+        out.update({tag + '_poses': poses, tag + '_joints': joints, tag + '_A': A})
+    out['parents'] = scene.PARENTS.astype(np.int32)
+    path = os.path.join(HERE, 'rigid_small.npz')
+    np.savez_compressed(path, **out)
+    print('wrote', path, os.path.getsize(path))
+
+
 if __name__ == '__main__':
     main()
+    main_f4()

@@ -439,3 +439,21 @@ def test_generate_rays_vs_reference_golden():
         assert np.array_equal(ro.cpu().numpy(), g[tag + '_ray_o'])
         assert np.array_equal(rd.cpu().numpy(), g[tag + '_ray_d'])
         assert np.array_equal(near.cpu().numpy(), g[tag + '_near']) and np.array_equal(far.cpu().numpy(), g[tag + '_far'])
+
+
+def test_scene_prep_on_device(small_setup):
+    """Row f4: get_rigid_transformation vs the reference goldens (tests/golden/rigid_small.npz) and the
+    per-part packing vs the dataset logic restated in invr.scene (bit-exact: it only moves data)."""
+    import os
+    from invr import prep
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'rigid_small.npz'))
+    for tag in ('p', 'q', 'z'):
+        A = prep.rigid_transformation(cu(g[tag + '_poses']), cu(g[tag + '_joints']), cu(g['parents']))
+        ref = g[tag + '_A']
+        err = np.abs(A.cpu().numpy() - ref)
+        assert err.max() <= 2.4e-7 and (err > 0).sum() <= 4          # float32 cast of float64 results: bit-equal up to rare 1-ulp flips
+    cfg, sd, batch, extras = small_setup
+    pp, pb, l2, bd = prep.pack_parts(cu(batch['ppts'][0]), cu(extras['weights']), cu(extras['parts']), cu(extras['tpose']), 0.2)
+    assert torch.equal(l2.cpu(), batch['lengths2'][0])
+    assert torch.equal(pp.cpu(), batch['part_pts'][0]) and torch.equal(pb.cpu(), batch['part_pbw'][0])
+    assert torch.equal(bd.cpu(), batch['bounds'][0])
