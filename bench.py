@@ -84,6 +84,7 @@ def main():
     ap.add_argument('--no-raw', action='store_true', help='do not materialise raw/occ (N x 20 B)')
     ap.add_argument('--cam-dist', type=float, default=1.8, help='camera distance (m); 1.8 -> 97.6%% of the 512x512 pixels hit the body AABB')
     ap.add_argument('--cpu-rays', type=int, default=128, help='rays in the bounded CPU-baseline sample')
+    ap.add_argument('--full-rows', action='store_true', help='read the trainable 64-byte table rows instead of the eval-mode row-sum tables')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -110,6 +111,7 @@ def main():
     if args.dense:
         kw['smpl_thresh'] = 1e9
     cfg = make_cfg(**kw)
+    cfg['eval_row_sums'] = not args.full_rows
     net = build_model(cfg, dev)
     n_params = sum(p.numel() for p in net.parameters())
     batch_np, _ = scene_mod.make_scene(args.res, args.res, seed=0, cam_dist=args.cam_dist)
@@ -170,7 +172,7 @@ def main():
         pairs_local = int(stats[1:6].sum())
         enc_ms = sum(stage_ms['encode_%d' % p] for p in range(5)) / max(n_prof, 1)
         mlp_ms = sum(stage_ms['mlp_%d' % p] for p in range(5)) / max(n_prof, 1)
-        enc_bytes = pairs_local * PAIR_TABLE_BYTES                   # per step, this rank's 5 encode launches
+        enc_bytes = pairs_local * (PAIR_TABLE_BYTES if args.full_rows else PAIR_TABLE_BYTES // 16)                   # per step, this rank's 5 encode launches
         achieved = enc_bytes / (enc_ms * 1e-3) if enc_ms > 0 else 0.0
         traffic = None
         tf = os.path.join(ROOT, 'profiles', 'encode_traffic_bytes_per_step.json')

@@ -52,6 +52,11 @@ typedef struct InvrGrid {
     int32_t sum;                   /* :163                                                         */
     int32_t sum_over_features;     /* :164                                                         */
     int32_t include_input;         /* :172                                                         */
+    const float* row_sums;         /* dev, optional (NULL = off): inference-only derived table built by
+                                      invr_grid_row_sums — one float per table row = sum of its F features.
+                                      Only read by the render path for sum && sum_over_features grids,
+                                      where sum_f sum_k w_k row_k[f] == sum_k w_k (sum_f row_k[f]); the
+                                      caller must rebuild it whenever dense/hash change.              */
 } InvrGrid;
 
 /* Softplus MLP: lib/networks/bw_deform/part_base_network.py:11-24 / uv_deformer.py:15-21 */
@@ -247,6 +252,13 @@ int invr_composite_fwd(const float* raw, int64_t n_rays, int32_t n_samples, floa
 int invr_generate_rays(const double* k_inv, const double* R, const double* T, const double* cam_o,
                        const float* bounds, int32_t H, int32_t W, float* ray_d, float* near, float* far,
                        uint8_t* mask, void* stream);
+
+/* Inference-only row-sum tables for grids with sum && sum_over_features (part_base_embedder.py:163-165:
+ * the F features of a level are only ever used through their sum, which commutes with the trilinear
+ * interpolation).  invr_grid_row_sums_len = number of floats: dense rows first, then T per hashed level
+ * (L*T for a non-separate table).  invr_grid_row_sums fills `out` (DEVICE) from grid->dense/hash. */
+int64_t invr_grid_row_sums_len(const InvrGrid* grid);
+int invr_grid_row_sums(const InvrGrid* grid, float* out, void* stream);
 
 /* batch_rodrigues + get_rigid_transformation (lib/utils/if_nerf/if_nerf_data_utils.py:523-577): DEVICE inputs
  * poses (24,3) float64 axis-angle, joints (24,3) float64, parents (24) int32 -> DEVICE A (24,4,4) float32. */

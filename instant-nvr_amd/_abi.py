@@ -25,7 +25,8 @@ class InvrGrid(C.Structure):
                 ('separate_dense', C.c_int32), ('table_len', C.c_int64),
                 ('res', C.c_int32 * MAX_LEVELS), ('cell', C.c_float * MAX_LEVELS),
                 ('dense_off', C.c_int64 * MAX_LEVELS),
-                ('sum', C.c_int32), ('sum_over_features', C.c_int32), ('include_input', C.c_int32)]
+                ('sum', C.c_int32), ('sum_over_features', C.c_int32), ('include_input', C.c_int32),
+                ('row_sums', C.c_void_p)]
 
 
 class InvrMlp(C.Structure):
@@ -66,7 +67,7 @@ EXPORTS = ['invr_last_error', 'invr_version', 'invr_sizeof', 'invr_workspace_byt
            'invr_profile_enable', 'invr_profile_read', 'invr_workspace_layout', 'invr_deform_fwd',
            'invr_distortion_fwd', 'invr_grid_encode_bwd', 'invr_composite_bwd',
            'invr_field_workspace_bytes', 'invr_field_fwd', 'invr_geometry_fwd', 'invr_generate_rays',
-           'invr_rigid_transformation', 'invr_pack_parts']
+           'invr_rigid_transformation', 'invr_pack_parts', 'invr_grid_row_sums_len', 'invr_grid_row_sums']
 NUM_STAGES = 14
 STAGE_NAMES = ['cull', 'knn', 'warp'] + ['encode_%d' % p for p in range(5)] + ['mlp_%d' % p for p in range(5)] + ['composite']
 
@@ -114,6 +115,10 @@ def lib():
         dp = C.POINTER(C.c_double)
         L.invr_generate_rays.argtypes = [dp, dp, dp, dp, C.POINTER(C.c_float), C.c_int32, C.c_int32, vp, vp, vp, vp, vp]
         L.invr_generate_rays.restype = C.c_int
+        L.invr_grid_row_sums_len.argtypes = [vp]
+        L.invr_grid_row_sums_len.restype = C.c_int64
+        L.invr_grid_row_sums.argtypes = [vp, vp, vp]
+        L.invr_grid_row_sums.restype = C.c_int
         L.invr_rigid_transformation.argtypes = [vp, vp, vp, vp, vp]
         L.invr_rigid_transformation.restype = C.c_int
         L.invr_pack_parts.argtypes = [vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_float, vp, vp, vp, vp, vp]

@@ -53,6 +53,8 @@ struct GridDev {
     float cell[INVR_MAX_LEVELS];
     int64_t dense_off[INVR_MAX_LEVELS];
     int32_t sum, sum_over_features, include_input;
+    const float* row_sums;      // optional inference-only (rows,) table of per-row feature sums
+    int64_t dense_rows;         // rows of `dense` (0 when !separate_dense)
 };
 
 struct VolDev {          // (Dx,Dy,Dz,C) volume + (2,3) bounds
@@ -236,6 +238,7 @@ int launch_deform_points(const SceneDev& s, const GridDev& dg, const MlpDev& dm,
 int launch_distortion(const float* weights, const float* z, int64_t n_rays, int S, float* out, hipStream_t st);
 int launch_generate_rays(const double* kinv, const double* r, const double* t, const double* o, const float* bounds,
                          int H, int W, float* ray_d, float* near, float* far, uint8_t* mask, hipStream_t st);
+int launch_row_sums(const GridDev& g, float* out, hipStream_t st);
 int launch_rigid_transformation(const double* poses, const double* joints, const int32_t* parents, float* A, hipStream_t st);
 int launch_pack_parts(const float* ppts, const float* weights, const int64_t* parts, const float* tpose, int n_verts, int n_w,
                       int stride, float overlap, float* part_pts, float* part_pbw, int64_t* lengths2, float* bounds, hipStream_t st);

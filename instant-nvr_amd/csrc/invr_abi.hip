@@ -51,6 +51,10 @@ GridDev make_grid_dev(const InvrGrid* g) {
     }
     for (int l = 0; l < INVR_MAX_LEVELS; ++l) { d.res[l] = g->res[l]; d.cell[l] = g->cell[l]; d.dense_off[l] = g->dense_off[l]; }
     d.sum = g->sum; d.sum_over_features = g->sum_over_features; d.include_input = g->include_input;
+    d.row_sums = (g->sum && g->sum_over_features) ? g->row_sums : nullptr;
+    d.dense_rows = 0;
+    if (g->separate_dense)
+        for (int l = 0; l < g->start_hash && l < INVR_MAX_LEVELS; ++l) d.dense_rows += (int64_t)g->res[l] * g->res[l] * g->res[l];
     return d;
 }
 
@@ -470,4 +474,18 @@ extern "C" int invr_pack_parts(const float* ppts, const float* weights, const in
     INVR_CHECK(n_verts >= 0 && n_weights >= 1 && stride >= n_verts, "invr_pack_parts: stride must be >= n_verts");
     return launch_pack_parts(ppts, weights, parts, tpose, n_verts, n_weights, stride, bbox_overlap, part_pts, part_pbw, lengths2,
                              bounds, (hipStream_t)stream);
+}
+
+extern "C" int64_t invr_grid_row_sums_len(const InvrGrid* grid) {
+    if (!grid || grid->n_levels < 1 || grid->n_levels > INVR_MAX_LEVELS) return 0;
+    GridDev g = make_grid_dev(grid);
+    return g.separate_dense ? g.dense_rows + (int64_t)(g.L - g.start_hash) * g.T : (int64_t)g.L * g.T;
+}
+
+extern "C" int invr_grid_row_sums(const InvrGrid* grid, float* out, void* stream) {
+    INVR_CHECK(grid && out, "invr_grid_row_sums: null pointer");
+    if (check_grid(grid, "grid")) return 1;
+    INVR_CHECK(grid->sum && grid->sum_over_features, "invr_grid_row_sums: only sum && sum_over_features grids have row sums");
+    INVR_CHECK(grid->n_features % 4 == 0, "invr_grid_row_sums: n_features must be a multiple of 4");
+    return launch_row_sums(make_grid_dev(grid), out, (hipStream_t)stream);
 }

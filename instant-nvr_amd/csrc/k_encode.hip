@@ -451,6 +451,97 @@ int launch_part_encode_bwd(const GridDev& g, const float* xyz, const float* gout
     return 0;
 }
 
+// ---- inference-only row-sum variant -------------------------------------------------------------------
+// With sum && sum_over_features the F features of a row are only ever used through their sum, and the
+// sum commutes with the trilinear interpolation: a derived (rows,) table of row sums (rebuilt by the host
+// whenever the tables change) shrinks the 1.09 GB of tables to 68 MB — resident in the 256 MB Infinity
+// Cache — and each corner fetch to one dword.  Thread-per-pair: the 64 lanes of a wave hold 64 consecutive
+// pairs of the list (consecutive samples of a ray), so on the dense levels neighbouring lanes fall into the
+// same / adjacent 64-byte lines; the level constants are wave-uniform (scalar registers).
+#define RS_BLOCK 256
+__global__ __launch_bounds__(RS_BLOCK) void k_part_encode_rs(GridDev g, const float* __restrict__ rs,
+                                                             const float* __restrict__ xs, int64_t stride,
+                                                             const int32_t* __restrict__ count, int64_t cap,
+                                                             float* __restrict__ emb) {
+    const int cnt = *count;
+    const float b0x = g.bounds[0], b0y = g.bounds[1], b0z = g.bounds[2];
+    const float ex = g.bounds[3] - b0x, ey = g.bounds[4] - b0y, ez = g.bounds[5] - b0z;
+    const int hstart = g.separate_dense ? g.start_hash : 0;
+    for (int64_t i = (int64_t)blockIdx.x * RS_BLOCK + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * RS_BLOCK) {
+        const float x = (xs[i] - b0x) / ex, y = (xs[stride + i] - b0y) / ey, z = (xs[2 * stride + i] - b0z) / ez;   // :112
+        emb[i] = x; emb[cap + i] = y; emb[2 * cap + i] = z;
+        emb[(int64_t)(EMB_K - 1) * cap + i] = 0.0f;                 // pad column
+#pragma unroll 2
+        for (int l = 0; l < 16; ++l) {
+            const int res = g.res[l];
+            const float cell = g.cell[l];
+            int c0x, c1x, c0y, c1y, c0z, c1z;
+            float tx, ty, tz;
+            level_corners(x, cell, res, c0x, c1x, tx);
+            level_corners(y, cell, res, c0y, c1y, ty);
+            level_corners(z, cell, res, c0z, c1z, tz);
+            unsigned row[8];
+            const float* tab;
+            if (l >= g.start_hash) {
+                tab = rs + g.dense_rows + (int64_t)(l - hstart) * g.T;
+                const uint64_t hx[2] = {(uint64_t)(uint32_t)c0x, (uint64_t)(uint32_t)c1x};
+                const uint64_t hy[2] = {(uint64_t)(uint32_t)c0y * HASH_P1, (uint64_t)(uint32_t)c1y * HASH_P1};
+                const uint64_t hz[2] = {(uint64_t)(uint32_t)c0z * HASH_P2, (uint64_t)(uint32_t)c1z * HASH_P2};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) row[k] = grid_hash_mod(hx[k >> 2] ^ hy[(k >> 1) & 1] ^ hz[k & 1], g);
+            } else {
+                tab = g.separate_dense ? rs + g.dense_off[l] : rs + (int64_t)l * g.T;
+                const unsigned ures = (unsigned)res;
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    row[k] = ((unsigned)((k & 4) ? c1x : c0x) * ures + (unsigned)((k & 2) ? c1y : c0y)) * ures + (unsigned)((k & 1) ? c1z : c0z);
+            }
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = tab[row[k]];
+            const float ux = 1.0f - tx, uy = 1.0f - ty, uz = 1.0f - tz;
+            float acc = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)     // weight_k = prod_axis ((1-o) + (2o-1) t)  (:157-158)
+                acc = fmaf(((k & 4) ? tx : ux) * ((k & 2) ? ty : uy) * ((k & 1) ? tz : uz), v[k], acc);
+            emb[(int64_t)(3 + l) * cap + i] = acc;
+        }
+    }
+}
+
+// one quad per table row: 4 x float4 of a 16-feature row (or F/4 lanes for narrower rows), pairwise sums
+__global__ void k_row_sums(const float* __restrict__ tab, int64_t rows, int F, float* __restrict__ out) {
+    const int per = F / 4;                                           // lanes per row
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t r = t / per;
+    if (r >= rows) return;
+    const int q = (int)(t - r * per);
+    const float4 a = reinterpret_cast<const float4*>(tab)[r * per + q];
+    float s = (a.x + a.y) + (a.z + a.w);
+    if (per == 4) {
+        s = quad_sum(s);
+        if (q == 0) out[r] = s;
+    } else {
+        atomicAdd(out + r, s);                                       // F != 16: rare; out pre-zeroed by the launcher
+    }
+}
+
+int launch_row_sums(const GridDev& g, float* out, hipStream_t st) {
+    const int per = g.F / 4;
+    auto run = [&](const float* tab, int64_t rows, float* o) -> int {
+        if (rows == 0) return 0;
+        if (per != 4) INVR_HIP(hipMemsetAsync(o, 0, rows * sizeof(float), st));
+        hipLaunchKernelGGL(k_row_sums, dim3((unsigned)cdiv(rows * per, 256)), dim3(256), 0, st, tab, rows, g.F, o);
+        INVR_LAUNCH_CHECK();
+        return 0;
+    };
+    if (g.separate_dense) {
+        if (run(g.dense, g.dense_rows, out)) return 1;
+        return run(g.hash, (int64_t)(g.L - g.start_hash) * g.T, out + g.dense_rows);
+    }
+    return run(g.hash, (int64_t)g.L * g.T, out);
+}
+
 int launch_part_encode(const GridDev& g, const float* x_soa, int64_t stride, const int32_t* count, int64_t cap,
                        float* emb, hipStream_t st) {
     if (g.L != 16 || g.F != 16 || !g.sum || !g.sum_over_features || !g.include_input) {
@@ -459,6 +550,11 @@ int launch_part_encode(const GridDev& g, const float* x_soa, int64_t stride, con
     }
     int64_t tiles = cdiv(cap, 64 * ENC_WAVES);
     unsigned grid = (unsigned)(tiles < 256 * 8 ? (tiles > 0 ? tiles : 1) : 256 * 8);
+    if (g.row_sums) {
+        hipLaunchKernelGGL(k_part_encode_rs, dim3(grid), dim3(RS_BLOCK), 0, st, g, g.row_sums, x_soa, stride, count, cap, emb);
+        INVR_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(k_part_encode, dim3(grid), dim3(ENC_BLOCK), 0, st, g, x_soa, stride, count, cap, emb);
     INVR_LAUNCH_CHECK();
     return 0;

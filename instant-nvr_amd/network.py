@@ -53,6 +53,20 @@ class Embedder(nn.Module):
     def grid_struct(self, keep):
         return _abi.make_grid(self.spec, self.dense if self.separate_dense else None, self.hash, self.bounds, keep)
 
+    def row_sums(self):
+        """Inference-only derived table (invr_grid_row_sums): one float per table row = sum of its F
+        features.  Cached; rebuilt when the tables were written to (tensor version counters) or moved."""
+        tabs = [self.hash] + ([self.dense] if self.separate_dense else [])
+        key = tuple((t.data_ptr(), t._version, str(t.device)) for t in tabs)
+        if getattr(self, '_rs_key', None) != key:
+            keep = []
+            g = self.grid_struct(keep)
+            n = _abi.lib().invr_grid_row_sums_len(C.byref(g))
+            rs = torch.empty(n, device=self.hash.device, dtype=torch.float32)
+            _abi.check(_abi.lib().invr_grid_row_sums(C.byref(g), _abi.ptr(rs), _abi.stream_ptr()))
+            self._rs, self._rs_key = rs, key
+        return self._rs
+
     def forward(self, xyz, batch=None):
         """HashEmbedder.forward (:106-174) through invr_grid_encode_fwd."""
         if batch is not None:
@@ -154,7 +168,16 @@ class Network(nn.Module):
     # -- C-ABI glue ---------------------------------------------------------------------------
     def model_struct(self, keep):
         sd = {k: v for k, v in self.named_parameters()}
-        return _abi.make_model(sd, self.cfg, keep)
+        m = _abi.make_model(sd, self.cfg, keep)
+        if not self.training and self.cfg.get('eval_row_sums', True):
+            # eval: the per-part grids are read through their row-sum tables (16x fewer table bytes)
+            for i, pn in enumerate(self.tpose_human.part_networks):
+                e = pn.embedder
+                if e.spec['sum'] and e.spec['sum_over_features'] and e.f % 4 == 0:
+                    rs = e.row_sums()
+                    keep.append(rs)
+                    m.part[i].grid.row_sums = rs.data_ptr()
+        return m
 
     def workspace(self, nbytes, device):
         if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:

@@ -48,7 +48,7 @@ def test_struct_sizes_match_header():
     """ctypes mirrors must have the C layout (checked against sizes computed from the header's field lists)."""
     import ctypes as C
     from invr import _abi
-    assert C.sizeof(_abi.InvrGrid) == 3 * 8 + 4 * 4 + 8 + 16 * 4 + 16 * 4 + 16 * 8 + 3 * 4 + 4
+    assert C.sizeof(_abi.InvrGrid) == 3 * 8 + 4 * 4 + 8 + 16 * 4 + 16 * 4 + 16 * 8 + 3 * 4 + 4 + 8
     assert C.sizeof(_abi.InvrMlp) == 8 * 8 + 5 * 4 + 4
     assert C.sizeof(_abi.InvrPart) == C.sizeof(_abi.InvrGrid) + 2 * C.sizeof(_abi.InvrMlp) + 8 + 8
     L = _abi.lib()

@@ -32,6 +32,24 @@ def gpu_setup(small_setup):
     return cfg, sd, batch, gb, net
 
 
+class encoder_mode:
+    """Eval renders read the part grids through row-sum tables by default (cfg.eval_row_sums); the
+    parity tests run both that path and the direct 64-byte-row path."""
+
+    def __init__(self, cfg, row_sums):
+        self.cfg, self.val = cfg, row_sums
+
+    def __enter__(self):
+        self.old = self.cfg.get('eval_row_sums', True)
+        self.cfg['eval_row_sums'] = self.val
+
+    def __exit__(self, *a):
+        self.cfg['eval_row_sums'] = self.old
+
+
+BOTH_ENCODERS = pytest.mark.parametrize('row_sums', [True, False], ids=['rowsum', 'fullrow'])
+
+
 def maxerr(a, b):
     a = a.detach().cpu().numpy() if torch.is_tensor(a) else a
     b = b.detach().cpu().numpy() if torch.is_tensor(b) else b
@@ -151,11 +169,14 @@ def test_warp_deform(gpu_setup, golden):
     assert maxerr(rs[None], golden['resd']) < 2e-6
 
 
-def test_part_fields(gpu_setup, golden):
+@BOTH_ENCODERS
+def test_part_fields(gpu_setup, golden, row_sums):
     cfg, sd, batch, gb, net = gpu_setup
     L = _abi.lib()
     keep = []
-    model = net.model_struct(keep)
+    with encoder_mode(cfg, row_sums):
+        model = net.model_struct(keep)
+    assert bool(model.part[0].grid.row_sums) == row_sums
     li = gb['latent_index'].reshape(-1)[:1].to(torch.int64).contiguous()
     pflag = golden['pflag'][0]
     n_inside = 0
@@ -196,11 +217,13 @@ def test_composite_random(gpu_setup):
         assert maxerr(wo, w) < 2e-6 and maxerr(ro, rgb) < 5e-6 and maxerr(ao, acc) < 5e-6
 
 
-def test_render_64x64x32_vs_reference_golden(gpu_setup, golden):
+@BOTH_ENCODERS
+def test_render_64x64x32_vs_reference_golden(gpu_setup, golden, row_sums):
     """BASELINE config 1 through Renderer.render (eval): <= 1e-4 per pixel vs the reference."""
     cfg, sd, batch, gb, net = gpu_setup
     r = Renderer(net)
-    ret = r.render(dict(gb))
+    with encoder_mode(cfg, row_sums):
+        ret = r.render(dict(gb))
     assert set(ret.keys()) == {'rgb_map', 'acc_map', 'raw', 'occ'}
     assert all(not v.is_cuda for v in ret.values())                       # reference moves eval outputs to CPU
     assert ret['raw'].shape == (1, gb['ray_o'].shape[1] * cfg.N_samples, 4)
