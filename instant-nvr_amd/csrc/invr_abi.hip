@@ -195,6 +195,7 @@ static size_t carve(Workspace& w, void* base, int64_t N, int64_t cap) {
     w.emb[0] = c.take<float>(lc * EMB_K);
     w.emb[1] = c.take<float>(lc * EMB_K);
     w.raws = c.take<float4>(lc * INVR_NUM_PARTS);
+    w.dslice = c.take<float2>(DF_SLICE_MAX);
     return align_up(c.off, 256);
 }
 

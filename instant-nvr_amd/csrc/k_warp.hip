@@ -10,6 +10,7 @@
 // One thread per pair.  The 24 joint matrices and the deformer MLP weights are wave-uniform:
 // they are read through the scalar path (s_load) and used as SGPR operands of v_fmac.
 // The deformer tables are 0.34 MB (L2 resident).
+#include <stdlib.h>
 #include "pipeline.h"
 #include "grid_generic.h"
 
@@ -174,21 +175,372 @@ __global__ __launch_bounds__(WARP_BLOCK) void k_warp_pairs(RenderArgs a, Workspa
     }
 }
 
-__global__ __launch_bounds__(WARP_BLOCK) void k_deform_pairs(RenderArgs a, Workspace w, GridDev dg,
-                                                             const float* __restrict__ W0, const float* __restrict__ B0,
-                                                             const float* __restrict__ W1, const float* __restrict__ B1,
-                                                             const float* __restrict__ W2, const float* __restrict__ B2) {
+// Residual deformer of the pair lists on the fp32 matrix cores (same D^T = W . X^T orientation as
+// k_part_mlp: 16 pairs = the N columns of v_mfma_f32_16x16x4_f32, accumulators of one layer are the B
+// operands of the next).  A wave handles 64 pairs per iteration:
+//   1. lane j: canonical point of pair j, trilinear (u,v) from the UV volume
+//   2. four 16-pair tiles; in tile cb lane (g = lane>>4, col = lane&15) encodes levels 2g and 2g+1 of
+//      pair cb*16+col (16 float2 gathers per lane, no index math duplicated between lanes) — the K order
+//      of layer 1 is permuted to match: k-slot (s<4, g) = feature 3 + 2*(2g + s/2) + s%2, (4, g) = uvt[g]
+//   3. 19(20) -> 32 -> 32 on MFMA (10 + 16 instructions per tile), 32 -> 3 head as VALU dots, 0.05*tanh
+//   4. lane j = cb*16+col takes the result of "its" pair back and writes tpose / resd, coalesced.
+typedef float dfx4 __attribute__((ext_vector_type(4)));
+#define DF_BLOCK 256
+#define DF_O_W1 0                       // 5 k-steps * 2 m-tiles * 64 lanes
+#define DF_O_W2 (DF_O_W1 + 5 * 2 * 64)  // 8 * 2 * 64
+#define DF_O_B1 (DF_O_W2 + 8 * 2 * 64)  // 32
+#define DF_O_B2 (DF_O_B1 + 32)          // 32
+#define DF_O_V (DF_O_B2 + 32)           // 3 * 32, slot order [c][g*8 + mt*4 + r]
+#define DF_O_B3 (DF_O_V + 96)           // 3 (+1)
+#define DF_LDS (DF_O_B3 + 4)
+
+__device__ __forceinline__ int df_col(int s, int g) { return s < 4 ? 3 + 2 * (2 * g + (s >> 1)) + (s & 1) : (g < 3 ? g : -1); }
+
+struct LaneLevel2 { const float2* tab; int res; float cell; bool hashed; };
+
+// one level of the 8x2 deformer grid for this lane's point: same arithmetic and accumulation order as
+// grid_level_lookup + grid_encode_concat (part_base_embedder.py:115-159)
+__device__ __forceinline__ void lane_level_f2(const GridDev& dg, const LaneLevel2& L, float x, float y, float z, float& f0, float& f1) {
+    int c0x, c1x, c0y, c1y, c0z, c1z;
+    float tx, ty, tz;
+    level_corners(x, L.cell, L.res, c0x, c1x, tx);
+    level_corners(y, L.cell, L.res, c0y, c1y, ty);
+    level_corners(z, L.cell, L.res, c0z, c1z, tz);
+    float2 v[8];
+    if (L.hashed) {
+        const uint64_t hx[2] = {(uint64_t)(uint32_t)c0x, (uint64_t)(uint32_t)c1x};
+        const uint64_t hy[2] = {(uint64_t)(uint32_t)c0y * HASH_P1, (uint64_t)(uint32_t)c1y * HASH_P1};
+        const uint64_t hz[2] = {(uint64_t)(uint32_t)c0z * HASH_P2, (uint64_t)(uint32_t)c1z * HASH_P2};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = L.tab[grid_hash_mod(hx[k >> 2] ^ hy[(k >> 1) & 1] ^ hz[k & 1], dg)];
+    } else {
+        const unsigned ures = (unsigned)L.res;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            v[k] = L.tab[((unsigned)((k & 4) ? c1x : c0x) * ures + (unsigned)((k & 2) ? c1y : c0y)) * ures + (unsigned)((k & 1) ? c1z : c0z)];
+    }
+    const float ux = 1.0f - tx, uy = 1.0f - ty, uz = 1.0f - tz;
+    f0 = 0.0f; f1 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float wk = ((k & 4) ? tx : ux) * ((k & 2) ? ty : uy) * ((k & 1) ? tz : uz);
+        f0 = fmaf(wk, v[k].x, f0);
+        f1 = fmaf(wk, v[k].y, f1);
+    }
+}
+
+template <int DF_CB>                    // 16-pair tiles in flight per wave (register budget)
+__global__ __launch_bounds__(DF_BLOCK) void k_deform_pairs(RenderArgs a, Workspace w, GridDev dg,
+                                                           const float* __restrict__ W0, const float* __restrict__ B0,
+                                                           const float* __restrict__ W1, const float* __restrict__ B1,
+                                                           const float* __restrict__ W2, const float* __restrict__ B2) {
+    __shared__ float lds[DF_LDS];
     const int p = blockIdx.y;
     const int cnt = w.counters[CNT_PAIRS + p];
-    for (int64_t i = (int64_t)blockIdx.x * WARP_BLOCK + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * WARP_BLOCK) {
-        float xb[3], r[3];
+    if ((int64_t)blockIdx.x * DF_BLOCK >= cnt) return;
+    for (int t = threadIdx.x; t < 5 * 2 * 64; t += DF_BLOCK) {
+        const int ln = t & 63, mt = (t >> 6) & 1, s = t >> 7, g = ln >> 4, i = ln & 15, col = df_col(s, g);
+        lds[DF_O_W1 + t] = col >= 0 ? W0[(16 * mt + i) * 19 + col] : 0.0f;
+    }
+    for (int t = threadIdx.x; t < 8 * 2 * 64; t += DF_BLOCK) {
+        const int ln = t & 63, mt = (t >> 6) & 1, s = t >> 7, g = ln >> 4, i = ln & 15;
+        lds[DF_O_W2 + t] = W1[(16 * mt + i) * 32 + 16 * (s >> 2) + 4 * g + (s & 3)];
+    }
+    if (threadIdx.x < 32) {
+        const int t = threadIdx.x, g = t >> 3, u = t & 7, hc = 16 * (u >> 2) + 4 * g + (u & 3);
+        lds[DF_O_B1 + t] = B0[t];
+        lds[DF_O_B2 + t] = B1[t];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) xb[c] = w.l_x[p][c * w.lcap + i];
-        deform_point(a.scene, dg, W0, B0, W1, B1, W2, B2, xb, r);
+        for (int c = 0; c < 3; ++c) lds[DF_O_V + c * 32 + t] = W2[c * 32 + hc];
+        if (t < 3) lds[DF_O_B3 + t] = B2[t];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, col = lane & 15;
+    LaneLevel2 LA, LB;                   // levels 2g and 2g+1
+    LA.tab = LB.tab = nullptr; LA.res = LB.res = 2; LA.cell = LB.cell = 1.0f; LA.hashed = LB.hashed = false;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            w.l_x[p][c * w.lcap + i] = xb[c] + r[c];     // tpose = init_bigpose + resd (:111)
-            w.l_r[p][c * w.lcap + i] = r[c];
+    for (int l = 0; l < 8; ++l) {
+        LaneLevel2 t;
+        t.hashed = l >= dg.start_hash;
+        t.res = dg.res[l];
+        t.cell = dg.cell[l];
+        const float* tb = dg.separate_dense ? (t.hashed ? dg.hash + (int64_t)(l - dg.start_hash) * dg.T * 2 : dg.dense + dg.dense_off[l] * 2)
+                                            : dg.hash + (int64_t)l * dg.T * 2;
+        t.tab = reinterpret_cast<const float2*>(tb);
+        if (l == 2 * g) LA = t;
+        if (l == 2 * g + 1) LB = t;
+    }
+    const float gb0 = dg.bounds[0], gb1 = dg.bounds[1], gb2 = dg.bounds[2];
+    const float ge0 = dg.bounds[3] - gb0, ge1 = dg.bounds[4] - gb1, ge2 = dg.bounds[5] - gb2;
+    const float tn = (a.scene.frame_dim[0] - gb2) / ge2;                 // uvt[2] = frame_dim, normalised (:112)
+    float* lx = w.l_x[p];
+    float* lr = w.l_r[p];
+
+    for (int64_t base = (int64_t)blockIdx.x * DF_BLOCK + wv * 64; base < cnt; base += (int64_t)gridDim.x * DF_BLOCK) {
+        const int64_t i = min(base + lane, (int64_t)cnt - 1);
+        float xb[3], uv[2];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) xb[c] = lx[c * w.lcap + i];
+        sample_volume_dev<2>(a.scene.tuv, 0, xb[0], xb[1], xb[2], uv);
+        const float un = (uv[0] - gb0) / ge0, vn = (uv[1] - gb1) / ge1;
+        float r3[3] = {0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int half = 0; half < 4 / DF_CB; ++half) {
+        float eb[DF_CB][5];
+#pragma unroll
+        for (int cb = 0; cb < DF_CB; ++cb) {
+            const int src = (half * DF_CB + cb) * 16 + col;
+            const float uu = __shfl(un, src), vv = __shfl(vn, src);
+            lane_level_f2(dg, LA, uu, vv, tn, eb[cb][0], eb[cb][1]);
+            lane_level_f2(dg, LB, uu, vv, tn, eb[cb][2], eb[cb][3]);
+            eb[cb][4] = g == 0 ? uu : (g == 1 ? vv : (g == 2 ? tn : 0.0f));
+        }
+        // ---- layer 1: 20 -> 32
+        dfx4 h[DF_CB][2];
+#pragma unroll
+        for (int cb = 0; cb < DF_CB; ++cb)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h[cb][mt][r] = lds[DF_O_B1 + 16 * mt + 4 * g + r];
+#pragma unroll
+        for (int s = 0; s < 5; ++s)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const float aw = lds[DF_O_W1 + (s * 2 + mt) * 64 + lane];
+#pragma unroll
+                for (int cb = 0; cb < DF_CB; ++cb) h[cb][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw, eb[cb][s], h[cb][mt], 0, 0, 0);
+            }
+#pragma unroll
+        for (int cb = 0; cb < DF_CB; ++cb)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h[cb][mt][r] = softplus_f(h[cb][mt][r]);
+        // ---- layer 2: 32 -> 32
+        dfx4 h2[DF_CB][2];
+#pragma unroll
+        for (int cb = 0; cb < DF_CB; ++cb)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h2[cb][mt][r] = lds[DF_O_B2 + 16 * mt + 4 * g + r];
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const float aw = lds[DF_O_W2 + (s * 2 + mt) * 64 + lane];
+#pragma unroll
+                for (int cb = 0; cb < DF_CB; ++cb) h2[cb][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw, h[cb][s >> 2][s & 3], h2[cb][mt], 0, 0, 0);
+            }
+        // ---- head 32 -> 3, 0.05 * tanh; lane j = cb*16+col keeps the result of pair j
+#pragma unroll
+        for (int cb = 0; cb < DF_CB; ++cb) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h2[cb][mt][r] = softplus_f(h2[cb][mt][r]);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc = fmaf(lds[DF_O_V + c * 32 + g * 8 + mt * 4 + r], h2[cb][mt][r], acc);
+                acc += __shfl_xor(acc, 16);
+                acc += __shfl_xor(acc, 32);
+                if (g == half * DF_CB + cb) r3[c] = acc + lds[DF_O_B3 + c];
+            }
+        }
+        }
+        if (base + lane < cnt) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float r = 0.05f * tanhf(r3[c]);
+                lx[c * w.lcap + i] = xb[c] + r;                  // tpose = init_bigpose + resd (:111)
+                lr[c * w.lcap + i] = r;
+            }
+        }
+    }
+}
+
+// ---- deformer with per-frame t-slices ---------------------------------------------------------------
+// The deformer's third grid coordinate is frame_dim (uv_deformer.py:33-34): ONE value for the whole call.
+// So per level the z corner pair and its weight are the same for every point, and the 3-D grid collapses
+// to a 2-D (u,v) table  S_l[cx][cy] = (1-tz) row(cx,cy,c0z) + tz row(cx,cy,c1z)  (hashed levels included:
+// the slice of a hashed level is materialised densely).  sum_l res_l^2 = 2959 entries (24 KB) for the
+// reference's 8 levels — built once per call by k_deform_slice and held in LDS, so the 64 L1-line gathers
+// per pair that bounded the kernel become 32 ds_read_b64.  (u,v) index math stays the reference's.
+struct DfSliceInfo { int off[INVR_MAX_LEVELS + 1]; };
+
+__global__ void k_deform_slice(GridDev dg, DfSliceInfo si, const float* __restrict__ frame_dim, float2* __restrict__ out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= si.off[dg.L]) return;
+    int l = 0;
+    while (e >= si.off[l + 1]) ++l;
+    const int res = dg.res[l];
+    const float tn = (frame_dim[0] - dg.bounds[2]) / (dg.bounds[5] - dg.bounds[2]);
+    int c0z, c1z;
+    float tz;
+    level_corners(tn, dg.cell[l], res, c0z, c1z, tz);
+    const int idx = e - si.off[l], cx = idx / res, cy = idx - cx * res;
+    const bool hashed = l >= dg.start_hash;
+    const float* tb = dg.separate_dense ? (hashed ? dg.hash + (int64_t)(l - dg.start_hash) * dg.T * 2 : dg.dense + dg.dense_off[l] * 2)
+                                        : dg.hash + (int64_t)l * dg.T * 2;
+    const float2* tab = reinterpret_cast<const float2*>(tb);
+    unsigned r0, r1;
+    if (hashed) {
+        const uint64_t hxy = (uint64_t)(uint32_t)cx ^ ((uint64_t)(uint32_t)cy * HASH_P1);
+        r0 = grid_hash_mod(hxy ^ ((uint64_t)(uint32_t)c0z * HASH_P2), dg);
+        r1 = grid_hash_mod(hxy ^ ((uint64_t)(uint32_t)c1z * HASH_P2), dg);
+    } else {
+        r0 = ((unsigned)cx * (unsigned)res + (unsigned)cy) * (unsigned)res + (unsigned)c0z;
+        r1 = ((unsigned)cx * (unsigned)res + (unsigned)cy) * (unsigned)res + (unsigned)c1z;
+    }
+    const float2 v0 = tab[r0], v1 = tab[r1];
+    const float uz = 1.0f - tz;
+    out[e] = make_float2(fmaf(tz, v1.x, uz * v0.x), fmaf(tz, v1.y, uz * v0.y));
+}
+
+struct LaneSlice { int off, res; float cell; };
+
+__device__ __forceinline__ void lane_level_slice(const float2* S, const LaneSlice& L, float x, float y, float& f0, float& f1) {
+    int c0x, c1x, c0y, c1y;
+    float tx, ty;
+    level_corners(x, L.cell, L.res, c0x, c1x, tx);
+    level_corners(y, L.cell, L.res, c0y, c1y, ty);
+    const float2* row0 = S + L.off + c0x * L.res;
+    const float2* row1 = S + L.off + c1x * L.res;
+    const float2 s00 = row0[c0y], s01 = row0[c1y], s10 = row1[c0y], s11 = row1[c1y];
+    const float ux = 1.0f - tx, uy = 1.0f - ty;
+    const float w00 = ux * uy, w01 = ux * ty, w10 = tx * uy, w11 = tx * ty;
+    f0 = fmaf(w11, s11.x, fmaf(w10, s10.x, fmaf(w01, s01.x, w00 * s00.x)));
+    f1 = fmaf(w11, s11.y, fmaf(w10, s10.y, fmaf(w01, s01.y, w00 * s00.y)));
+}
+
+template <int DF_CB>
+__global__ __launch_bounds__(DF_BLOCK) void k_deform_pairs_slice(RenderArgs a, Workspace w, GridDev dg, DfSliceInfo si,
+                                                                 const float* __restrict__ W0, const float* __restrict__ B0,
+                                                                 const float* __restrict__ W1, const float* __restrict__ B1,
+                                                                 const float* __restrict__ W2, const float* __restrict__ B2) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];          // [MLP weights | slices]
+    const int p = blockIdx.y;
+    const int cnt = w.counters[CNT_PAIRS + p];
+    if ((int64_t)blockIdx.x * DF_BLOCK >= cnt) return;
+    float2* S = reinterpret_cast<float2*>(lds + DF_LDS);
+    for (int t = threadIdx.x; t < si.off[8]; t += DF_BLOCK) S[t] = w.dslice[t];
+    for (int t = threadIdx.x; t < 5 * 2 * 64; t += DF_BLOCK) {
+        const int ln = t & 63, mt = (t >> 6) & 1, s = t >> 7, g = ln >> 4, i = ln & 15, col = df_col(s, g);
+        lds[DF_O_W1 + t] = col >= 0 ? W0[(16 * mt + i) * 19 + col] : 0.0f;
+    }
+    for (int t = threadIdx.x; t < 8 * 2 * 64; t += DF_BLOCK) {
+        const int ln = t & 63, mt = (t >> 6) & 1, s = t >> 7, g = ln >> 4, i = ln & 15;
+        lds[DF_O_W2 + t] = W1[(16 * mt + i) * 32 + 16 * (s >> 2) + 4 * g + (s & 3)];
+    }
+    if (threadIdx.x < 32) {
+        const int t = threadIdx.x, g = t >> 3, u = t & 7, hc = 16 * (u >> 2) + 4 * g + (u & 3);
+        lds[DF_O_B1 + t] = B0[t];
+        lds[DF_O_B2 + t] = B1[t];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) lds[DF_O_V + c * 32 + t] = W2[c * 32 + hc];
+        if (t < 3) lds[DF_O_B3 + t] = B2[t];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, col = lane & 15;
+    LaneSlice LA = {0, 2, 1.0f}, LB = {0, 2, 1.0f};             // levels 2g and 2g+1
+#pragma unroll
+    for (int l = 0; l < 8; ++l) {
+        const LaneSlice t = {si.off[l], dg.res[l], dg.cell[l]};
+        if (l == 2 * g) LA = t;
+        if (l == 2 * g + 1) LB = t;
+    }
+    const float gb0 = dg.bounds[0], gb1 = dg.bounds[1], gb2 = dg.bounds[2];
+    const float ge0 = dg.bounds[3] - gb0, ge1 = dg.bounds[4] - gb1, ge2 = dg.bounds[5] - gb2;
+    const float tn = (a.scene.frame_dim[0] - gb2) / ge2;
+    float* lx = w.l_x[p];
+    float* lr = w.l_r[p];
+
+    for (int64_t base = (int64_t)blockIdx.x * DF_BLOCK + wv * 64; base < cnt; base += (int64_t)gridDim.x * DF_BLOCK) {
+        const int64_t i = min(base + lane, (int64_t)cnt - 1);
+        float xb[3], uv[2];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) xb[c] = lx[c * w.lcap + i];
+        sample_volume_dev<2>(a.scene.tuv, 0, xb[0], xb[1], xb[2], uv);
+        const float un = (uv[0] - gb0) / ge0, vn = (uv[1] - gb1) / ge1;
+        float r3[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int half = 0; half < 4 / DF_CB; ++half) {
+            float eb[DF_CB][5];
+#pragma unroll
+            for (int cb = 0; cb < DF_CB; ++cb) {
+                const int src = (half * DF_CB + cb) * 16 + col;
+                const float uu = __shfl(un, src), vv = __shfl(vn, src);
+                lane_level_slice(S, LA, uu, vv, eb[cb][0], eb[cb][1]);
+                lane_level_slice(S, LB, uu, vv, eb[cb][2], eb[cb][3]);
+                eb[cb][4] = g == 0 ? uu : (g == 1 ? vv : (g == 2 ? tn : 0.0f));
+            }
+            dfx4 h[DF_CB][2];
+#pragma unroll
+            for (int cb = 0; cb < DF_CB; ++cb)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h[cb][mt][r] = lds[DF_O_B1 + 16 * mt + 4 * g + r];
+#pragma unroll
+            for (int s = 0; s < 5; ++s)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const float aw = lds[DF_O_W1 + (s * 2 + mt) * 64 + lane];
+#pragma unroll
+                    for (int cb = 0; cb < DF_CB; ++cb) h[cb][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw, eb[cb][s], h[cb][mt], 0, 0, 0);
+                }
+#pragma unroll
+            for (int cb = 0; cb < DF_CB; ++cb)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h[cb][mt][r] = softplus_f(h[cb][mt][r]);
+            dfx4 h2[DF_CB][2];
+#pragma unroll
+            for (int cb = 0; cb < DF_CB; ++cb)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h2[cb][mt][r] = lds[DF_O_B2 + 16 * mt + 4 * g + r];
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const float aw = lds[DF_O_W2 + (s * 2 + mt) * 64 + lane];
+#pragma unroll
+                    for (int cb = 0; cb < DF_CB; ++cb) h2[cb][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw, h[cb][s >> 2][s & 3], h2[cb][mt], 0, 0, 0);
+                }
+#pragma unroll
+            for (int cb = 0; cb < DF_CB; ++cb) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h2[cb][mt][r] = softplus_f(h2[cb][mt][r]);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc = fmaf(lds[DF_O_V + c * 32 + g * 8 + mt * 4 + r], h2[cb][mt][r], acc);
+                    acc += __shfl_xor(acc, 16);
+                    acc += __shfl_xor(acc, 32);
+                    if (g == half * DF_CB + cb) r3[c] = acc + lds[DF_O_B3 + c];
+                }
+            }
+        }
+        if (base + lane < cnt) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float r = 0.05f * tanhf(r3[c]);
+                lx[c * w.lcap + i] = xb[c] + r;                  // tpose = init_bigpose + resd (:111)
+                lr[c * w.lcap + i] = r;
+            }
         }
     }
 }
@@ -198,8 +550,31 @@ int launch_warp_pairs(const RenderArgs& a, const Workspace& w, const GridDev& dg
     unsigned gx = (unsigned)(tiles < 1024 ? (tiles > 0 ? tiles : 1) : 1024);
     hipLaunchKernelGGL(k_warp_pairs, dim3(gx, INVR_NUM_PARTS), dim3(WARP_BLOCK), 0, st, a, w, a.scene.A, a.scene.big_A);
     INVR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_deform_pairs, dim3(gx, INVR_NUM_PARTS), dim3(WARP_BLOCK), 0, st, a, w, dg, dm.w[0], dm.b[0], dm.w[1],
-                       dm.b[1], dm.w[2], dm.b[2]);
+    int64_t dtiles = cdiv(w.lcap, DF_BLOCK);
+    unsigned dgx = (unsigned)(dtiles < 512 ? (dtiles > 0 ? dtiles : 1) : 512);
+    static int cbv = getenv("INVR_DF_CB") ? atoi(getenv("INVR_DF_CB")) : 2;
+    DfSliceInfo si;
+    si.off[0] = 0;
+    for (int l = 0; l < INVR_MAX_LEVELS; ++l) si.off[l + 1] = si.off[l] + (l < dg.L ? dg.res[l] * dg.res[l] : 0);
+    if (dg.L == 8 && si.off[8] <= DF_SLICE_MAX && cbv < 10) {
+        hipLaunchKernelGGL(k_deform_slice, dim3((unsigned)cdiv(si.off[8], 256)), dim3(256), 0, st, dg, si, a.scene.frame_dim, w.dslice);
+        INVR_LAUNCH_CHECK();
+        const size_t lds_bytes = (size_t)DF_LDS * sizeof(float) + (size_t)si.off[8] * sizeof(float2);
+        if (cbv == 1)
+            hipLaunchKernelGGL(k_deform_pairs_slice<1>, dim3(dgx, INVR_NUM_PARTS), dim3(DF_BLOCK), lds_bytes, st, a, w, dg, si, dm.w[0], dm.b[0],
+                               dm.w[1], dm.b[1], dm.w[2], dm.b[2]);
+        else
+            hipLaunchKernelGGL(k_deform_pairs_slice<2>, dim3(dgx, INVR_NUM_PARTS), dim3(DF_BLOCK), lds_bytes, st, a, w, dg, si, dm.w[0], dm.b[0],
+                               dm.w[1], dm.b[1], dm.w[2], dm.b[2]);
+        INVR_LAUNCH_CHECK();
+        return 0;
+    }
+    if (cbv % 10 == 1)
+        hipLaunchKernelGGL(k_deform_pairs<1>, dim3(dgx, INVR_NUM_PARTS), dim3(DF_BLOCK), 0, st, a, w, dg, dm.w[0], dm.b[0], dm.w[1],
+                           dm.b[1], dm.w[2], dm.b[2]);
+    else
+        hipLaunchKernelGGL(k_deform_pairs<2>, dim3(dgx, INVR_NUM_PARTS), dim3(DF_BLOCK), 0, st, a, w, dg, dm.w[0], dm.b[0], dm.w[1],
+                           dm.b[1], dm.w[2], dm.b[2]);
     INVR_LAUNCH_CHECK();
     return 0;
 }

@@ -480,3 +480,25 @@ def test_scene_prep_on_device(small_setup):
     assert torch.equal(l2.cpu(), batch['lengths2'][0])
     assert torch.equal(pp.cpu(), batch['part_pts'][0]) and torch.equal(pb.cpu(), batch['part_pbw'][0])
     assert torch.equal(bd.cpu(), batch['bounds'][0])
+
+
+def test_pair_deformer_matches_point_deformer(gpu_setup):
+    """The pair-list deformer of the render pipeline (MFMA MLP, per-frame t-slices of the grid held in LDS)
+    against the thread-per-point deformer behind Network.resd (3-D grid lookups, VALU MLP), which
+    test_warp_deform pins to the reference goldens."""
+    cfg, sd, batch, gb, net = gpu_setup
+    ro, rd, nr, fr = (gb[k][0] for k in ('ray_o', 'ray_d', 'near', 'far'))
+    out = net.render_rays(gb, ro, rd, nr, fr, cfg.N_samples)
+    torch.cuda.synchronize()
+    v = _abi.ws_views(*out['_ws'])
+    stats = out['stats'].cpu().numpy()
+    n_checked = 0
+    for p in range(5):
+        c = int(stats[1 + p])
+        r_pairs = v['l_r'][p][:, :c].t().contiguous()
+        xb = (v['l_x'][p][:, :c].t() - r_pairs).contiguous()                # init_bigpose up to 1 ulp
+        r_pts = net.resd(xb[None], gb)[0]
+        assert maxerr(r_pairs, r_pts) < 1e-6, p
+        assert float(r_pairs.abs().max()) <= 0.05 and float(r_pairs.abs().max()) > 1e-4
+        n_checked += c
+    assert n_checked > 1000
