@@ -9,16 +9,21 @@
 //   * thresh*1.01 <= d1 <= ~0.47 m            -> dist >= d1*w1/(w1+1e-8) >= thresh -> NOT flagged
 //   * d1 >~ 0.5 m                             -> weights underflow against the epsilon, dist -> 0
 //                                                -> flagged with tiny blend weights  ("band")
-//   * d1 > 0.8 m                              -> w/1e-8 < 1e-16: blend weights are 0 to 1e-16, the
-//                                                pair warps to the canonical origin with a zero view
-//                                                direction -> its field value is a per-part CONSTANT
+//   * d1 > 0.68 m                             -> every normalised weight <= exp(-0.68^2/0.01125)/1e-8
+//                                                = 1.4e-10, sum s <= 5.6e-10.  Then |A_bw| <= 1.1e-9,
+//                                                R_inv = adj/(det+eps_f32) <= 5e-12, x_t <= 5e-11 and the
+//                                                canonical point |x_b| <= s*|t_big| <= 1.1e-9 m, view
+//                                                direction <= 1e-20: below the fp32 resolution of every
+//                                                coordinate the encoders / UV volume form from it (half an
+//                                                ulp of the 0.3..1.2 m box offsets is 1.5e-8..6e-8) -> the
+//                                                pair's field value is a per-part CONSTANT (x_b = 0, d = 0)
 // So every sample evaluates ~3 parts in the reference, most of them "far" pairs that all collapse
 // onto the same canonical point.  This kernel classifies each (point, part) with cluster bounds,
 // runs the exact 4-NN only where the result can matter (near / band), marks far pairs with a bit
 // (the merge kernel substitutes the per-part constant, evaluated once per frame through the very
 // same warp/encode/MLP kernels from an appended zero-weight pair) and drops provably unflagged
 // pairs.  Exactness: near/band pairs are bit-faithful brute-force results; far pairs differ from
-// the reference by <= 1e-16 relative in the blend weights.
+// the reference by <= 1.1e-9 m in the canonical point (see above).
 //
 // Data layout: a per-frame prepare kernel Morton-sorts each part's vertices (bitonic sort in LDS),
 // writes them as float4 {x,y,z,original row} and builds 64-vertex clusters {AABB, representative}.
@@ -32,7 +37,7 @@
 #define KNN_EPS 1e-8f
 // 2 * radius**2 with radius = 0.075 (blend_utils.py:741,747), evaluated in double like Python does
 #define KNN_TWO_R2 ((float)(2.0 * 0.075 * 0.075))
-#define KNN_DFAR2 0.64f          // (0.8 m)^2
+#define KNN_DFAR2 0.4624f        // (0.68 m)^2, see the header comment
 
 // Sorted 4-best list on 64-bit keys (squared distance bits << 32 | vertex row): non-negative floats
 // order like their bit patterns, so one unsigned compare orders by (distance, row) and the result
@@ -357,7 +362,9 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w, 
             }
             const bool is_far = lb2 > KNN_DFAR2;
             const bool unflagged = lb2 >= a.scene.near_hi2 && ub2 <= a.scene.band_lo2;
-            const bool scan = live && !is_far && !unflagged;
+            bool scan = live && !is_far && !unflagged;
+            if ((dbg & 4) && lb2 >= a.scene.near_hi2) scan = false;      // ablation: drop band-type scans
+            if ((dbg & 8) && lb2 < a.scene.near_hi2) scan = false;       // ablation: drop near-type scans
             if (live && is_far) farflags |= 1u << p;
             if (__ballot(scan) == 0 || (dbg & 1)) continue;
             // exact 4-NN: seed with the cluster of the wave's first scanning lane, then pruned sweep
