@@ -177,6 +177,7 @@ static size_t carve(Workspace& w, void* base, int64_t N, int64_t cap) {
     w.knn.cpad = KNN_MAX_PART / 64;
     w.knn.sverts = c.take<float4>((size_t)INVR_NUM_PARTS * w.knn.mpad);
     w.knn.cl = c.take<float4>((size_t)INVR_NUM_PARTS * w.knn.cpad * 3);
+    w.knn.sub = c.take<float4>((size_t)INVR_NUM_PARTS * w.knn.cpad * 8);
     w.mask = c.take<unsigned long long>(nb * 16);
     w.block_cnt = c.take<int32_t>(nb);
     w.block_off = c.take<int32_t>(nb);
