@@ -86,6 +86,8 @@ def main():
     ap.add_argument('--cpu-rays', type=int, default=128, help='rays in the bounded CPU-baseline sample')
     ap.add_argument('--full-rows', action='store_true', help='read the trainable 64-byte table rows instead of the eval-mode row-sum tables')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-graph', action='store_true', help='launch the ~25 kernels of a frame eagerly instead of replaying one captured hipGraph')
+    ap.add_argument('--shard-of', type=int, default=0, help='debug (1 GPU): render only rank 0\'s ray shard of a W-way split')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -121,17 +123,19 @@ def main():
     S = args.samples
 
     # shard the frame's rays (tile-cyclic) once; inputs stay resident in HBM
-    idx = idist.tile_indices(n_rays, rank, world, device=dev)
+    idx = idist.tile_indices(n_rays, rank, args.shard_of or world, device=dev)
     ro, rd = batch['ray_o'][0][idx].contiguous(), batch['ray_d'][0][idx].contiguous()
     nr, fr = batch['near'][0][idx].contiguous(), batch['far'][0][idx].contiguous()
     ctx = net.prepare(batch)
     want_raw = not args.no_raw
 
-    def step():
+    def render():
         out = net.render_rays(ctx, ro, rd, nr, fr, S, want_raw=want_raw)
-        rgba = torch.cat([out['rgb_map'], out['acc_map'][:, None]], 1)
-        full = idist.gather_maps(rgba, n_rays, rank, world)
-        return out, full
+        return out, torch.cat([out['rgb_map'], out['acc_map'][:, None]], 1)
+
+    def step():
+        out, rgba = render()
+        return out, idist.gather_maps(rgba, n_rays, rank, world)
 
     def fence():
         torch.cuda.synchronize()
@@ -139,16 +143,38 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 1)):
         out, full = step()
     fence()
-    _abi.profile_enable(True)
-    _abi.profile_read()
+    if not args.no_graph:
+        # one hipGraph per frame: the kernels of invr_render_fwd are enqueued on torch's capture stream
+        # (the library never synchronises or allocates), so a frame replays with one launch
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            render()
+        torch.cuda.current_stream().wait_stream(side)
+        with torch.cuda.graph(graph):
+            g_out, g_rgba = render()
+
+        def step():
+            graph.replay()
+            return g_out, idist.gather_maps(g_rgba, n_rays, rank, world)
+        out, full = step()
+        fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out, full = step()
     fence()
     dt = time.perf_counter() - t0
+    # per-stage HIP-event times: a few extra eager frames outside the timed region (event records are not
+    # replayable graph nodes)
+    _abi.profile_enable(True)
+    _abi.profile_read()
+    for _ in range(3):
+        render()
+    torch.cuda.synchronize()
     _abi.profile_enable(False)
     stage_ms, n_prof = _abi.profile_read()
     if world > 1:
@@ -189,7 +215,7 @@ def main():
                 'active_samples': int(stats_all[0]), 'active_fraction': float(stats_all[0]) / total_samples,
                 'pairs_per_part': [int(v) for v in stats_all[1:6]],
                 'pairs_per_active_sample': float(stats_all[1:6].sum()) / max(int(stats_all[0]), 1),
-                'parameters': int(n_params), 'raw_occ_materialised': want_raw,
+                'parameters': int(n_params), 'raw_occ_materialised': want_raw, 'hip_graph': not args.no_graph,
                 'parallelism': 'tile-cyclic ray shards x%d, full replicas, 1 all-gather/frame' % world,
                 'rays_per_sec': n_rays * args.steps / dt,
             },

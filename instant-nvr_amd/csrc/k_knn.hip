@@ -45,11 +45,13 @@
 // ~1e-7 per pair).  +inf / row 0 is both the empty marker and the cluster padding sentinel.
 struct Top4 {
     unsigned long long k[KNN_K];
+    float junk;
     float d[KNN_K];
     int i[KNN_K];
     __device__ __forceinline__ void init() {
 #pragma unroll
         for (int j = 0; j < KNN_K; ++j) k[j] = 0x7F80000000000000ull;
+        junk = 0.0f;
     }
     // ONE (usually wave-skipped) branch, the shifting is predicated selects — a nested-branch insert
     // costs ~10 scalar-ALU instructions per vertex and the CU has a single SALU
@@ -274,6 +276,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // reads are issued together; the squared distances of two vertices are formed with packed fp32 ops
 // (v_pk_add/mul_f32 — each component is the same IEEE op sequence as ((p1-p2)**2).sum(-1)); one fp32
 // compare against the current 4th best guards the exact 64-bit-key inserts of both.
+template <bool NOPUSH = false>
 __device__ __forceinline__ void scan_sub16(const float4* sv, v2f px, v2f py, v2f pz, Top4& t) {
 #pragma unroll
     for (int m0 = 0; m0 < 8; m0 += 4) {
@@ -285,6 +288,7 @@ __device__ __forceinline__ void scan_sub16(const float4* sv, v2f px, v2f py, v2f
             const v2f dx = px - (v2f){A[k].x, A[k].y}, dy = py - (v2f){A[k].z, A[k].w}, dz = pz - (v2f){B[k].x, B[k].y};
             const v2f d2 = (dx * dx + dy * dy) + dz * dz;
             if (fminf(d2.x, d2.y) <= t.worst()) {
+                if (NOPUSH) { t.junk += d2.x + d2.y + B[k].z; continue; }     // ablation only (INVR_KNN_DBG=32)
                 t.push(d2.x, __float_as_int(B[k].z));
                 t.push(d2.y, __float_as_int(B[k].w));
             }
@@ -413,14 +417,15 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w, 
                     for (int s4 = 0; s4 < 4; ++s4) {
                         const bool need_s = need && aabb_dist2(px, py, pz, lds_ld4(sb + c * 8 + s4 * 2), lds_ld4(sb + c * 8 + s4 * 2 + 1)) <= t.worst();
                         if (__ballot(need_s) == 0) continue;
-                        scan_sub16(sv + c * 64 + s4 * 16, px2, py2, pz2, t);
+                        if (dbg & 32) scan_sub16<true>(sv + c * 64 + s4 * 16, px2, py2, pz2, t);
+                        else scan_sub16(sv + c * 64 + s4 * 16, px2, py2, pz2, t);
                     }
                 }
             }
             t.finish();
             float wt[KNN_K];
             const float ds = knn_weights(t, wt);
-            if (scan && ds < a.scene.thresh) {                        // pflag (inb_part_network_multiassign.py:90)
+            if (scan && ds < a.scene.thresh && t.junk != 123.456f) {   // pflag (inb_part_network_multiassign.py:90)
                 flags |= 1u << p;
                 res_nn[p] = make_int4(t.i[0], t.i[1], t.i[2], t.i[3]);
                 res_w[p] = make_float4(wt[0], wt[1], wt[2], wt[3]);

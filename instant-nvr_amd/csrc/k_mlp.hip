@@ -14,6 +14,7 @@
 // that per-(k-step, m-tile, lane) order while they are staged into LDS (46 KB per part).
 // The 1-wide / 3-wide heads (occupancy logit, rgb out) are 16-term VALU dot products plus two
 // cross-lane adds instead of wasting 15/16 of an MFMA tile.
+#include <stdlib.h>
 #include "pipeline.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -268,7 +269,8 @@ int launch_part_mlp(const PartMlpDev& pm, const float* emb, const float* d_soa, 
     }
     const int64_t per_block = (MLP_BLOCK / 64) * MLP_CB * 16;
     int64_t tiles = cdiv(cap, per_block);
-    unsigned grid = (unsigned)(tiles < 256 * 2 ? (tiles > 0 ? tiles : 1) : 256 * 2);
+    static int wpb = getenv("INVR_MLP_BPC") ? atoi(getenv("INVR_MLP_BPC")) : 2;
+    unsigned grid = (unsigned)(tiles < 256 * wpb ? (tiles > 0 ? tiles : 1) : 256 * wpb);
     if (r.n_linear == 3)
         hipLaunchKernelGGL(k_part_mlp<3>, dim3(grid), dim3(MLP_BLOCK), 0, st, pm, emb, d_soa, stride, l_slot, count, cap, raws, part, raw_direct);
     else
