@@ -269,7 +269,7 @@ int launch_part_mlp(const PartMlpDev& pm, const float* emb, const float* d_soa, 
     }
     const int64_t per_block = (MLP_BLOCK / 64) * MLP_CB * 16;
     int64_t tiles = cdiv(cap, per_block);
-    static int wpb = getenv("INVR_MLP_BPC") ? atoi(getenv("INVR_MLP_BPC")) : 2;
+    static int wpb = getenv("INVR_MLP_BPC") ? atoi(getenv("INVR_MLP_BPC")) : 3;
     unsigned grid = (unsigned)(tiles < 256 * wpb ? (tiles > 0 ? tiles : 1) : 256 * wpb);
     if (r.n_linear == 3)
         hipLaunchKernelGGL(k_part_mlp<3>, dim3(grid), dim3(MLP_BLOCK), 0, st, pm, emb, d_soa, stride, l_slot, count, cap, raws, part, raw_direct);
