@@ -174,7 +174,7 @@ typedef struct InvrWsLayout {
     int64_t l_x[INVR_NUM_PARTS];           /* float[3*lcap] SoA: canonical point incl. residual    */
     int64_t l_d[INVR_NUM_PARTS];           /* float[3*lcap] SoA: canonical view direction          */
     int64_t l_r[INVR_NUM_PARTS];           /* float[3*lcap] SoA: residual (resd)                   */
-    int64_t emb[2];                        /* float[20*lcap] SoA: encoder output of the last parts */
+    int64_t emb[2];                        /* float[20*lcap] SoA: encoder output of parts 0 and 1 */
     int64_t raws;                          /* float4[lcap*5]: [rgb, occ] per (slot, part)          */
 } InvrWsLayout;
 int invr_workspace_layout(int64_t n_rays, int32_t n_samples, int64_t max_active, InvrWsLayout* out);

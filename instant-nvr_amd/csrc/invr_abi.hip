@@ -193,8 +193,7 @@ static size_t carve(Workspace& w, void* base, int64_t N, int64_t cap) {
         w.l_d[p] = c.take<float>(lc * 3);
         w.l_r[p] = c.take<float>(lc * 3);
     }
-    w.emb[0] = c.take<float>(lc * EMB_K);
-    w.emb[1] = c.take<float>(lc * EMB_K);
+    for (int p = 0; p < INVR_NUM_PARTS; ++p) w.emb[p] = c.take<float>(lc * EMB_K);
     w.raws = c.take<float4>(lc * INVR_NUM_PARTS);
     w.dslice = c.take<float2>(DF_SLICE_MAX);
     return align_up(c.off, 256);
@@ -294,8 +293,26 @@ static int render_impl(const InvrScene* scene, const InvrModel* model,
         MlpDev dm = make_mlp_dev(&model->deform_mlp);
         if (launch_warp_pairs(a, w, dg, dm, st)) return 1;
     }
-    for (int p = 0; p < INVR_NUM_PARTS && !geometry_only; ++p) {
-        float* emb = w.emb[p & 1];
+    bool merged = !geometry_only && getenv("INVR_NO_MERGE") == nullptr;
+    for (int p = 0; p < INVR_NUM_PARTS; ++p) merged = merged && model->part[p].grid.row_sums != nullptr;
+    if (merged) {
+        // eval path: the five parts in one encoder launch and one MLP launch (stage times are booked on part 0)
+        EncodeAllArgs ea;
+        MlpAllArgs ma;
+        for (int p = 0; p < INVR_NUM_PARTS; ++p) {
+            ea.g[p] = make_grid_dev(&model->part[p].grid);
+            ea.xs[p] = w.l_x[p]; ea.emb[p] = w.emb[p];
+            ma.pm[p] = make_part_mlp(model, p, scene->latent_index);
+            ma.emb[p] = w.emb[p]; ma.ds[p] = w.l_d[p]; ma.l_slot[p] = w.l_slot[p];
+        }
+        ea.counts = ma.counts = w.counters + CNT_PAIRS;
+        ea.stride = ma.stride = w.lcap; ea.cap = ma.cap = w.lcap;
+        ma.raws = w.raws;
+        { ProfStage ps(INVR_STAGE_ENCODE, st); if (launch_part_encode_all(ea, st)) return 1; }
+        { ProfStage ps(INVR_STAGE_MLP, st); if (launch_part_mlp_all(ma, st)) return 1; }
+    }
+    for (int p = 0; p < INVR_NUM_PARTS && !geometry_only && !merged; ++p) {
+        float* emb = w.emb[p];
         {
             ProfStage ps(INVR_STAGE_ENCODE + p, st);
             GridDev g = make_grid_dev(&model->part[p].grid);

@@ -459,11 +459,8 @@ int launch_part_encode_bwd(const GridDev& g, const float* xyz, const float* gout
 // pairs of the list (consecutive samples of a ray), so on the dense levels neighbouring lanes fall into the
 // same / adjacent 64-byte lines; the level constants are wave-uniform (scalar registers).
 #define RS_BLOCK 256
-__global__ __launch_bounds__(RS_BLOCK) void k_part_encode_rs(GridDev g, const float* __restrict__ rs,
-                                                             const float* __restrict__ xs, int64_t stride,
-                                                             const int32_t* __restrict__ count, int64_t cap,
-                                                             float* __restrict__ emb) {
-    const int cnt = *count;
+__device__ __forceinline__ void encode_rs_part(const GridDev& g, const float* __restrict__ rs, const float* __restrict__ xs,
+                                               int64_t stride, int cnt, int64_t cap, float* __restrict__ emb) {
     const float b0x = g.bounds[0], b0y = g.bounds[1], b0z = g.bounds[2];
     const float ex = g.bounds[3] - b0x, ey = g.bounds[4] - b0y, ez = g.bounds[5] - b0z;
     const int hstart = g.separate_dense ? g.start_hash : 0;
@@ -509,6 +506,20 @@ __global__ __launch_bounds__(RS_BLOCK) void k_part_encode_rs(GridDev g, const fl
     }
 }
 
+__global__ __launch_bounds__(RS_BLOCK) void k_part_encode_rs(GridDev g, const float* __restrict__ rs,
+                                                             const float* __restrict__ xs, int64_t stride,
+                                                             const int32_t* __restrict__ count, int64_t cap,
+                                                             float* __restrict__ emb) {
+    encode_rs_part(g, rs, xs, stride, *count, cap, emb);
+}
+
+// all five parts in ONE persistent launch: a workgroup walks its share of part 0, then of part 1, ... without a
+// device-wide drain between parts (5 launches of this size spend ~15 us each on ramp-up and tail)
+__global__ __launch_bounds__(RS_BLOCK) void k_part_encode_rs_all(EncodeAllArgs a) {
+    for (int p = 0; p < INVR_NUM_PARTS; ++p)
+        encode_rs_part(a.g[p], a.g[p].row_sums, a.xs[p], a.stride, a.counts[p], a.cap, a.emb[p]);
+}
+
 // one quad per table row: 4 x float4 of a 16-feature row (or F/4 lanes for narrower rows), pairwise sums
 __global__ void k_row_sums(const float* __restrict__ tab, int64_t rows, int F, float* __restrict__ out) {
     const int per = F / 4;                                           // lanes per row
@@ -540,6 +551,21 @@ int launch_row_sums(const GridDev& g, float* out, hipStream_t st) {
         return run(g.hash, (int64_t)(g.L - g.start_hash) * g.T, out + g.dense_rows);
     }
     return run(g.hash, (int64_t)g.L * g.T, out);
+}
+
+int launch_part_encode_all(const EncodeAllArgs& a, hipStream_t st) {
+    for (int p = 0; p < INVR_NUM_PARTS; ++p) {
+        const GridDev& g = a.g[p];
+        if (g.L != 16 || !g.sum || !g.sum_over_features || !g.include_input || !g.row_sums) {
+            invr_set_error("merged part encoder needs 16-level sum/sum_over_features grids with row-sum tables");
+            return 1;
+        }
+    }
+    int64_t tiles = cdiv(a.cap, RS_BLOCK);
+    unsigned grid = (unsigned)(tiles < 256 * 8 ? (tiles > 0 ? tiles : 1) : 256 * 8);
+    hipLaunchKernelGGL(k_part_encode_rs_all, dim3(grid), dim3(RS_BLOCK), 0, st, a);
+    INVR_LAUNCH_CHECK();
+    return 0;
 }
 
 int launch_part_encode(const GridDev& g, const float* x_soa, int64_t stride, const int32_t* count, int64_t cap,

@@ -356,6 +356,7 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w, 
         float px = 0, py = 0, pz = 0;
         if (live) sample_pose_point(a, w.active_idx[slot], px, py, pz, nullptr, nullptr);
         unsigned flags = 0, farflags = 0;
+        int dbg_subs = 0, dbg_tests = 0, dbg_scans = 0;     // INVR_KNN_DBG=64: work counters -> stats[13..15]
         int4 res_nn[INVR_NUM_PARTS];
         float4 res_w[INVR_NUM_PARTS];
 #pragma unroll
@@ -405,6 +406,7 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w, 
             const int seed_c = __builtin_amdgcn_readlane(seed, __ffsll((long long)__ballot(scan)) - 1);
 #pragma unroll 1
             for (int s4 = 0; s4 < 4; ++s4) scan_sub16(sv + seed_c * 64 + s4 * 16, px2, py2, pz2, t);
+            dbg_subs += 4; dbg_scans += 1;
 #pragma unroll 1
             for (int k = 1; (seed_c + k < ncl || seed_c - k >= 0) && !(dbg & 2); ++k) {
 #pragma unroll 1
@@ -412,11 +414,13 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w, 
                     const int c = side ? seed_c - k : seed_c + k;
                     if (c < 0 || c >= ncl) continue;
                     const bool need = scan && aabb_dist2(px, py, pz, lds_ld4(cl + c * 3), lds_ld4(cl + c * 3 + 1)) <= t.worst();
+                    dbg_tests += 1;
                     if (__ballot(need) == 0) continue;
 #pragma unroll 1
                     for (int s4 = 0; s4 < 4; ++s4) {
                         const bool need_s = need && aabb_dist2(px, py, pz, lds_ld4(sb + c * 8 + s4 * 2), lds_ld4(sb + c * 8 + s4 * 2 + 1)) <= t.worst();
                         if (__ballot(need_s) == 0) continue;
+                        dbg_subs += 1;
                         if (dbg & 32) scan_sub16<true>(sv + c * 64 + s4 * 16, px2, py2, pz2, t);
                         else scan_sub16(sv + c * 64 + s4 * 16, px2, py2, pz2, t);
                     }
@@ -430,6 +434,9 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w, 
                 res_nn[p] = make_int4(t.i[0], t.i[1], t.i[2], t.i[3]);
                 res_w[p] = make_float4(wt[0], wt[1], wt[2], wt[3]);
             }
+        }
+        if ((dbg & 64) && lane == 0) {
+            atomicAdd(&w.counters[13], dbg_subs); atomicAdd(&w.counters[14], dbg_tests); atomicAdd(&w.counters[15], dbg_scans);
         }
         // list append, aggregated per workgroup-tile: 5 global atomics per 1024 points instead of one
         // returned atomic per wave per part (whose contended latency dominated the kernel)

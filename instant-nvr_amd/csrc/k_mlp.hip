@@ -116,14 +116,12 @@ __device__ __forceinline__ float head_dot(const f32x4* h, const float* wv, int g
 }
 
 template <int NRGB>
-__global__ __launch_bounds__(MLP_BLOCK, 3) void k_part_mlp(PartMlpDev pm, const float* __restrict__ emb,
-                                                        const float* __restrict__ ds, int64_t stride,
-                                                        const int32_t* __restrict__ l_slot,
-                                                        const int32_t* __restrict__ count, int64_t cap,
-                                                        float4* __restrict__ raws, int part, float4* __restrict__ raw_direct) {
-    __shared__ float lds[LDS_FLOATS];
-    const int cnt = *count;
+__device__ __forceinline__ void mlp_part(float* lds, const PartMlpDev& pm, const float* __restrict__ emb,
+                                         const float* __restrict__ ds, int64_t stride, const int32_t* __restrict__ l_slot,
+                                         int cnt, int64_t cap, float4* __restrict__ raws, int part,
+                                         float4* __restrict__ raw_direct) {
     if ((int64_t)blockIdx.x * (MLP_BLOCK / 64) * MLP_CB * 16 >= cnt) return;
+    __syncthreads();                                   // previous part's weights no longer in use
     stage_weights<NRGB>(pm, lds);
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, col = lane & 15;
@@ -252,6 +250,52 @@ __global__ __launch_bounds__(MLP_BLOCK, 3) void k_part_mlp(PartMlpDev pm, const 
             }
         }
     }
+}
+
+
+template <int NRGB>
+__global__ __launch_bounds__(MLP_BLOCK, 3) void k_part_mlp(PartMlpDev pm, const float* __restrict__ emb,
+                                                        const float* __restrict__ ds, int64_t stride,
+                                                        const int32_t* __restrict__ l_slot,
+                                                        const int32_t* __restrict__ count, int64_t cap,
+                                                        float4* __restrict__ raws, int part, float4* __restrict__ raw_direct) {
+    __shared__ float lds[LDS_FLOATS];
+    mlp_part<NRGB>(lds, pm, emb, ds, stride, l_slot, *count, cap, raws, part, raw_direct);
+}
+
+// all five parts in one persistent launch (see k_part_encode_rs_all): the weights of the next part are staged
+// into the same LDS image when a workgroup has finished its share of the previous one
+__global__ __launch_bounds__(MLP_BLOCK, 3) void k_part_mlp_all(MlpAllArgs a) {
+    __shared__ float lds[LDS_FLOATS];
+    for (int p = 0; p < INVR_NUM_PARTS; ++p) {
+        if (a.pm[p].rgb.n_linear == 3)
+            mlp_part<3>(lds, a.pm[p], a.emb[p], a.ds[p], a.stride, a.l_slot[p], a.counts[p], a.cap, a.raws, p, nullptr);
+        else
+            mlp_part<2>(lds, a.pm[p], a.emb[p], a.ds[p], a.stride, a.l_slot[p], a.counts[p], a.cap, a.raws, p, nullptr);
+    }
+}
+
+static bool part_mlp_supported(const PartMlpDev& pm) {
+    const MlpDev& o = pm.occ;
+    const MlpDev& r = pm.rgb;
+    return o.n_linear == 2 && o.dims[0] == 19 && o.dims[1] == HID && o.dims[2] == 17 &&
+           (r.n_linear == 2 || r.n_linear == 3) && r.dims[0] == 70 && r.dims[1] == HID &&
+           r.dims[r.n_linear] == 3 && (r.n_linear == 2 || r.dims[2] == HID) &&
+           pm.n_freq == 4 && pm.latent_dim == 8 && pm.geo_dim == 16;
+}
+
+int launch_part_mlp_all(const MlpAllArgs& a, hipStream_t st) {
+    for (int p = 0; p < INVR_NUM_PARTS; ++p)
+        if (!part_mlp_supported(a.pm[p])) {
+            invr_set_error("part MLP kernel supports occ 19-64-17 and rgb 70-64(-64)-3 with 4 view-dir frequencies, latent 8, geo feature 16");
+            return 1;
+        }
+    const int64_t per_block = (MLP_BLOCK / 64) * MLP_CB * 16;
+    int64_t tiles = cdiv(a.cap, per_block);
+    unsigned grid = (unsigned)(tiles < 256 * 3 ? (tiles > 0 ? tiles : 1) : 256 * 3);
+    hipLaunchKernelGGL(k_part_mlp_all, dim3(grid), dim3(MLP_BLOCK), 0, st, a);
+    INVR_LAUNCH_CHECK();
+    return 0;
 }
 
 int launch_part_mlp(const PartMlpDev& pm, const float* emb, const float* d_soa, int64_t stride,

@@ -51,7 +51,7 @@ struct Workspace {
     float* l_x[INVR_NUM_PARTS];           // 3*cap : canonical (big-pose + residual) xyz, SoA
     float* l_d[INVR_NUM_PARTS];           // 3*cap : canonical view dir, SoA
     float* l_r[INVR_NUM_PARTS];           // 3*cap : residual deformation (resd), SoA
-    float* emb[2];                        // EMB_K*cap : encoder output, SoA [k][pair] (ping-pong)
+    float* emb[INVR_NUM_PARTS];           // EMB_K*cap each : encoder output of part p, SoA [k][pair]
     float4* raws;                         // cap*P : [rgb, occ] per (slot, part)
     float2* dslice;                       // DF_SLICE_MAX : per-frame t-slices of the deformer grid (k_warp.hip)
     int64_t cap;                          // max survivors
@@ -108,6 +108,14 @@ int launch_knn_pairs(const RenderArgs& a, const Workspace& w, hipStream_t st);
 int launch_warp_pairs(const RenderArgs& a, const Workspace& w, const GridDev& dg, const MlpDev& dm, hipStream_t st);
 int launch_part_encode(const GridDev& g, const float* x_soa, int64_t stride, const int32_t* count, int64_t cap,
                        float* emb, hipStream_t st);
+struct EncodeAllArgs {            // k_part_encode_rs_all: the five part grids of one render
+    GridDev g[INVR_NUM_PARTS];
+    const float* xs[INVR_NUM_PARTS];
+    float* emb[INVR_NUM_PARTS];
+    const int32_t* counts;        // counters + CNT_PAIRS
+    int64_t stride, cap;
+};
+int launch_part_encode_all(const EncodeAllArgs& a, hipStream_t st);
 struct PartMlpDev {
     MlpDev occ, rgb;
     const float* rgb_latent;
@@ -117,5 +125,15 @@ struct PartMlpDev {
 int launch_part_mlp(const PartMlpDev& pm, const float* emb, const float* d_soa, int64_t stride,
                     const int32_t* l_slot, const int32_t* count, int64_t cap, float4* raws, int part,
                     float4* raw_direct, hipStream_t st);
+struct MlpAllArgs {               // k_part_mlp_all
+    PartMlpDev pm[INVR_NUM_PARTS];
+    const float* emb[INVR_NUM_PARTS];
+    const float* ds[INVR_NUM_PARTS];
+    const int32_t* l_slot[INVR_NUM_PARTS];
+    const int32_t* counts;
+    int64_t stride, cap;
+    float4* raws;
+};
+int launch_part_mlp_all(const MlpAllArgs& a, hipStream_t st);
 int launch_merge_composite(const RenderArgs& a, const Workspace& w, float* rgb_map, float* acc_map, float* raw,
                            float* occ, float* weights, hipStream_t st);
