@@ -278,11 +278,24 @@ static int render_impl(const InvrScene* scene, const InvrModel* model,
     a.wpts = wpts; a.wdirs = wdirs;
     a.R = n_rays; a.S = n_samples; a.N = N;
 
+    // fork: KNN index build (k_part_prepare, 5 workgroups, ~60 us) on a side stream beside the cull kernels
+    static thread_local hipStream_t side = nullptr;
+    static thread_local hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    if (!side) {
+        INVR_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+        INVR_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        INVR_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    }
+    INVR_HIP(hipEventRecord(ev_fork, st));
+    INVR_HIP(hipStreamWaitEvent(side, ev_fork, 0));
+    if (launch_knn_prepare(a, w, side)) return 1;
+    INVR_HIP(hipEventRecord(ev_join, side));
     {
         ProfStage ps(INVR_STAGE_CULL, st);
         INVR_HIP(hipMemsetAsync(w.counters, 0, CNT_LEN * sizeof(int32_t), st));
         if (launch_cull(a, w, max_active, st)) return 1;
     }
+    INVR_HIP(hipStreamWaitEvent(st, ev_join, 0));        // join
     {
         ProfStage ps(INVR_STAGE_KNN, st);
         if (launch_knn_pairs(a, w, st)) return 1;

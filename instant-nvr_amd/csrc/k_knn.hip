@@ -488,9 +488,15 @@ __global__ void k_append_const_pairs(Workspace w) {
     if (p == 0) w.active_idx[w.cap] = 0;
 }
 
-int launch_knn_pairs(const RenderArgs& a, const Workspace& w, hipStream_t st) {
+// The per-frame KNN index only depends on the posed vertices, not on the rays: it is built on a side stream
+// beside the cull kernels (fork / join with events — also a valid pattern under hipGraph capture).
+int launch_knn_prepare(const RenderArgs& a, const Workspace& w, hipStream_t st) {
     hipLaunchKernelGGL(k_part_prepare, dim3(INVR_NUM_PARTS), dim3(PREP_T), 0, st, a.scene, w.knn);
     INVR_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_knn_pairs(const RenderArgs& a, const Workspace& w, hipStream_t st) {
     const size_t lds_bytes = (size_t)KNN_LDS_FLOAT4 * sizeof(float4);      // ~150 KB: one workgroup per CU
     static bool attr_set = false;
     if (!attr_set) {

@@ -104,6 +104,7 @@ __device__ __forceinline__ void sample_pose_point(const RenderArgs& a, int64_t i
 
 // ---- pipeline stage launchers ------------------------------------------------------------------
 int launch_cull(const RenderArgs& a, const Workspace& w, int64_t max_active, hipStream_t st);
+int launch_knn_prepare(const RenderArgs& a, const Workspace& w, hipStream_t st);
 int launch_knn_pairs(const RenderArgs& a, const Workspace& w, hipStream_t st);
 int launch_warp_pairs(const RenderArgs& a, const Workspace& w, const GridDev& dg, const MlpDev& dm, hipStream_t st);
 int launch_part_encode(const GridDev& g, const float* x_soa, int64_t stride, const int32_t* count, int64_t cap,
