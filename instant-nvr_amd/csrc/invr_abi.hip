@@ -196,6 +196,7 @@ static size_t carve(Workspace& w, void* base, int64_t N, int64_t cap) {
     for (int p = 0; p < INVR_NUM_PARTS; ++p) w.emb[p] = c.take<float>(lc * EMB_K);
     w.raws = c.take<float4>(lc * INVR_NUM_PARTS);
     w.dslice = c.take<float2>(DF_SLICE_MAX);
+    w.cullmask = c.take<uint8_t>(CULL_MASK_MAX);
     return align_up(c.off, 256);
 }
 

@@ -7,14 +7,66 @@
 //   k_compact     : rank = block offset + wave prefix + popcount(mask below lane) -> active list
 // The active list is in ray-major / sample-minor order, exactly the order torch.nonzero gives,
 // so the train-time (Na*P, .) layouts of resd/tpts/tocc keep the reference's row order.
+#include <stdlib.h>
 #include "pipeline.h"
 
 #define CULL_BLOCK 256
 #define CULL_PER 4                      // ray-samples per thread
 #define CULL_TILE (CULL_BLOCK * CULL_PER)
 
+// Per-frame cell mask of the distance volume: the trilinear value of a sample is a convex combination of the 8
+// corners of its cell (weights in [0,1], sum 1 within 4e-7), so a cell whose corners are all >= thresh*(1+1e-5)
+// cannot hold a survivor — 93 % of the samples of the bench frame then skip the 8 taps.  Cell (x0,y0,z0) pairs
+// with corner x1 = min(x0+1, dx-1) exactly as the border-clamped sampler does, so there are dx*dy*dz cells.
+__global__ void k_cull_cells(VolDev v, float thresh_hi, uint8_t* __restrict__ mask) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= v.dx * v.dy * v.dz) return;
+    const int z0 = i % v.dz, y0 = (i / v.dz) % v.dy, x0 = i / (v.dz * v.dy);
+    const int x1 = min(x0 + 1, v.dx - 1), y1 = min(y0 + 1, v.dy - 1), z1 = min(z0 + 1, v.dz - 1);
+    float m = __builtin_inff();
+    bool nan = false;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int xx = (k & 4) ? x1 : x0, yy = (k & 2) ? y1 : y0, zz = (k & 1) ? z1 : z0;
+        const float d = v.data[(((int64_t)xx * v.dy + yy) * v.dz + zz) * v.c + (v.c - 1)];
+        nan = nan || d != d;
+        m = fminf(m, d);
+    }
+    mask[i] = (m < thresh_hi || nan) ? 1 : 0;
+}
+
+// distance channel of the pose-space volume at (px,py,pz): sample_volume_dev<1> (same arithmetic, bit for bit)
+// with the cell-mask early-out; returns +inf for samples in masked-out cells (they fail pn < thresh either way)
+__device__ __forceinline__ float cull_distance(const VolDev& v, const uint8_t* __restrict__ mask, float px, float py, float pz) {
+    const float b0x = v.bounds[0], b0y = v.bounds[1], b0z = v.bounds[2];
+    const float b1x = v.bounds[3], b1y = v.bounds[4], b1z = v.bounds[5];
+    float gx = (px - b0x) / (b1x - b0x) * 2.0f - 1.0f;
+    float gy = (py - b0y) / (b1y - b0y) * 2.0f - 1.0f;
+    float gz = (pz - b0z) / (b1z - b0z) * 2.0f - 1.0f;
+    float ix = ((gx + 1.0f) * 0.5f) * (float)(v.dx - 1);
+    float iy = ((gy + 1.0f) * 0.5f) * (float)(v.dy - 1);
+    float iz = ((gz + 1.0f) * 0.5f) * (float)(v.dz - 1);
+    ix = fminf(fmaxf(ix, 0.0f), (float)(v.dx - 1));
+    iy = fminf(fmaxf(iy, 0.0f), (float)(v.dy - 1));
+    iz = fminf(fmaxf(iz, 0.0f), (float)(v.dz - 1));
+    const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+    const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+    if (!mask[((int64_t)x0 * v.dy + y0) * v.dz + z0]) return __builtin_inff();
+    const float tx = ix - fx, ty = iy - fy, tz = iz - fz;
+    const int x1 = min(x0 + 1, v.dx - 1), y1 = min(y0 + 1, v.dy - 1), z1 = min(z0 + 1, v.dz - 1);
+    float out = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int xx = (k & 4) ? x1 : x0, yy = (k & 2) ? y1 : y0, zz = (k & 1) ? z1 : z0;
+        const float wk = ((k & 4) ? tx : 1.0f - tx) * ((k & 2) ? ty : 1.0f - ty) * ((k & 1) ? tz : 1.0f - tz);
+        out = fmaf(wk, v.data[(((int64_t)xx * v.dy + yy) * v.dz + zz) * v.c + (v.c - 1)], out);
+    }
+    return out;
+}
+
 // tile of 1024 consecutive ray-samples per workgroup: sub-tile k holds samples base + k*256 + tid,
 // one 64-bit survivor mask per (sub-tile, wave): mask word index = tile*16 + k*4 + wave
+template <bool MASKED>
 __global__ __launch_bounds__(CULL_BLOCK) void k_cull_flag(RenderArgs a, Workspace w) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     __shared__ int cnt[CULL_PER * (CULL_BLOCK / 64)];
@@ -27,7 +79,8 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_cull_flag(RenderArgs a, Workspac
             sample_pose_point(a, i, px, py, pz, &z, nullptr);
             if (a.z_vals) a.z_vals[i] = z;
             float pn;
-            sample_volume_dev<1>(a.scene.pbw, a.scene.pbw.c - 1, px, py, pz, &pn);   // distance channel
+            if (MASKED) pn = cull_distance(a.scene.pbw, w.cullmask, px, py, pz);
+            else sample_volume_dev<1>(a.scene.pbw, a.scene.pbw.c - 1, px, py, pz, &pn);   // distance channel
             keep = pn < a.scene.thresh;                                               // :135
         }
         const unsigned long long m = __ballot(keep);
@@ -119,7 +172,16 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_compact(RenderArgs a, Workspace 
 
 int launch_cull(const RenderArgs& a, const Workspace& w, int64_t max_active, hipStream_t st) {
     int64_t nb = cdiv(a.N, CULL_TILE);
-    hipLaunchKernelGGL(k_cull_flag, dim3((unsigned)nb), dim3(CULL_BLOCK), 0, st, a, w);
+    const VolDev& v = a.scene.pbw;
+    const int64_t cells = (int64_t)v.dx * v.dy * v.dz;
+    static const bool no_mask = getenv("INVR_NO_CULLMASK") != nullptr;
+    if (cells <= CULL_MASK_MAX && a.N >= 4 * cells && !no_mask) {        // the mask pays for itself on full frames only
+        hipLaunchKernelGGL(k_cull_cells, dim3((unsigned)cdiv(cells, 256)), dim3(256), 0, st, v, a.scene.thresh * (1.0f + 1e-5f), w.cullmask);
+        INVR_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_cull_flag<true>, dim3((unsigned)nb), dim3(CULL_BLOCK), 0, st, a, w);
+    } else {
+        hipLaunchKernelGGL(k_cull_flag<false>, dim3((unsigned)nb), dim3(CULL_BLOCK), 0, st, a, w);
+    }
     INVR_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(SCAN_T), 0, st, w, nb, max_active);
     INVR_LAUNCH_CHECK();

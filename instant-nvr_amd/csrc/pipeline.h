@@ -4,6 +4,7 @@
 
 enum { CNT_ACTIVE = 0, CNT_PAIRS = 1 /* ..5 */, CNT_OVERFLOW = 6, CNT_FAR = 7 /* ..11 */, CNT_TICKET = 12, CNT_LEN = 16 };
 
+#define CULL_MASK_MAX (4 << 20)   // cells of the per-frame cull mask (bytes); larger distance volumes run unmasked
 #define DF_SLICE_MAX 4096  // float2 entries of the deformer's per-frame (u,v) slice tables (32 KB of LDS)
 #define EMB_K 20            // 19-d encoder output padded to 5 MFMA k-steps
 
@@ -53,6 +54,7 @@ struct Workspace {
     float* l_r[INVR_NUM_PARTS];           // 3*cap : residual deformation (resd), SoA
     float* emb[INVR_NUM_PARTS];           // EMB_K*cap each : encoder output of part p, SoA [k][pair]
     float4* raws;                         // cap*P : [rgb, occ] per (slot, part)
+    uint8_t* cullmask;                    // CULL_MASK_MAX : 1 if the trilinear cell can hold a survivor (k_cull.hip)
     float2* dslice;                       // DF_SLICE_MAX : per-frame t-slices of the deformer grid (k_warp.hip)
     int64_t cap;                          // max survivors
     int64_t lcap;                         // cap + 1: list / per-slot array capacity (stride of the SoA lists)
