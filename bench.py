@@ -12,8 +12,8 @@ ranks tile-cyclically, every rank renders its tiles with a full model replica an
 all-gather assembles [r,g,b,acc]; total work is fixed -> "scaling": "strong".
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     — the dominant kernel (k_part_encode, HBM-bound): algorithmic bytes
-                 (8192 B x flagged pairs) / its HIP-event time, vs 8.0 TB/s
+  roofline     — the dominant roofline-bound kernel (k_part_mlp_all, fp32 MFMA): algorithmic FLOPs
+                 (SURVEY.md §8d per pair) / its HIP-event time, vs 157.3 TFLOP/s; roofline_other: KNN, encoder
   cpu_baseline — the oracle (CPU PyTorch port of the reference path) timed on the host cores on a
                  bounded sample of the same workload (N=1 only)
 """
@@ -196,14 +196,20 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         value = total_samples * args.steps / dt
         pairs_local = int(stats[1:6].sum())
-        enc_ms = sum(stage_ms['encode_%d' % p] for p in range(5)) / max(n_prof, 1)
-        mlp_ms = sum(stage_ms['mlp_%d' % p] for p in range(5)) / max(n_prof, 1)
-        enc_bytes = pairs_local * (PAIR_TABLE_BYTES if args.full_rows else PAIR_TABLE_BYTES // 16)                   # per step, this rank's 5 encode launches
-        achieved = enc_bytes / (enc_ms * 1e-3) if enc_ms > 0 else 0.0
-        traffic = None
-        tf = os.path.join(ROOT, 'profiles', 'encode_traffic_bytes_per_step.json')
-        if os.path.exists(tf) and world == 1 and not args.dense and args.table_log2 is None and args.res == 512 and S == 128:
-            traffic = json.load(open(tf)).get('hbm_bytes_per_step')
+        per = max(n_prof, 1)
+        enc_ms = sum(stage_ms['encode_%d' % p] for p in range(5)) / per
+        mlp_ms = sum(stage_ms['mlp_%d' % p] for p in range(5)) / per
+        knn_ms = stage_ms['knn'] / per
+        enc_bytes = pairs_local * (PAIR_TABLE_BYTES if args.full_rows else PAIR_TABLE_BYTES // 16)   # 16 levels x 8 corners x 64 B | 4 B
+        mlp_flops = sum(int(stats[1 + p]) * (22144 if p in (0, 2) else 13952) for p in range(5))          # 2 x MACs, SURVEY 8(d)
+        knn_flops = int(stats[0]) * 62000                                                                # brute-force 4-NN of the reference, SURVEY 8(d)
+        # HBM bytes per launch from the PMC passes (profiles/, FETCH_SIZE+WRITE_SIZE with the guide's gfx950 correction)
+        traffic = {}
+        tf = os.path.join(ROOT, 'profiles', 'hbm_traffic_per_launch.json')
+        if os.path.exists(tf) and world == 1 and not args.dense and args.table_log2 is None and args.res == 512 and S == 128 \
+                and not args.full_rows and not args.shard_of:
+            traffic = json.load(open(tf))
+        tfl = lambda fl, ms: fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         line = {
             'metric': 'ray-samples/sec', 'value': value, 'unit': 'ray-samples/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
@@ -219,18 +225,32 @@ def main():
                 'parallelism': 'tile-cyclic ray shards x%d, full replicas, 1 all-gather/frame' % world,
                 'rays_per_sec': n_rays * args.steps / dt,
             },
+            # dominant roofline-bound kernel: the two tiny MLPs of all five parts on the fp32 matrix cores (one launch)
             'roofline': {
-                'kernel': 'k_part_encode (5 launches/step, hash-grid row gathers)', 'bound': 'hbm',
-                'achieved': achieved / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
-                'frac': achieved / HBM_PEAK, 'traffic': traffic,
-                'algorithmic_bytes_per_step': int(enc_bytes), 'kernel_ms_per_step': enc_ms,
-                'note': 'algorithmic = 8192 B x flagged (point,part) pairs on rank 0; frac vs 6.29 TB/s measured-copy peak = %.3f'
-                        % (achieved / 6.29e12),
+                'kernel': 'k_part_mlp_all (1 launch/step: occ + rgb MLPs of the 5 parts, v_mfma_f32_16x16x4_f32)', 'bound': 'mfma',
+                'achieved': tfl(mlp_flops, mlp_ms), 'peak': 157.3, 'unit': 'TFLOP/s', 'frac': tfl(mlp_flops, mlp_ms) / 157.3,
+                'traffic': traffic.get('k_part_mlp_all'),
+                'algorithmic_flops_per_launch': int(mlp_flops), 'kernel_ms_per_launch': mlp_ms,
+                'note': 'algorithmic = 22.1 kFLOP (body, head) / 14.0 kFLOP (leg, arms) per evaluated (point,part) pair on rank 0 '
+                        '(SURVEY 8d); fp32-in MFMA peak = fp32 vector peak on gfx950; HIP events on the launch stream',
             },
-            'stage_ms_per_step': {k: v / max(n_prof, 1) for k, v in stage_ms.items()},
-            'mlp': {'kernel_ms_per_step': mlp_ms,
-                    'tflops': (sum(int(stats[1 + p]) * (22144 if p in (0, 2) else 13952) for p in range(5)) / (mlp_ms * 1e-3) / 1e12)
-                    if mlp_ms > 0 else 0.0, 'peak_tflops_fp32_mfma': 157.3},
+            'roofline_other': [
+                {'kernel': 'k_knn_pairs (largest single kernel; exact per-part 4-NN, VALU + LDS, no HBM/MFMA roofline)',
+                 'bound': 'valu-fp32', 'achieved': tfl(knn_flops, knn_ms), 'peak': 157.3, 'unit': 'TFLOP/s',
+                 'frac': tfl(knn_flops, knn_ms) / 157.3, 'traffic': traffic.get('k_knn_pairs'), 'kernel_ms_per_launch': knn_ms,
+                 'note': 'algorithmic = the brute-force search the reference runs (6890 vertices x ~9 FLOP = 62 kFLOP per survivor, '
+                         'SURVEY 8d); the cluster-pruned search executes a fraction of it, hence a large algorithmic rate'},
+                {'kernel': 'k_part_encode_rs_all (hash-grid gathers through the eval-mode row-sum tables)' if not args.full_rows
+                           else 'k_part_encode (64-byte table rows)',
+                 'bound': 'hbm', 'achieved': enc_bytes / (enc_ms * 1e-3) / 1e9 if enc_ms > 0 else 0.0, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
+                 'frac': (enc_bytes / (enc_ms * 1e-3) / HBM_PEAK) if enc_ms > 0 else 0.0,
+                 'traffic': traffic.get('k_part_encode_rs_all'), 'algorithmic_bytes_per_launch': int(enc_bytes),
+                 'kernel_ms_per_launch': enc_ms,
+                 'note': '512 B (16 levels x 8 corners x 4 B row sums) per pair; the 68 MB of row-sum tables are L2 / Infinity-Cache '
+                         'resident, the kernel is bound by index math + L1 line rate, not by HBM' if not args.full_rows
+                         else '8192 B (16 levels x 8 corners x 64 B rows) per pair'},
+            ],
+            'stage_ms_per_step': {k: v / per for k, v in stage_ms.items()},
         }
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(net, cfg, batch_cpu, min(args.cpu_rays, n_rays), S)
