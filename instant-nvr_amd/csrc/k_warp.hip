@@ -42,11 +42,18 @@ __device__ __forceinline__ void inverse3x3(const Mat34& M, float* inv) {
     inv[6] = m02 / den;  inv[7] = -m12 / den; inv[8] = m22 / den;
 }
 
+__device__ __forceinline__ void warp_with_mats(const Mat34& Aw, const Mat34& Bw, const float* pp, const float* pd, float* xb, float* db);
+
 __device__ __forceinline__ void warp_point(const float* __restrict__ A, const float* __restrict__ big_A, const float* bw,
                                            const float* pp, const float* pd, float* xb, float* db) {
     Mat34 Aw, Bw;
     blend_mats(A, bw, Aw);
     blend_mats(big_A, bw, Bw);
+    warp_with_mats(Aw, Bw, pp, pd, xb, db);
+}
+
+// canonical big-pose point / direction from the blended pose matrix Aw and big-pose matrix Bw
+__device__ __forceinline__ void warp_with_mats(const Mat34& Aw, const Mat34& Bw, const float* pp, const float* pd, float* xb, float* db) {
     float inv[9];
     inverse3x3(Aw, inv);
     const float x0 = pp[0] - Aw.m[3], x1 = pp[1] - Aw.m[7], x2 = pp[2] - Aw.m[11];
@@ -137,31 +144,64 @@ int launch_warp_deform_dense(const SceneDev& s, const GridDev& dg, const MlpDev&
 // Two kernels so that neither carries the other's live state (LBS: 24 blend weights + two 3x4
 // matrices; deformer: 19 features + two 32-wide hidden layers): each fits well under 128 VGPRs and
 // runs at >= 4 waves/SIMD instead of the 2 waves/SIMD (256 VGPRs) of the fused form.
-__global__ __launch_bounds__(WARP_BLOCK) void k_warp_pairs(RenderArgs a, Workspace w, const float* __restrict__ A,
+// Per-vertex pre-blended matrices (built once per frame, k_vertex_mats): bw @ A with bw = sum_k w_k pbw[nn_k]
+// is linear in the skinning rows, so  A_bw = sum_k w_k M_A[nn_k]  with  M_A[v] = sum_j pbw[v][j] A_j  (and the same
+// for big_A).  A pair then needs 4 x 96 B gathers and 96 FMAs instead of 4 x 96 B gathers, the 24-wide blend and
+// 576 FMAs against 576 scalar matrix entries (which the compiler could only keep by spilling SGPRs into VGPR
+// lanes: 2.2 k v_readlane / v_writelane per pair made the old kernel VALU-bound at 0.32 ms).
+#define VMAT_BLOCK 128
+__global__ __launch_bounds__(VMAT_BLOCK) void k_vertex_mats(SceneDev s, KnnIndex ix, const float* __restrict__ A,
                                                            const float* __restrict__ big_A) {
+    const int p = blockIdx.y, v = blockIdx.x * VMAT_BLOCK + threadIdx.x;
+    if (v >= s.M || v >= ix.mpad) return;          // padding rows behind lengths2[p] are zeros in part_pbw: kept finite
+    const float* __restrict__ row = s.part_pbw + ((int64_t)p * s.M + v) * INVR_NUM_JOINTS;
+    float b[INVR_NUM_JOINTS];
+#pragma unroll
+    for (int j = 0; j < INVR_NUM_JOINTS; ++j) b[j] = row[j];
+    Mat34 Ma, Mb;
+    blend_mats(A, b, Ma);
+    blend_mats(big_A, b, Mb);
+    float4* o = ix.vmat + ((int64_t)p * ix.mpad + v) * 6;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        o[r] = make_float4(Ma.m[r * 4], Ma.m[r * 4 + 1], Ma.m[r * 4 + 2], Ma.m[r * 4 + 3]);
+        o[3 + r] = make_float4(Mb.m[r * 4], Mb.m[r * 4 + 1], Mb.m[r * 4 + 2], Mb.m[r * 4 + 3]);
+    }
+}
+
+int launch_vertex_mats(const RenderArgs& a, const Workspace& w, hipStream_t st) {
+    const int m = a.scene.M < w.knn.mpad ? a.scene.M : w.knn.mpad;
+    hipLaunchKernelGGL(k_vertex_mats, dim3((unsigned)cdiv(m, VMAT_BLOCK), INVR_NUM_PARTS), dim3(VMAT_BLOCK), 0, st, a.scene, w.knn,
+                       a.scene.A, a.scene.big_A);
+    INVR_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ __launch_bounds__(WARP_BLOCK) void k_warp_pairs(RenderArgs a, Workspace w) {
     const int p = blockIdx.y;
     const int cnt = w.counters[CNT_PAIRS + p];
-    const float* __restrict__ pb = a.scene.part_pbw + (int64_t)p * a.scene.M * INVR_NUM_JOINTS;
+    const float4* __restrict__ vm = w.knn.vmat + (int64_t)p * w.knn.mpad * 6;
     for (int64_t i = (int64_t)blockIdx.x * WARP_BLOCK + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * WARP_BLOCK) {
         const int slot = w.l_slot[p][i];
         const int4 nn = reinterpret_cast<const int4*>(w.l_nn[p])[i];
         const float4 wt = reinterpret_cast<const float4*>(w.l_w[p])[i];
-        float b[INVR_NUM_JOINTS];
-        const float4* r0 = reinterpret_cast<const float4*>(pb + (int64_t)nn.x * INVR_NUM_JOINTS);
-        const float4* r1 = reinterpret_cast<const float4*>(pb + (int64_t)nn.y * INVR_NUM_JOINTS);
-        const float4* r2 = reinterpret_cast<const float4*>(pb + (int64_t)nn.z * INVR_NUM_JOINTS);
-        const float4* r3 = reinterpret_cast<const float4*>(pb + (int64_t)nn.w * INVR_NUM_JOINTS);
+        const float4* r0 = vm + (int64_t)nn.x * 6;
+        const float4* r1 = vm + (int64_t)nn.y * 6;
+        const float4* r2 = vm + (int64_t)nn.z * 6;
+        const float4* r3 = vm + (int64_t)nn.w * 6;
+        Mat34 Aw, Bw;
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
-            float4 v0 = r0[j], v1 = r1[j], v2 = r2[j], v3 = r3[j];
-            b[j * 4 + 0] = v0.x * wt.x + v1.x * wt.y + v2.x * wt.z + v3.x * wt.w;     // einsum('ijkl,ijk->ijl')
-            b[j * 4 + 1] = v0.y * wt.x + v1.y * wt.y + v2.y * wt.z + v3.y * wt.w;
-            b[j * 4 + 2] = v0.z * wt.x + v1.z * wt.y + v2.z * wt.z + v3.z * wt.w;
-            b[j * 4 + 3] = v0.w * wt.x + v1.w * wt.y + v2.w * wt.z + v3.w * wt.w;
+            const float4 v0 = r0[j], v1 = r1[j], v2 = r2[j], v3 = r3[j];
+            float* o = j < 3 ? Aw.m + j * 4 : Bw.m + (j - 3) * 4;
+            o[0] = fmaf(wt.w, v3.x, fmaf(wt.z, v2.x, fmaf(wt.y, v1.x, wt.x * v0.x)));
+            o[1] = fmaf(wt.w, v3.y, fmaf(wt.z, v2.y, fmaf(wt.y, v1.y, wt.x * v0.y)));
+            o[2] = fmaf(wt.w, v3.z, fmaf(wt.z, v2.z, fmaf(wt.y, v1.z, wt.x * v0.z)));
+            o[3] = fmaf(wt.w, v3.w, fmaf(wt.z, v2.w, fmaf(wt.y, v1.w, wt.x * v0.w)));
         }
         float pp[3], pd[3], xb[3], db[3];
         sample_pose_point(a, w.active_idx[slot], pp[0], pp[1], pp[2], nullptr, pd);
-        warp_point(A, big_A, b, pp, pd, xb, db);
+        warp_with_mats(Aw, Bw, pp, pd, xb, db);
         if (!a.scene.tpose_viewdir) {                       // cfg.tpose_viewdir False: world view dir
             int64_t ray = w.active_idx[slot] / a.S;
             const float* vd = a.wpts ? a.wdirs : a.ray_d;
@@ -548,7 +588,7 @@ __global__ __launch_bounds__(DF_BLOCK) void k_deform_pairs_slice(RenderArgs a, W
 int launch_warp_pairs(const RenderArgs& a, const Workspace& w, const GridDev& dg, const MlpDev& dm, hipStream_t st) {
     int64_t tiles = cdiv(w.lcap, WARP_BLOCK);
     unsigned gx = (unsigned)(tiles < 1024 ? (tiles > 0 ? tiles : 1) : 1024);
-    hipLaunchKernelGGL(k_warp_pairs, dim3(gx, INVR_NUM_PARTS), dim3(WARP_BLOCK), 0, st, a, w, a.scene.A, a.scene.big_A);
+    hipLaunchKernelGGL(k_warp_pairs, dim3(gx, INVR_NUM_PARTS), dim3(WARP_BLOCK), 0, st, a, w);
     INVR_LAUNCH_CHECK();
     int64_t dtiles = cdiv(w.lcap, DF_BLOCK);
     unsigned dgx = (unsigned)(dtiles < 512 ? (dtiles > 0 ? dtiles : 1) : 512);
