@@ -11,6 +11,7 @@
 // summed with two quad-DPP adds, level results are staged per wave in LDS ([k][64 points]) and
 // flushed as coalesced 256-byte rows into the SoA embedding buffer the MLP kernel consumes.
 // Two points are processed per iteration to keep 16 row fetches in flight per wave.
+#include <stdlib.h>
 #include "pipeline.h"
 #include "grid_generic.h"
 
@@ -459,6 +460,42 @@ int launch_part_encode_bwd(const GridDev& g, const float* xyz, const float* gout
 // pairs of the list (consecutive samples of a ray), so on the dense levels neighbouring lanes fall into the
 // same / adjacent 64-byte lines; the level constants are wave-uniform (scalar registers).
 #define RS_BLOCK 256
+// one level of one point through the row-sum table (wave-uniform level l)
+__device__ __forceinline__ float level_rowsum(const GridDev& g, const float* __restrict__ rs, int hstart, int l, float x, float y, float z) {
+    const int res = g.res[l];
+    const float cell = g.cell[l];
+    int c0x, c1x, c0y, c1y, c0z, c1z;
+    float tx, ty, tz;
+    level_corners(x, cell, res, c0x, c1x, tx);
+    level_corners(y, cell, res, c0y, c1y, ty);
+    level_corners(z, cell, res, c0z, c1z, tz);
+    unsigned row[8];
+    const float* tab;
+    if (l >= g.start_hash) {
+        tab = rs + g.dense_rows + (int64_t)(l - hstart) * g.T;
+        const uint64_t hx[2] = {(uint64_t)(uint32_t)c0x, (uint64_t)(uint32_t)c1x};
+        const uint64_t hy[2] = {(uint64_t)(uint32_t)c0y * HASH_P1, (uint64_t)(uint32_t)c1y * HASH_P1};
+        const uint64_t hz[2] = {(uint64_t)(uint32_t)c0z * HASH_P2, (uint64_t)(uint32_t)c1z * HASH_P2};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) row[k] = grid_hash_mod(hx[k >> 2] ^ hy[(k >> 1) & 1] ^ hz[k & 1], g);
+    } else {
+        tab = g.separate_dense ? rs + g.dense_off[l] : rs + (int64_t)l * g.T;
+        const unsigned ures = (unsigned)res;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            row[k] = ((unsigned)((k & 4) ? c1x : c0x) * ures + (unsigned)((k & 2) ? c1y : c0y)) * ures + (unsigned)((k & 1) ? c1z : c0z);
+    }
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = tab[row[k]];
+    const float ux = 1.0f - tx, uy = 1.0f - ty, uz = 1.0f - tz;
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)     // weight_k = prod_axis ((1-o) + (2o-1) t)  (:157-158)
+        acc = fmaf(((k & 4) ? tx : ux) * ((k & 2) ? ty : uy) * ((k & 1) ? tz : uz), v[k], acc);
+    return acc;
+}
+
 __device__ __forceinline__ void encode_rs_part(const GridDev& g, const float* __restrict__ rs, const float* __restrict__ xs,
                                                int64_t stride, int cnt, int64_t cap, float* __restrict__ emb) {
     const float b0x = g.bounds[0], b0y = g.bounds[1], b0z = g.bounds[2];
@@ -469,40 +506,7 @@ __device__ __forceinline__ void encode_rs_part(const GridDev& g, const float* __
         emb[i] = x; emb[cap + i] = y; emb[2 * cap + i] = z;
         emb[(int64_t)(EMB_K - 1) * cap + i] = 0.0f;                 // pad column
 #pragma unroll 2
-        for (int l = 0; l < 16; ++l) {
-            const int res = g.res[l];
-            const float cell = g.cell[l];
-            int c0x, c1x, c0y, c1y, c0z, c1z;
-            float tx, ty, tz;
-            level_corners(x, cell, res, c0x, c1x, tx);
-            level_corners(y, cell, res, c0y, c1y, ty);
-            level_corners(z, cell, res, c0z, c1z, tz);
-            unsigned row[8];
-            const float* tab;
-            if (l >= g.start_hash) {
-                tab = rs + g.dense_rows + (int64_t)(l - hstart) * g.T;
-                const uint64_t hx[2] = {(uint64_t)(uint32_t)c0x, (uint64_t)(uint32_t)c1x};
-                const uint64_t hy[2] = {(uint64_t)(uint32_t)c0y * HASH_P1, (uint64_t)(uint32_t)c1y * HASH_P1};
-                const uint64_t hz[2] = {(uint64_t)(uint32_t)c0z * HASH_P2, (uint64_t)(uint32_t)c1z * HASH_P2};
-#pragma unroll
-                for (int k = 0; k < 8; ++k) row[k] = grid_hash_mod(hx[k >> 2] ^ hy[(k >> 1) & 1] ^ hz[k & 1], g);
-            } else {
-                tab = g.separate_dense ? rs + g.dense_off[l] : rs + (int64_t)l * g.T;
-                const unsigned ures = (unsigned)res;
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    row[k] = ((unsigned)((k & 4) ? c1x : c0x) * ures + (unsigned)((k & 2) ? c1y : c0y)) * ures + (unsigned)((k & 1) ? c1z : c0z);
-            }
-            float v[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = tab[row[k]];
-            const float ux = 1.0f - tx, uy = 1.0f - ty, uz = 1.0f - tz;
-            float acc = 0.0f;
-#pragma unroll
-            for (int k = 0; k < 8; ++k)     // weight_k = prod_axis ((1-o) + (2o-1) t)  (:157-158)
-                acc = fmaf(((k & 4) ? tx : ux) * ((k & 2) ? ty : uy) * ((k & 1) ? tz : uz), v[k], acc);
-            emb[(int64_t)(3 + l) * cap + i] = acc;
-        }
+        for (int l = 0; l < 16; ++l) emb[(int64_t)(3 + l) * cap + i] = level_rowsum(g, rs, hstart, l, x, y, z);
     }
 }
 
@@ -518,6 +522,34 @@ __global__ __launch_bounds__(RS_BLOCK) void k_part_encode_rs(GridDev g, const fl
 __global__ __launch_bounds__(RS_BLOCK) void k_part_encode_rs_all(EncodeAllArgs a) {
     for (int p = 0; p < INVR_NUM_PARTS; ++p)
         encode_rs_part(a.g[p], a.g[p].row_sums, a.xs[p], a.stride, a.counts[p], a.cap, a.emb[p]);
+}
+
+// XCD-partitioned variant: workgroups are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8), each with
+// its own 4 MB L2.  Level group lg = blockIdx.x & 7 handles levels {lg, 15 - lg} (rotated per part so that the
+// heavier hashed pairs do not always land on the same XCD) of EVERY pair tile: an XCD's L2 then only ever sees one
+// eighth of the row-sum tables (8.5 MB of 68 MB) instead of all of them.
+__global__ __launch_bounds__(RS_BLOCK) void k_part_encode_rs_xcd(EncodeAllArgs a) {
+    const int xcd = blockIdx.x & 7;
+    const int64_t tile0 = blockIdx.x >> 3, tstride = gridDim.x >> 3;
+    for (int p = 0; p < INVR_NUM_PARTS; ++p) {
+        const GridDev& g = a.g[p];
+        const float* __restrict__ rs = g.row_sums;
+        const float* __restrict__ xs = a.xs[p];
+        float* __restrict__ emb = a.emb[p];
+        const int cnt = a.counts[p];
+        const int lg = (xcd + 3 * p) & 7;
+        const int la = lg, lb = 15 - lg;
+        const float b0x = g.bounds[0], b0y = g.bounds[1], b0z = g.bounds[2];
+        const float ex = g.bounds[3] - b0x, ey = g.bounds[4] - b0y, ez = g.bounds[5] - b0z;
+        const int hstart = g.separate_dense ? g.start_hash : 0;
+        for (int64_t i = tile0 * RS_BLOCK + threadIdx.x; i < cnt; i += tstride * RS_BLOCK) {
+            const float x = (xs[i] - b0x) / ex, y = (xs[a.stride + i] - b0y) / ey, z = (xs[2 * a.stride + i] - b0z) / ez;   // :112
+            if (lg < 3) emb[(int64_t)lg * a.cap + i] = lg == 0 ? x : (lg == 1 ? y : z);
+            else if (lg == 3) emb[(int64_t)(EMB_K - 1) * a.cap + i] = 0.0f;          // pad column
+            emb[(int64_t)(3 + la) * a.cap + i] = level_rowsum(g, rs, hstart, la, x, y, z);
+            emb[(int64_t)(3 + lb) * a.cap + i] = level_rowsum(g, rs, hstart, lb, x, y, z);
+        }
+    }
 }
 
 // one quad per table row: 4 x float4 of a 16-feature row (or F/4 lanes for narrower rows), pairwise sums
@@ -563,7 +595,13 @@ int launch_part_encode_all(const EncodeAllArgs& a, hipStream_t st) {
     }
     int64_t tiles = cdiv(a.cap, RS_BLOCK);
     unsigned grid = (unsigned)(tiles < 256 * 8 ? (tiles > 0 ? tiles : 1) : 256 * 8);
-    hipLaunchKernelGGL(k_part_encode_rs_all, dim3(grid), dim3(RS_BLOCK), 0, st, a);
+    static const int xcd_mode = getenv("INVR_ENC_XCD") ? atoi(getenv("INVR_ENC_XCD")) : 1;
+    if (xcd_mode) {
+        unsigned gx = (unsigned)(tiles * 8 < 256 * 8 ? (tiles > 0 ? tiles * 8 : 8) : 256 * 8);      // a multiple of 8
+        hipLaunchKernelGGL(k_part_encode_rs_xcd, dim3(gx), dim3(RS_BLOCK), 0, st, a);
+    } else {
+        hipLaunchKernelGGL(k_part_encode_rs_all, dim3(grid), dim3(RS_BLOCK), 0, st, a);
+    }
     INVR_LAUNCH_CHECK();
     return 0;
 }
