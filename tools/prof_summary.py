@@ -1,0 +1,55 @@
+"""Markdown summary of one scratch/prof_all.sh result directory (gpurun_out/<tag>): bench line, rocprofv3
+--kernel-trace --stats table, per-kernel PMC averages and derived utilisations; also writes
+profiles/hbm_traffic_per_launch.json (FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, bytes per launch).
+usage: python tools/prof_summary.py gpurun_out/r1f profiles/r1f_kernel_stats_and_pmc.md "<title>" """
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+R, dst, title = sys.argv[1], sys.argv[2], sys.argv[3]
+out = ['# ' + title + '\n']
+out.append('Commands (MI355X box, `bash scratch/prof_all.sh <tag>`): `python bench.py --steps 20 --warmup 5` (default flags, hipGraph replay), then\n'
+           '`rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu-baseline --no-graph --steps 10 --warmup 3`, then one\n'
+           '`rocprofv3 --kernel-trace --pmc <group> --output-format csv` run per counter group (`--steps 2 --warmup 1`; eager launches).\n')
+out.append('## bench.py (default flags) JSON line\n```\n' + open(R + '/bench.json').read().strip() + '\n```\n')
+rows = list(csv.DictReader(open(R + '/trace/trace_kernel_stats.csv')))
+short = lambda n: n.replace('void ', '').split('(')[0][:80]
+out.append('## kernel-trace stats (16 renders = 3 warm-up + 10 timed + 3 stage-profile frames)\n| kernel | calls | total_ms | avg_us | min_us | max_us | pct |\n|---|---|---|---|---|---|---|')
+for r in rows[:24]:
+    out.append('| %s | %s | %.3f | %.1f | %.1f | %.1f | %s |' % (short(r['Name']), r['Calls'], float(r['TotalDurationNs']) / 1e6, float(r['AverageNs']) / 1e3,
+                                                              float(r['MinNs']) / 1e3, float(r['MaxNs']) / 1e3, r['Percentage']))
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(R + '/*/*_counter_collection.csv'):
+    for r in csv.DictReader(open(f)):
+        agg[short(r['Kernel_Name'])][r['Counter_Name']].append(float(r['Counter_Value']))
+keys = sorted({c for k in agg for c in agg[k]})
+sel = sorted(k for k in agg if k.startswith('k_'))
+out.append('\n## PMC, average per dispatch (FETCH_SIZE/WRITE_SIZE in KiB as reported; GRBM_GUI_ACTIVE is summed over the 8 XCDs)\n| kernel | dispatches | '
+           + ' | '.join(keys) + ' |\n|---|---|' + '---|' * len(keys))
+for k in sel:
+    n = max(len(v) for v in agg[k].values())
+    out.append('| %s | %d | ' % (k, n) + ' | '.join(('%.4g' % (sum(agg[k][c]) / len(agg[k][c]))) if c in agg[k] else '-' for c in keys) + ' |')
+avg = lambda k, c: sum(agg[k][c]) / len(agg[k][c]) if c in agg[k] else float('nan')
+dur = {short(r['Name']): float(r['AverageNs']) / 1e3 for r in rows}
+out.append('\n## Derived (per launch)\nVALU busy = SQ_ACTIVE_INST_VALU x 4 (quad-cycles) / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8); MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / 1024 / (GRBM_GUI_ACTIVE / 8).\n\n'
+           '| kernel | avg_us | HBM/Infinity-Cache read GB (FETCH_SIZE x2, guide gfx950 correction) | write GB | L2 hit % | VALU busy % | MFMA busy % | WAIT_INST_ANY % of wave cycles | VALU instr. per wave |\n|---|---|---|---|---|---|---|---|---|')
+traffic = {}
+for k in sel:
+    fetch = avg(k, 'FETCH_SIZE') * 1024 * 2 / 1e9
+    wr = avg(k, 'WRITE_SIZE') * 1024 / 1e9
+    hit, miss = avg(k, 'TCC_HIT_sum'), avg(k, 'TCC_MISS_sum')
+    gui = avg(k, 'GRBM_GUI_ACTIVE') / 8
+    valu = avg(k, 'SQ_ACTIVE_INST_VALU') * 4 / 1024 / gui * 100 if gui == gui and gui > 0 else float('nan')
+    mfma = avg(k, 'SQ_VALU_MFMA_BUSY_CYCLES') / 1024 / gui * 100 if gui == gui and gui > 0 else float('nan')
+    wait = avg(k, 'SQ_WAIT_INST_ANY') / avg(k, 'SQ_WAVE_CYCLES') * 100
+    out.append('| %s | %.1f | %.3f | %.3f | %.0f | %.0f | %.0f | %.0f | %.0f |' % (k, dur.get(k, float('nan')), fetch, wr, 100 * hit / (hit + miss) if hit + miss > 0 else float('nan'),
+                                                                         valu, mfma, wait, avg(k, 'SQ_INSTS_VALU') / avg(k, 'SQ_WAVES')))
+    t = (avg(k, 'FETCH_SIZE') * 2 + avg(k, 'WRITE_SIZE')) * 1024
+    if t == t:
+        traffic[k] = int(t)
+open(dst, 'w').write('\n'.join(out) + '\n')
+json.dump(traffic, open(os.path.join(os.path.dirname(dst), 'hbm_traffic_per_launch.json'), 'w'), indent=1)
+print('\n'.join(out[-20:]))
