@@ -260,6 +260,23 @@ int invr_generate_rays(const double* k_inv, const double* R, const double* T, co
 int64_t invr_grid_row_sums_len(const InvrGrid* grid);
 int invr_grid_row_sums(const InvrGrid* grid, float* out, void* stream);
 
+/* Dense Adam step over many tensors in ONE launch (the optimiser of the reference's training loop:
+ * lib/train/optimizer.py:13-31 -> torch.optim.Adam, one parameter group per tensor, amsgrad off).
+ * `tensors` is a DEVICE array; chunk c covers elements [chunk_index[c]*E, (chunk_index[c]+1)*E) of tensor
+ * chunk_tensor[c] with E = invr_adam_chunk_elems(); both chunk tables are DEVICE int32 arrays.  bc1 / bc2_sqrt
+ * are the bias corrections 1-beta1^step and sqrt(1-beta2^step) of the tensor's own step count. */
+typedef struct InvrAdamTensor {
+    float* param;               /* dev, updated in place */
+    const float* grad;          /* dev */
+    float* exp_avg;             /* dev, updated in place */
+    float* exp_avg_sq;          /* dev, updated in place */
+    int64_t numel;
+    float lr, weight_decay, bc1, bc2_sqrt;
+} InvrAdamTensor;
+int32_t invr_adam_chunk_elems(void);
+int invr_adam_step(const InvrAdamTensor* tensors, const int32_t* chunk_tensor, const int32_t* chunk_index,
+                   int64_t n_chunks, float beta1, float beta2, float eps, void* stream);
+
 /* batch_rodrigues + get_rigid_transformation (lib/utils/if_nerf/if_nerf_data_utils.py:523-577): DEVICE inputs
  * poses (24,3) float64 axis-angle, joints (24,3) float64, parents (24) int32 -> DEVICE A (24,4,4) float32. */
 int invr_rigid_transformation(const double* poses, const double* joints, const int32_t* parents, float* A, void* stream);

@@ -1,0 +1,54 @@
+// Row f1: the optimiser step of the training loop — torch.optim.Adam over every trainable tensor
+// (lib/train/optimizer.py:13-31: one parameter group per tensor, eps = cfg.train.eps = 1e-15).  torch's foreach
+// implementation cannot batch across parameter groups: ~8 element-wise launches per tensor x 186 tensors = 1.5 k
+// launches and 7 ms per step for the 286 M parameters of inb_377.  This is ONE launch: a flat list of 64 k-element
+// chunks over all tensors (chunk -> tensor table built once by the host), single pass over param / grad / exp_avg /
+// exp_avg_sq = 28 B per parameter, the HBM floor of a dense Adam step.
+// Arithmetic of torch/optim/adam.py (_single_tensor_adam, amsgrad=False, maximize=False):
+//   g += wd * p ; m = lerp(m, g, 1-b1) ; v = b2*v + (1-b2) g*g ; p -= (lr / bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+#include "common.h"
+
+#define ADAM_BLOCK 256
+#define ADAM_CHUNK 16384            // elements per workgroup
+
+struct AdamTensor {                 // device-resident table, one entry per tensor that has a gradient this step
+    float* p; const float* g; float* m; float* v;
+    int64_t n;
+    float lr, wd, bc1, bc2_sqrt;    // bias corrections 1-b1^step and sqrt(1-b2^step) of THIS tensor's step count
+};
+
+__global__ __launch_bounds__(ADAM_BLOCK) void k_adam(const AdamTensor* __restrict__ tensors, const int32_t* __restrict__ chunk_tensor,
+                                                     const int32_t* __restrict__ chunk_index, float b1, float b2, float eps) {
+    const AdamTensor t = tensors[chunk_tensor[blockIdx.x]];
+    const int64_t base = (int64_t)chunk_index[blockIdx.x] * ADAM_CHUNK;
+    const int64_t end = min(base + ADAM_CHUNK, t.n);
+    const float w1 = 1.0f - b1, w2 = 1.0f - b2, step_size = t.lr / t.bc1;
+    auto upd = [&](float& p, float g, float& m, float& v) {
+        if (t.wd != 0.0f) g = fmaf(t.wd, p, g);
+        m = m + w1 * (g - m);                                     // torch.lerp, weight < 0.5
+        v = fmaf(w2 * g, g, b2 * v);                               // mul_(b2).addcmul_(g, g, value=1-b2)
+        const float denom = sqrtf(v) / t.bc2_sqrt + eps;
+        p = p - step_size * (m / denom);                           // addcdiv_(m, denom, value=-step_size)
+    };
+    const bool vec = ((((uintptr_t)t.p | (uintptr_t)t.g | (uintptr_t)t.m | (uintptr_t)t.v) & 15) == 0);
+    if (vec) {
+        for (int64_t i = base + (int64_t)threadIdx.x * 4; i + 3 < end; i += ADAM_BLOCK * 4) {
+            float4 p = *reinterpret_cast<float4*>(t.p + i), m = *reinterpret_cast<float4*>(t.m + i), v = *reinterpret_cast<float4*>(t.v + i);
+            const float4 g = *reinterpret_cast<const float4*>(t.g + i);
+            upd(p.x, g.x, m.x, v.x); upd(p.y, g.y, m.y, v.y); upd(p.z, g.z, m.z, v.z); upd(p.w, g.w, m.w, v.w);
+            *reinterpret_cast<float4*>(t.p + i) = p; *reinterpret_cast<float4*>(t.m + i) = m; *reinterpret_cast<float4*>(t.v + i) = v;
+        }
+        for (int64_t i = base + ((end - base) & ~(int64_t)3) + threadIdx.x; i < end; i += ADAM_BLOCK) upd(t.p[i], t.g[i], t.m[i], t.v[i]);
+    } else {
+        for (int64_t i = base + threadIdx.x; i < end; i += ADAM_BLOCK) upd(t.p[i], t.g[i], t.m[i], t.v[i]);
+    }
+}
+
+int launch_adam(const void* tensors, const int32_t* chunk_tensor, const int32_t* chunk_index, int64_t n_chunks, float b1, float b2,
+                float eps, hipStream_t st) {
+    if (n_chunks == 0) return 0;
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)n_chunks), dim3(ADAM_BLOCK), 0, st, reinterpret_cast<const AdamTensor*>(tensors), chunk_tensor,
+                       chunk_index, b1, b2, eps);
+    INVR_LAUNCH_CHECK();
+    return 0;
+}

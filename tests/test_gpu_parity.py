@@ -502,3 +502,39 @@ def test_pair_deformer_matches_point_deformer(gpu_setup):
         assert float(r_pairs.abs().max()) <= 0.05 and float(r_pairs.abs().max()) > 1e-4
         n_checked += c
     assert n_checked > 1000
+
+
+def test_fused_adam_matches_torch_adam():
+    """Row f1: invr_adam_step (one launch for all tensors) vs torch.optim.Adam with the reference's construction
+    (one parameter group per tensor, eps 1e-15), including tensors that get no gradient in some steps, per-group
+    learning-rate changes (the reference's schedulers write group['lr']) and state_dict interchange."""
+    from invr.optim import FusedAdam
+    g = torch.Generator().manual_seed(11)
+    shapes = [(3,), (64, 70), (17,), (5, 4099, 16), (100000,), (1,), (33, 7)]
+    ref_p = [torch.randn(s, generator=g).to(DEV).requires_grad_() for s in shapes]
+    my_p = [p.detach().clone().requires_grad_() for p in ref_p]
+    mk = lambda ps: [{'params': [p], 'lr': 5e-4, 'weight_decay': 0.0} for p in ps]
+    ref = torch.optim.Adam(mk(ref_p), 5e-4, eps=1e-15)
+    mine = FusedAdam(mk(my_p), 5e-4, eps=1e-15)
+    for it in range(6):
+        for k, (a, b) in enumerate(zip(ref_p, my_p)):
+            if (it + k) % 4 == 3:                       # no gradient for this tensor in this step
+                a.grad = b.grad = None
+                continue
+            gr = torch.randn(a.shape, generator=g).to(DEV) * (10.0 ** ((k % 3) - 2))
+            a.grad, b.grad = gr.clone(), gr.clone()
+        if it == 3:
+            for opt in (ref, mine):
+                for grp in opt.param_groups:
+                    grp['lr'] *= 0.5
+        ref.step()
+        mine.step()
+    for a, b in zip(ref_p, my_p):
+        assert maxerr(a, b) <= 2e-6 * float(a.abs().max()) + 1e-9
+    sa, sb = ref.state_dict(), mine.state_dict()
+    assert sa['param_groups'][0].keys() >= {'lr', 'betas', 'eps', 'weight_decay'} and len(sa['state']) == len(sb['state'])
+    for k in sa['state']:
+        assert float(sa['state'][k]['step']) == float(sb['state'][k]['step'])
+        assert maxerr(sa['state'][k]['exp_avg'], sb['state'][k]['exp_avg']) <= 1e-6 * float(sa['state'][k]['exp_avg'].abs().max()) + 1e-12
+    ref2 = torch.optim.Adam(mk([p.detach().clone().requires_grad_() for p in my_p]), 5e-4, eps=1e-15)
+    ref2.load_state_dict(mine.state_dict())             # checkpoints interchange
