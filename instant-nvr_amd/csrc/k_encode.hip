@@ -335,7 +335,7 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_part_encode(GridDev g, const floa
 #define BWD_SMALL_FLOATS 6144
 
 __global__ __launch_bounds__(ENC_BLOCK) void k_part_encode_bwd(GridDev g, const float* __restrict__ xyz,
-                                                               const float* __restrict__ gout, int64_t n,
+                                                               const float* __restrict__ gout, int64_t n, int tp, int dbg,
                                                                float* g_dense, float* g_hash, float* __restrict__ g_xyz) {
     __shared__ float sgo[ENC_WAVES][64][20];          // g_out tile of the wave
     __shared__ float sgx[ENC_WAVES][64][3];           // per point: gradient w.r.t. the normalised coordinate
@@ -364,12 +364,26 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_part_encode_bwd(GridDev g, const 
     const float b0x = g.bounds[0], b0y = g.bounds[1], b0z = g.bounds[2];
     const float ex = g.bounds[3] - b0x, ey = g.bounds[4] - b0y, ez = g.bounds[5] - b0z;
 
-    for (int64_t tile = (int64_t)blockIdx.x * ENC_WAVES + wv; tile * 64 < n; tile += (int64_t)gridDim.x * ENC_WAVES) {
-        const int64_t base = tile * 64;
-        const int m = (int)min((int64_t)64, n - base);
+    // a wave walks the tp (<= 64) points of its tile one after the other (all 64 lanes on one point): a training
+    // patch has only ~3e4 pairs per part, so the tile shrinks until the grid fills the GPU
+    for (int64_t tile = (int64_t)blockIdx.x * ENC_WAVES + wv; tile * tp < n; tile += (int64_t)gridDim.x * ENC_WAVES) {
+        const int64_t base = tile * tp;
+        const int m = (int)min((int64_t)tp, n - base);
         const int64_t pi = base + min(lane, m - 1);
         const float xi = (xyz[pi * 3] - b0x) / ex, yi = (xyz[pi * 3 + 1] - b0y) / ey, zi = (xyz[pi * 3 + 2] - b0z) / ez;
         for (int e = lane; e < m * 19; e += 64) sgo[wv][e / 19][e % 19] = gout[base * 19 + e];      // coalesced tile copy
+        // run-length combining: consecutive pairs of the list are consecutive samples of a ray / neighbouring rays and
+        // fall into the same cell of the coarse and middle levels, where a 64x64 training patch puts 1e4..1e5
+        // contributions on a few dozen rows — their same-address global atomics serialised the kernel (0.6 ms per
+        // part).  Each lane keeps the pending (row, sum) of its 8 corners and only issues an atomic when the row changes.
+        unsigned prow[8];
+        float pval[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { prow[k] = 0xFFFFFFFFu; pval[k] = 0.0f; }
+        auto flush = [&](unsigned r, float vsum) {
+            if (small_off >= 0) { if (!(dbg & 2)) atomicAdd(&ssmall[small_off + r], vsum); }
+            else if (!(dbg & 1)) unsafeAtomicAdd(gtb + (size_t)r * 16, vsum);                 // column 0 = row scalar
+        };
         for (int j = 0; j < m; ++j) {
             const float x = rdlane(xi, j), y = rdlane(yi, j), z = rdlane(zi, j);
             int c0, c1;
@@ -400,7 +414,7 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_part_encode_bwd(GridDev g, const 
             const float gl = sgo[wv][j][3 + level];
             float4 v[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = L.tab[(size_t)row[k] * 4];
+            for (int k = 0; k < 8; ++k) v[k] = (dbg & 4) ? make_float4(1.f, 2.f, 3.f, 4.f) : L.tab[(size_t)row[k] * 4];
             float gtx = 0.f, gty = 0.f, gtz = 0.f;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -411,8 +425,12 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_part_encode_bwd(GridDev g, const 
                 gtz += ((k & 1) ? 1.0f : -1.0f) * wx * wy * S;
                 if (q == 0) {
                     const float val = (wx * wy * wz) * gl;
-                    if (small_off >= 0) atomicAdd(&ssmall[small_off + row[k]], val);
-                    else unsafeAtomicAdd(gtb + (size_t)row[k] * 16, val);               // column 0 = row scalar
+                    if (row[k] == prow[k]) pval[k] += val;
+                    else {
+                        if (prow[k] != 0xFFFFFFFFu) flush(prow[k], pval[k]);
+                        prow[k] = row[k];
+                        pval[k] = val;
+                    }
                 }
             }
             // d out / d x_norm of this level, then summed over the 16 levels (lanes 4 apart)
@@ -420,6 +438,11 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_part_encode_bwd(GridDev g, const 
 #pragma unroll
             for (int d = 4; d < 64; d <<= 1) { ax += __shfl_xor(ax, d); ay += __shfl_xor(ay, d); az += __shfl_xor(az, d); }
             if (lane == 0) { sgx[wv][j][0] = ax; sgx[wv][j][1] = ay; sgx[wv][j][2] = az; }
+        }
+        if (q == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (prow[k] != 0xFFFFFFFFu) flush(prow[k], pval[k]);
         }
         if (g_xyz && lane < m) {
             g_xyz[(base + lane) * 3 + 0] = (sgx[wv][lane][0] + sgo[wv][lane][0]) / ex;
@@ -445,9 +468,12 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_part_encode_bwd(GridDev g, const 
 
 int launch_part_encode_bwd(const GridDev& g, const float* xyz, const float* gout, int64_t n, float* g_dense, float* g_hash,
                            float* g_xyz, hipStream_t st) {
-    int64_t tiles = cdiv(n, 64 * ENC_WAVES);
-    unsigned grid = (unsigned)(tiles < 1024 ? (tiles > 0 ? tiles : 1) : 1024);
-    hipLaunchKernelGGL(k_part_encode_bwd, dim3(grid), dim3(ENC_BLOCK), 0, st, g, xyz, gout, n, g_dense, g_hash, g_xyz);
+    int tp = 64;
+    while (tp > 16 && n / tp < 4096) tp >>= 1;                // enough waves to fill the GPU, long enough runs to combine
+    int64_t tiles = cdiv(n, (int64_t)tp * ENC_WAVES);
+    unsigned grid = (unsigned)(tiles < 2048 ? (tiles > 0 ? tiles : 1) : 2048);
+    static int dbg = getenv("INVR_BWD_DBG") ? atoi(getenv("INVR_BWD_DBG")) : 0;
+    hipLaunchKernelGGL(k_part_encode_bwd, dim3(grid), dim3(ENC_BLOCK), 0, st, g, xyz, gout, n, tp, dbg, g_dense, g_hash, g_xyz);
     INVR_LAUNCH_CHECK();
     return 0;
 }
