@@ -260,6 +260,31 @@ int invr_generate_rays(const double* k_inv, const double* R, const double* T, co
 int64_t invr_grid_row_sums_len(const InvrGrid* grid);
 int invr_grid_row_sums(const InvrGrid* grid, float* out, void* stream);
 
+/* Training path of the two part MLPs (part_base_network.py:44-63 after the encoder) on SoA inputs:
+ * emb_soa (20,n) = the 19 encoder outputs as rows (row 19 = 0), dirs_soa (3,n) canonical view directions.
+ * fwd: raw (n,4) = [sigmoid rgb, occ]; count_dev = DEVICE int32 holding n.
+ * bwd: recomputes the forward, propagates g_raw (n,4) to the embedding and writes, per layer, the pre-activation
+ * gradients g_z and the layer inputs as row-major (n,dim) matrices — the weight gradients are dW = g_z^T a_in, the bias
+ * gradients the column sums of g_z (K = n reductions, done by the caller's GEMMs).  x_k is the rgb layer-1 input in
+ * the kernel's k-slot order (column 4 s + g, s = 0..17, g = 0..3; see rgb1_col in csrc/mlp_common.h). */
+typedef struct InvrMlpBwdOut {
+    float* g_emb;     /* (20,n) rows 0..18 written */
+    float* go;        /* (n,3)  d/d rgb pre-activation */
+    float* gz_last;   /* (n,64) last hidden rgb layer */
+    float* gz_r1;     /* (n,64) rgb layer 1, 3-linear colour nets only (else NULL) */
+    float* g_out2;    /* (n,17) [logit, 16 features] of occ layer 2 */
+    float* gz_h1;     /* (n,64) occ hidden layer */
+    float* a_last;    /* (n,64) input of the rgb head */
+    float* a_r1;      /* (n,64) input of rgb layer 2 (3-linear nets only) */
+    float* a_h1;      /* (n,64) input of occ layer 2 */
+    float* x_k;       /* (n,72) input of rgb layer 1, k-slot order */
+    float* g_latent;  /* (8) accumulated (caller pre-zeroes) */
+} InvrMlpBwdOut;
+int invr_part_mlp_fwd(const InvrModel* model, int32_t pid, const int64_t* latent_index, const float* emb_soa,
+                      const float* dirs_soa, int64_t n, const int32_t* count_dev, float* raw, void* stream);
+int invr_part_mlp_bwd(const InvrModel* model, int32_t pid, const int64_t* latent_index, const float* emb_soa,
+                      const float* dirs_soa, int64_t n, const float* g_raw, const InvrMlpBwdOut* out, void* stream);
+
 /* Dense Adam step over many tensors in ONE launch (the optimiser of the reference's training loop:
  * lib/train/optimizer.py:13-31 -> torch.optim.Adam, one parameter group per tensor, amsgrad off).
  * `tensors` is a DEVICE array; chunk c covers elements [chunk_index[c]*E, (chunk_index[c]+1)*E) of tensor

@@ -29,6 +29,10 @@ class InvrGrid(C.Structure):
                 ('row_sums', C.c_void_p)]
 
 
+class InvrMlpBwdOut(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ('g_emb', 'go', 'gz_last', 'gz_r1', 'g_out2', 'gz_h1', 'a_last', 'a_r1', 'a_h1', 'x_k', 'g_latent')]
+
+
 class InvrAdamTensor(C.Structure):
     _fields_ = [('param', C.c_void_p), ('grad', C.c_void_p), ('exp_avg', C.c_void_p), ('exp_avg_sq', C.c_void_p),
                 ('numel', C.c_int64), ('lr', C.c_float), ('weight_decay', C.c_float), ('bc1', C.c_float), ('bc2_sqrt', C.c_float)]
@@ -72,7 +76,7 @@ EXPORTS = ['invr_last_error', 'invr_version', 'invr_sizeof', 'invr_workspace_byt
            'invr_profile_enable', 'invr_profile_read', 'invr_workspace_layout', 'invr_deform_fwd',
            'invr_distortion_fwd', 'invr_grid_encode_bwd', 'invr_composite_bwd',
            'invr_field_workspace_bytes', 'invr_field_fwd', 'invr_geometry_fwd', 'invr_generate_rays',
-           'invr_rigid_transformation', 'invr_pack_parts', 'invr_grid_row_sums_len', 'invr_grid_row_sums', 'invr_adam_chunk_elems', 'invr_adam_step']
+           'invr_rigid_transformation', 'invr_pack_parts', 'invr_grid_row_sums_len', 'invr_grid_row_sums', 'invr_adam_chunk_elems', 'invr_adam_step', 'invr_part_mlp_fwd', 'invr_part_mlp_bwd']
 NUM_STAGES = 14
 STAGE_NAMES = ['cull', 'knn', 'warp'] + ['encode_%d' % p for p in range(5)] + ['mlp_%d' % p for p in range(5)] + ['composite']
 
@@ -124,6 +128,10 @@ def lib():
         L.invr_grid_row_sums_len.restype = C.c_int64
         L.invr_grid_row_sums.argtypes = [vp, vp, vp]
         L.invr_grid_row_sums.restype = C.c_int
+        L.invr_part_mlp_fwd.argtypes = [C.POINTER(InvrModel), C.c_int32, vp, vp, vp, C.c_int64, vp, vp, vp]
+        L.invr_part_mlp_fwd.restype = C.c_int
+        L.invr_part_mlp_bwd.argtypes = [C.POINTER(InvrModel), C.c_int32, vp, vp, vp, C.c_int64, vp, C.POINTER(InvrMlpBwdOut), vp]
+        L.invr_part_mlp_bwd.restype = C.c_int
         L.invr_adam_chunk_elems.restype = C.c_int32
         L.invr_adam_step.argtypes = [vp, vp, vp, C.c_int64, C.c_float, C.c_float, C.c_float, vp]
         L.invr_adam_step.restype = C.c_int

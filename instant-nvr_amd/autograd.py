@@ -148,13 +148,112 @@ def deform(net, batch, pts):
     return 0.05 * torch.tanh(linear(dfm.mlp[4], h))
 
 
-def part_field(pn, tpts, tdirs, latent_index, n_freq):
-    """part_base_network.Network.forward (:44-63) with gradients."""
+def _splitk(gy, x):
+    """gy (n,out), x (n,in) -> gy^T x (out,in) as a slab-batched GEMM (see LinearFn)."""
+    n = x.shape[0]
+    main = (n // _SPLIT_ROWS) * _SPLIT_ROWS
+    gw = None
+    if main:
+        gw = torch.bmm(gy[:main].view(-1, _SPLIT_ROWS, gy.shape[1]).transpose(1, 2), x[:main].view(-1, _SPLIT_ROWS, x.shape[1])).sum(0)
+    if main < n:
+        tail = gy[main:].t() @ x[main:]
+        gw = tail if gw is None else gw + tail
+    return gw
+
+
+def _rgb1_col(s, g):
+    """csrc/mlp_common.h rgb1_col: input column of rgb layer 1 held by k-slot (s, g); -1 = padding."""
+    if s < 5:
+        e = 4 * s + g
+        return e if e < 19 else -1
+    if s < 11:
+        u = s - 5
+        return 19 + 3 + g * 6 + (u & 1) * 3 + (u >> 1)
+    if s < 14:
+        e = 4 * (s - 11) + g
+        return 19 + e if e < 3 else (62 + (e - 3) if e < 11 else -1)
+    return 46 + 4 * g + (s - 14)
+
+
+_SLOT_OF_COL = [0] * 70
+for _s in range(18):
+    for _g in range(4):
+        if _rgb1_col(_s, _g) >= 0:
+            _SLOT_OF_COL[_rgb1_col(_s, _g)] = 4 * _s + _g
+
+
+class PartMlpFn(torch.autograd.Function):
+    """The two MLPs of one part (part_base_network.py:44-63 after the encoder) on the matrix cores in both directions:
+    invr_part_mlp_fwd / invr_part_mlp_bwd.  The backward kernel recomputes the forward, returns the embedding gradient
+    and the per-layer (g_z, a_in) matrices; the K = n weight-gradient reductions are slab-batched GEMMs here."""
+
+    @staticmethod
+    def forward(ctx, emb, dirs, model, pid, latent_index, rgb_latent, *params):
+        n = emb.shape[0]
+        dev = emb.device
+        emb_soa = torch.zeros(20, n, device=dev)
+        emb_soa[:19] = emb.detach().t()
+        dirs_soa = dirs.detach().t().contiguous()
+        raw = torch.empty(n, 4, device=dev)
+        cnt = torch.full((1,), n, dtype=torch.int32, device=dev)
+        li = latent_index.reshape(-1)[:1].to(torch.int64).contiguous()
+        _abi.check(_abi.lib().invr_part_mlp_fwd(C.byref(model), pid, _abi.ptr(li, torch.int64), _abi.ptr(emb_soa), _abi.ptr(dirs_soa), n,
+                                                _abi.ptr(cnt, torch.int32), _abi.ptr(raw), _abi.stream_ptr()))
+        ctx.save_for_backward(emb_soa, dirs_soa, li, rgb_latent)
+        ctx.model, ctx.pid, ctx.n_rgb = model, pid, (len(params) - 4) // 2
+        return raw
+
+    @staticmethod
+    def backward(ctx, g_raw):
+        emb_soa, dirs_soa, li, rgb_latent = ctx.saved_tensors
+        n, dev, three = emb_soa.shape[1], emb_soa.device, ctx.n_rgb == 3
+        E = lambda *sh: torch.empty(*sh, device=dev)
+        o = dict(g_emb=E(20, n), go=E(n, 3), gz_last=E(n, 64), g_out2=E(n, 17), gz_h1=E(n, 64), a_last=E(n, 64), a_h1=E(n, 64),
+                 x_k=E(n, 72), g_latent=torch.zeros(8, device=dev), gz_r1=E(n, 64) if three else None, a_r1=E(n, 64) if three else None)
+        out = _abi.InvrMlpBwdOut()
+        for k, v in o.items():
+            setattr(out, k, None if v is None else v.data_ptr())
+        g_raw = g_raw.to(torch.float32).contiguous()
+        _abi.check(_abi.lib().invr_part_mlp_bwd(C.byref(ctx.model), ctx.pid, _abi.ptr(li, torch.int64), _abi.ptr(emb_soa), _abi.ptr(dirs_soa),
+                                                n, _abi.ptr(g_raw), C.byref(out), _abi.stream_ptr()))
+        g_emb = o['g_emb'][:19].t()
+        emb = emb_soa[:19].t()
+        col = torch.as_tensor(_SLOT_OF_COL, device=dev)
+        # parameter order: occ W0 b0 W1 b1, rgb W0 b0 [W1 b1] Wout bout
+        grads = [_splitk(o['gz_h1'], emb), o['gz_h1'].sum(0), _splitk(o['g_out2'], o['a_h1']), o['g_out2'].sum(0)]
+        gz_first = o['gz_r1'] if three else o['gz_last']
+        grads += [_splitk(gz_first, o['x_k'])[:, col], gz_first.sum(0)]
+        if three:
+            grads += [_splitk(o['gz_last'], o['a_r1']), o['gz_last'].sum(0)]
+        grads += [_splitk(o['go'], o['a_last']), o['go'].sum(0)]
+        g_lat = torch.zeros_like(rgb_latent)
+        g_lat[li[0]] = o['g_latent']
+        return (g_emb, None, None, None, None, g_lat) + tuple(grads)
+
+
+def part_field_hip(pn, tpts, tdirs, latent_index, model, pid):
+    """part_field with the MLPs on the HIP forward / backward kernels."""
     e = pn.embedder
     emb = GridEncodeFn.apply(tpts, e.dense if e.separate_dense else None, e.hash, e.bounds, e.spec)
+    params = []
+    for mlp in (pn.occ, pn.rgb):
+        for l in mlp.linears:
+            params += [l.weight, l.bias]
+    return PartMlpFn.apply(emb, tdirs, model, pid, latent_index, pn.rgb_latent, *params)
+
+
+def part_field(pn, tpts, tdirs, latent_index, n_freq):
+    """part_base_network.Network.forward (:44-63) with gradients (torch MLPs; the reference path of the tests)."""
+    e = pn.embedder
+    emb = GridEncodeFn.apply(tpts, e.dense if e.separate_dense else None, e.hash, e.bounds, e.spec)
+    return part_mlps_torch(pn, emb, tdirs, latent_index, n_freq)
+
+
+def part_mlps_torch(pn, emb, tdirs, latent_index, n_freq):
+    """The two MLPs of a part on an embedding (n,19), torch ops (part_base_network.py:50-63)."""
     h = mlp_forward(pn.occ, emb)
     occ = 1 - torch.exp(-F.softplus(h[..., :1]))
-    lat = pn.rgb_latent[latent_index.reshape(-1)[0]][None].expand(tpts.shape[0], -1)
+    lat = pn.rgb_latent[latent_index.reshape(-1)[0]][None].expand(emb.shape[0], -1)
     x = torch.cat([emb, dir_encode(tdirs, n_freq), h[..., 1:], lat], -1)
     rgb = torch.sigmoid(mlp_forward(pn.rgb, x))
     return torch.cat([rgb, occ], -1)
@@ -187,6 +286,10 @@ def render_train(net, batch, geo, views, stats, n_rays, S, pair_noise):
     resd_all = deform(net, batch, torch.cat(xb, 0))
     resd_p = torch.split(resd_all, cnts, 0)
     far = views['farflags'][:Na].to(torch.int32)
+    hip_mlp = cfg.get('train_hip_mlp', True)
+    if hip_mlp:
+        keep_model = []
+        model = _abi.make_model({k: v for k, v in net.named_parameters()}, cfg, keep_model)
     raws_flat = torch.zeros((Na + 1) * P, 4, device=dev)
     resd_flat = torch.zeros((Na + 1) * P, 3, device=dev)
     tpts_flat = torch.zeros((Na + 1) * P, 3, device=dev)
@@ -195,7 +298,8 @@ def render_train(net, batch, geo, views, stats, n_rays, S, pair_noise):
             continue
         pn = net.tpose_human.part_networks[p]
         tpose = xb[p] + resd_p[p]                                                        # :111
-        raw = part_field(pn, tpose, dirs[p], batch['latent_index'], n_freq)
+        raw = (part_field_hip(pn, tpose, dirs[p], batch['latent_index'], model, p) if hip_mlp
+               else part_field(pn, tpose, dirs[p], batch['latent_index'], n_freq))
         flat = rows[p] * P + p
         raws_flat = raws_flat.index_copy(0, flat, raw)
         resd_flat = resd_flat.index_copy(0, flat, resd_p[p])

@@ -74,6 +74,7 @@ DEFAULTS = {
     'pair_loss_weight': 10.0,
     'reg_dist_weight': 0.1,
     'resd_loss_weight': 0.1,
+    'train_hip_mlp': True,   # training: part MLPs forward + backward on the HIP kernels (False: torch ops, autograd.part_field)
     'eval_row_sums': True,   # eval-mode renders read the part grids through derived row-sum tables (invr_grid_row_sums)
     'use_lpips': False,      # the reference yaml sets True (VGG19 from torchvision); absent on this image
     'network': {'occ': {'d_hidden': 64, 'n_layers': 1}},

@@ -533,3 +533,29 @@ extern "C" int invr_adam_step(const InvrAdamTensor* tensors, const int32_t* chun
     INVR_CHECK(n_chunks >= 0 && n_chunks < (1ll << 31), "invr_adam_step: bad chunk count");
     return launch_adam(tensors, chunk_tensor, chunk_index, n_chunks, beta1, beta2, eps, (hipStream_t)stream);
 }
+
+extern "C" int invr_part_mlp_fwd(const InvrModel* model, int32_t pid, const int64_t* latent_index, const float* emb_soa,
+                                 const float* dirs_soa, int64_t n, const int32_t* count_dev, float* raw, void* stream) {
+    INVR_CHECK(model && latent_index && pid >= 0 && pid < INVR_NUM_PARTS, "invr_part_mlp_fwd: bad model/pid");
+    if (n == 0) return 0;
+    INVR_CHECK(emb_soa && dirs_soa && count_dev && raw, "invr_part_mlp_fwd: null pointer");
+    PartMlpDev pm = make_part_mlp(model, pid, latent_index);
+    return launch_part_mlp(pm, emb_soa, dirs_soa, n, nullptr, count_dev, n, nullptr, pid, reinterpret_cast<float4*>(raw), (hipStream_t)stream);
+}
+
+extern "C" int invr_part_mlp_bwd(const InvrModel* model, int32_t pid, const int64_t* latent_index, const float* emb_soa,
+                                 const float* dirs_soa, int64_t n, const float* g_raw, const InvrMlpBwdOut* out, void* stream) {
+    INVR_CHECK(model && latent_index && pid >= 0 && pid < INVR_NUM_PARTS && out, "invr_part_mlp_bwd: bad model/pid/out");
+    if (n == 0) return 0;
+    PartMlpDev pm = make_part_mlp(model, pid, latent_index);
+    const bool three = pm.rgb.n_linear == 3;
+    INVR_CHECK(emb_soa && dirs_soa && g_raw && out->g_emb && out->go && out->gz_last && out->g_out2 && out->gz_h1 && out->a_last &&
+               out->a_h1 && out->x_k && out->g_latent && (!three || (out->gz_r1 && out->a_r1)), "invr_part_mlp_bwd: null pointer");
+    const MlpDev& oc = pm.occ;
+    const MlpDev& r = pm.rgb;
+    INVR_CHECK(oc.n_linear == 2 && oc.dims[0] == 19 && oc.dims[1] == 64 && oc.dims[2] == 17 && (r.n_linear == 2 || r.n_linear == 3) &&
+               r.dims[0] == 70 && r.dims[1] == 64 && r.dims[r.n_linear] == 3 && pm.n_freq == 4 && pm.latent_dim == 8 && pm.geo_dim == 16,
+               "invr_part_mlp_bwd: supports occ 19-64-17 and rgb 70-64(-64)-3");
+    MlpBwdOut o{out->g_emb, out->go, out->gz_last, out->gz_r1, out->g_out2, out->gz_h1, out->a_last, out->a_r1, out->a_h1, out->x_k, out->g_latent};
+    return launch_part_mlp_bwd(pm, emb_soa, dirs_soa, n, g_raw, o, (hipStream_t)stream);
+}

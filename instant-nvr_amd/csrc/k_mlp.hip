@@ -17,103 +17,7 @@
 #include <stdlib.h>
 #include "pipeline.h"
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-#define MLP_BLOCK 256
-#define MLP_CB 2                 // 16-pair column blocks per wave iteration
-#define HID 64
-#define EMB_STEPS 5              // 20 / 4
-#define RGB1_STEPS 18            // 72 / 4
-
-// LDS carve (floats)
-#define O_W_OCC1 0                                   // 5*4*64
-#define O_B_OCC1 (O_W_OCC1 + EMB_STEPS * 4 * 64)     // 64
-#define O_W_OCC2 (O_B_OCC1 + 64)                     // 16*64   (feature rows 1..16)
-#define O_B_OCC2 (O_W_OCC2 + 16 * 64)                // 16
-#define O_V_OCC (O_B_OCC2 + 16)                      // 4*16    (row 0, slot order) + bias
-#define O_W_RGB1 (O_V_OCC + 64 + 4)                  // 18*4*64
-#define O_B_RGB1 (O_W_RGB1 + RGB1_STEPS * 4 * 64)    // 64
-#define O_W_RGB2 (O_B_RGB1 + 64)                     // 16*4*64
-#define O_B_RGB2 (O_W_RGB2 + 16 * 4 * 64)            // 64
-#define O_V_OUT (O_B_RGB2 + 64)                      // 3*4*16 + 3(+1)
-#define LDS_FLOATS (O_V_OUT + 3 * 64 + 4)
-
-// source column of rgb layer-1 for k-slot (step s, lane group g); -1 = zero padding.
-// rgb input = [emb 0..18 | dirPE 19..45 | feat 46..61 | latent 62..69] (part_base_network.py:57)
-// dirPE = [d, sin(2^0 d), cos(2^0 d), sin(2^1 d), ...] (freq_embedder.py:20-31)
-__device__ __forceinline__ int rgb1_col(int s, int g) {
-    if (s < 5) { int e = 4 * s + g; return e < 19 ? e : -1; }
-    if (s < 11) { int u = s - 5, comp = u >> 1, fn = u & 1; return 19 + 3 + g * 6 + fn * 3 + comp; }
-    if (s < 14) { int e = 4 * (s - 11) + g; return e < 3 ? 19 + e : (e < 11 ? 62 + (e - 3) : -1); }
-    return 46 + 4 * g + (s - 14);
-}
-// hidden unit held by lane group g for k-step s of a 64-wide hidden layer
-__device__ __forceinline__ int hid_col(int s, int g) { return 16 * (s >> 2) + 4 * g + (s & 3); }
-
-template <int NRGB>   // number of rgb linears: 2 (70-64-3) or 3 (70-64-64-3)
-__device__ void stage_weights(const PartMlpDev& pm, float* lds) {
-    const float* W0 = pm.occ.w[0]; const float* W1 = pm.occ.w[1];
-    const float* R0 = pm.rgb.w[0]; const float* R1 = pm.rgb.w[1]; const float* R2 = pm.rgb.w[NRGB - 1];
-    for (int t = threadIdx.x; t < EMB_STEPS * 4 * 64; t += MLP_BLOCK) {
-        int ln = t & 63, mt = (t >> 6) & 3, s = t >> 8, g = ln >> 4, i = ln & 15;
-        int col = 4 * s + g;
-        lds[O_W_OCC1 + t] = col < 19 ? W0[(16 * mt + i) * 19 + col] : 0.0f;
-    }
-    for (int t = threadIdx.x; t < 16 * 64; t += MLP_BLOCK) {
-        int ln = t & 63, s = t >> 6, g = ln >> 4, i = ln & 15;
-        lds[O_W_OCC2 + t] = W1[(1 + i) * HID + hid_col(s, g)];
-    }
-    for (int t = threadIdx.x; t < RGB1_STEPS * 4 * 64; t += MLP_BLOCK) {
-        int ln = t & 63, mt = (t >> 6) & 3, s = t >> 8, g = ln >> 4, i = ln & 15;
-        int col = rgb1_col(s, g);
-        lds[O_W_RGB1 + t] = col >= 0 ? R0[(16 * mt + i) * 70 + col] : 0.0f;
-    }
-    if (NRGB == 3)
-        for (int t = threadIdx.x; t < 16 * 4 * 64; t += MLP_BLOCK) {
-            int ln = t & 63, mt = (t >> 6) & 3, s = t >> 8, g = ln >> 4, i = ln & 15;
-            lds[O_W_RGB2 + t] = R1[(16 * mt + i) * HID + hid_col(s, g)];
-        }
-    for (int t = threadIdx.x; t < 64; t += MLP_BLOCK) {
-        lds[O_B_OCC1 + t] = pm.occ.b[0][t];
-        lds[O_B_RGB1 + t] = pm.rgb.b[0][t];
-        if (NRGB == 3) lds[O_B_RGB2 + t] = pm.rgb.b[1][t];
-        int g = t >> 4, u = t & 15;                              // slot order: [g][mt*4+r]
-        int hc = 16 * (u >> 2) + 4 * g + (u & 3);
-        lds[O_V_OCC + t] = W1[hc];                               // occ logit row 0
-#pragma unroll
-        for (int c = 0; c < 3; ++c) lds[O_V_OUT + c * 64 + t] = R2[c * HID + hc];
-    }
-    if (threadIdx.x < 16) lds[O_B_OCC2 + threadIdx.x] = pm.occ.b[1][1 + threadIdx.x];
-    if (threadIdx.x == 0) {
-        lds[O_V_OCC + 64] = pm.occ.b[1][0];
-        for (int c = 0; c < 3; ++c) lds[O_V_OUT + 3 * 64 + c] = pm.rgb.b[NRGB - 1][c];
-    }
-}
-
-__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
-__device__ __forceinline__ f32x4 softplus4(f32x4 v) {
-    f32x4 r;
-    r[0] = softplus_f(v[0]); r[1] = softplus_f(v[1]); r[2] = softplus_f(v[2]); r[3] = softplus_f(v[3]);
-    return r;
-}
-__device__ __forceinline__ f32x4 bias4(const float* b, int mt, int g) {
-    const float* p = b + 16 * mt + 4 * g;
-    f32x4 r; r[0] = p[0]; r[1] = p[1]; r[2] = p[2]; r[3] = p[3];
-    return r;
-}
-// dot of the 16 hidden values this lane holds with slot-ordered head weights, summed over the 4 lane groups
-__device__ __forceinline__ float head_dot(const f32x4* h, const float* wv, int g) {
-    float acc = 0.0f;
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc = fmaf(wv[g * 16 + mt * 4 + r], h[mt][r], acc);
-    acc += __shfl_xor(acc, 16);
-    acc += __shfl_xor(acc, 32);
-    return acc;
-}
+#include "mlp_common.h"
 
 template <int NRGB>
 __device__ __forceinline__ void mlp_part(float* lds, const PartMlpDev& pm, const float* __restrict__ emb,

@@ -538,3 +538,38 @@ def test_fused_adam_matches_torch_adam():
         assert maxerr(sa['state'][k]['exp_avg'], sb['state'][k]['exp_avg']) <= 1e-6 * float(sa['state'][k]['exp_avg'].abs().max()) + 1e-12
     ref2 = torch.optim.Adam(mk([p.detach().clone().requires_grad_() for p in my_p]), 5e-4, eps=1e-15)
     ref2.load_state_dict(mine.state_dict())             # checkpoints interchange
+
+
+def test_part_mlp_hip_backward_vs_torch_autograd(gpu_setup):
+    """Row f1: invr_part_mlp_fwd / invr_part_mlp_bwd (PartMlpFn) against the same two MLPs as torch ops under
+    torch.autograd: outputs, the embedding gradient and every parameter gradient (both colour-net depths, ragged n)."""
+    from invr import autograd as AG
+    cfg, sd, batch, gb, net = gpu_setup
+    g = torch.Generator().manual_seed(5)
+    keep = []
+    model = _abi.make_model({k: v for k, v in net.named_parameters()}, cfg, keep)
+    n_freq = cfg.viewdir_embedder.kwargs['res']
+    for pid, n in ((0, 5000), (1, 1234), (2, 17), (4, 2048)):
+        pn = net.tpose_human.part_networks[pid]
+        emb0 = torch.randn(n, 19, generator=g) * 0.5
+        dirs = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=1) * (0.5 + torch.rand(n, 1, generator=g))
+        gr = torch.randn(n, 4, generator=g)
+        params = [p for m in (pn.occ, pn.rgb) for l in m.linears for p in (l.weight, l.bias)] + [pn.rgb_latent]
+        res = []
+        for hip in (False, True):
+            emb = cu(emb0).requires_grad_()
+            for p in params:
+                p.grad = None
+            if hip:
+                plist = [p for m in (pn.occ, pn.rgb) for l in m.linears for p in (l.weight, l.bias)]
+                raw = AG.PartMlpFn.apply(emb, cu(dirs), model, pid, gb['latent_index'], pn.rgb_latent, *plist)
+            else:
+                raw = AG.part_mlps_torch(pn, emb, cu(dirs), gb['latent_index'], n_freq)
+            (raw * cu(gr)).sum().backward()
+            res.append([raw.detach(), emb.grad] + [p.grad.clone() for p in params])
+        names = ['raw', 'g_emb'] + ['param%d' % k for k in range(len(params))]
+        for nm, a, b in zip(names, *res):
+            scale = float(a.abs().max()) + 1e-12
+            assert maxerr(a, b) <= 2e-5 * scale + 1e-7, (pid, n, nm, maxerr(a, b), scale)
+    for p in net.parameters():
+        p.grad = None
