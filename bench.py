@@ -146,22 +146,33 @@ def main():
     for _ in range(max(args.warmup, 1)):
         out, full = step()
     fence()
-    if not args.no_graph:
+    use_graph = not args.no_graph
+    if use_graph:
         # one hipGraph per frame: the kernels of invr_render_fwd are enqueued on torch's capture stream
-        # (the library never synchronises or allocates), so a frame replays with one launch
-        graph = torch.cuda.CUDAGraph()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            render()
-        torch.cuda.current_stream().wait_stream(side)
-        with torch.cuda.graph(graph):
-            g_out, g_rgba = render()
+        # (the library never synchronises or allocates), so a frame replays with one launch.  thread_local capture
+        # mode: the RCCL watchdog thread of a multi-rank run may query events while this thread captures.
+        try:
+            graph = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                render()
+            torch.cuda.current_stream().wait_stream(side)
+            with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+                g_out, g_rgba = render()
 
-        def step():
-            graph.replay()
-            return g_out, idist.gather_maps(g_rgba, n_rays, rank, world)
-        out, full = step()
+            def step():
+                graph.replay()
+                return g_out, idist.gather_maps(g_rgba, n_rays, rank, world)
+            out, full = step()
+        except Exception as e:                       # keep the bench alive: eager launches measure the same work
+            sys.stderr.write('hipGraph capture failed (%s); falling back to eager launches\n' % e)
+            use_graph = False
+
+            def step():
+                out, rgba = render()
+                return out, idist.gather_maps(rgba, n_rays, rank, world)
+            out, full = step()
         fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -221,7 +232,7 @@ def main():
                 'active_samples': int(stats_all[0]), 'active_fraction': float(stats_all[0]) / total_samples,
                 'pairs_per_part': [int(v) for v in stats_all[1:6]],
                 'pairs_per_active_sample': float(stats_all[1:6].sum()) / max(int(stats_all[0]), 1),
-                'parameters': int(n_params), 'raw_occ_materialised': want_raw, 'hip_graph': not args.no_graph,
+                'parameters': int(n_params), 'raw_occ_materialised': want_raw, 'hip_graph': use_graph,
                 'parallelism': 'tile-cyclic ray shards x%d, full replicas, 1 all-gather/frame' % world,
                 'rays_per_sec': n_rays * args.steps / dt,
             },
