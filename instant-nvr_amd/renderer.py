@@ -22,6 +22,8 @@ class Renderer:
         # knobs that are not part of the reference signature
         self.eval_to_cpu = True        # reference moves every eval output to the CPU (:199-200)
         self.want_raw = True           # reference always returns raw/occ
+        self.adaptive_cap = True       # size the workspace from the previous frame's survivor count (eval_to_cpu only)
+        self._cap_hint = None
 
     def render(self, batch, test=False, epoch=-1):
         cfg = self.cfg
@@ -42,8 +44,23 @@ class Renderer:
         outs = []
         for i in range(0, n_pixel, per_call):
             sl = slice(i, i + per_call)
-            outs.append(self.net.render_rays(batch, ray_o[0, sl], ray_d[0, sl], near[0, sl], far[0, sl], S,
-                                             jitter=None if jitter is None else jitter[sl], want_raw=self.want_raw))
+            n_samp = min(per_call, n_pixel - i) * S
+            # The workspace is ~850 B per possible survivor.  With max_active = 0 every ray-sample may survive (28 GB
+            # for 512x512x128); since the eval contract ends in a host copy anyway, the survivor capacity follows the
+            # previous frame (x1.5) and a frame that overflows it (stats[6]) is rendered again at full capacity.
+            cap = 0
+            if self.adaptive_cap and self.eval_to_cpu:
+                cap = min(n_samp, max(self._cap_hint if self._cap_hint is not None else n_samp // 4, 65536))
+            call = lambda c: self.net.render_rays(batch, ray_o[0, sl], ray_d[0, sl], near[0, sl], far[0, sl], S,
+                                                  jitter=None if jitter is None else jitter[sl], want_raw=self.want_raw, max_active=c)
+            out = call(cap)
+            if cap:
+                st = out['stats'].cpu()
+                if int(st[6]) != 0:
+                    out = call(0)
+                    st = out['stats'].cpu()
+                self._cap_hint = int(1.5 * int(st[0])) + 65536
+            outs.append(out)
         cat = (lambda k: outs[0][k]) if len(outs) == 1 else (lambda k: torch.cat([o[k] for o in outs], 0))
         ret = {'rgb_map': cat('rgb_map')[None], 'acc_map': cat('acc_map')[None]}
         if self.want_raw:

@@ -573,3 +573,19 @@ def test_part_mlp_hip_backward_vs_torch_autograd(gpu_setup):
             assert maxerr(a, b) <= 2e-5 * scale + 1e-7, (pid, n, nm, maxerr(a, b), scale)
     for p in net.parameters():
         p.grad = None
+
+
+def test_renderer_adaptive_workspace_capacity(gpu_setup, golden):
+    """Renderer sizes the survivor capacity from the previous frame; an undersized guess is detected through
+    stats[6] and the frame rendered again — outputs are identical either way."""
+    cfg, sd, batch, gb, net = gpu_setup
+    r = Renderer(net)
+    a = r.render(dict(gb))
+    assert r._cap_hint is not None and r._cap_hint >= int(r.last_stats[0])
+    r._cap_hint = 10                                        # far too small -> overflow -> full-capacity retry
+    b = r.render(dict(gb))
+    r.adaptive_cap = False
+    c = r.render(dict(gb))
+    for k in a:
+        assert torch.equal(a[k], b[k]) and torch.equal(a[k], c[k]), k
+    assert int(r.last_stats[6]) == 0
