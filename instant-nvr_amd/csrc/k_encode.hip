@@ -335,7 +335,7 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_part_encode(GridDev g, const floa
 #define BWD_SMALL_FLOATS 6144
 
 __global__ __launch_bounds__(ENC_BLOCK) void k_part_encode_bwd(GridDev g, const float* __restrict__ xyz,
-                                                               const float* __restrict__ gout, int64_t n, int tp, int dbg,
+                                                               const float* __restrict__ gout, int64_t n, int tp,
                                                                float* g_dense, float* g_hash, float* __restrict__ g_xyz) {
     __shared__ float sgo[ENC_WAVES][64][20];          // g_out tile of the wave
     __shared__ float sgx[ENC_WAVES][64][3];           // per point: gradient w.r.t. the normalised coordinate
@@ -381,8 +381,8 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_part_encode_bwd(GridDev g, const 
 #pragma unroll
         for (int k = 0; k < 8; ++k) { prow[k] = 0xFFFFFFFFu; pval[k] = 0.0f; }
         auto flush = [&](unsigned r, float vsum) {
-            if (small_off >= 0) { if (!(dbg & 2)) atomicAdd(&ssmall[small_off + r], vsum); }
-            else if (!(dbg & 1)) unsafeAtomicAdd(gtb + (size_t)r * 16, vsum);                 // column 0 = row scalar
+            if (small_off >= 0) atomicAdd(&ssmall[small_off + r], vsum);
+            else unsafeAtomicAdd(gtb + (size_t)r * 16, vsum);                 // column 0 = row scalar
         };
         for (int j = 0; j < m; ++j) {
             const float x = rdlane(xi, j), y = rdlane(yi, j), z = rdlane(zi, j);
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_part_encode_bwd(GridDev g, const 
             const float gl = sgo[wv][j][3 + level];
             float4 v[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = (dbg & 4) ? make_float4(1.f, 2.f, 3.f, 4.f) : L.tab[(size_t)row[k] * 4];
+            for (int k = 0; k < 8; ++k) v[k] = L.tab[(size_t)row[k] * 4];
             float gtx = 0.f, gty = 0.f, gtz = 0.f;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -472,8 +472,7 @@ int launch_part_encode_bwd(const GridDev& g, const float* xyz, const float* gout
     while (tp > 16 && n / tp < 4096) tp >>= 1;                // enough waves to fill the GPU, long enough runs to combine
     int64_t tiles = cdiv(n, (int64_t)tp * ENC_WAVES);
     unsigned grid = (unsigned)(tiles < 2048 ? (tiles > 0 ? tiles : 1) : 2048);
-    static int dbg = getenv("INVR_BWD_DBG") ? atoi(getenv("INVR_BWD_DBG")) : 0;
-    hipLaunchKernelGGL(k_part_encode_bwd, dim3(grid), dim3(ENC_BLOCK), 0, st, g, xyz, gout, n, tp, dbg, g_dense, g_hash, g_xyz);
+    hipLaunchKernelGGL(k_part_encode_bwd, dim3(grid), dim3(ENC_BLOCK), 0, st, g, xyz, gout, n, tp, g_dense, g_hash, g_xyz);
     INVR_LAUNCH_CHECK();
     return 0;
 }

@@ -45,13 +45,11 @@
 // ~1e-7 per pair).  +inf / row 0 is both the empty marker and the cluster padding sentinel.
 struct Top4 {
     unsigned long long k[KNN_K];
-    float junk;
     float d[KNN_K];
     int i[KNN_K];
     __device__ __forceinline__ void init() {
 #pragma unroll
         for (int j = 0; j < KNN_K; ++j) k[j] = 0x7F80000000000000ull;
-        junk = 0.0f;
     }
     // ONE (usually wave-skipped) branch, the shifting is predicated selects — a nested-branch insert
     // costs ~10 scalar-ALU instructions per vertex and the CU has a single SALU
@@ -276,7 +274,6 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // reads are issued together; the squared distances of two vertices are formed with packed fp32 ops
 // (v_pk_add/mul_f32 — each component is the same IEEE op sequence as ((p1-p2)**2).sum(-1)); one fp32
 // compare against the current 4th best guards the exact 64-bit-key inserts of both.
-template <bool NOPUSH = false>
 __device__ __forceinline__ void scan_sub16(const float4* sv, v2f px, v2f py, v2f pz, Top4& t) {
 #pragma unroll
     for (int m0 = 0; m0 < 8; m0 += 4) {
@@ -288,7 +285,6 @@ __device__ __forceinline__ void scan_sub16(const float4* sv, v2f px, v2f py, v2f
             const v2f dx = px - (v2f){A[k].x, A[k].y}, dy = py - (v2f){A[k].z, A[k].w}, dz = pz - (v2f){B[k].x, B[k].y};
             const v2f d2 = (dx * dx + dy * dy) + dz * dz;
             if (fminf(d2.x, d2.y) <= t.worst()) {
-                if (NOPUSH) { t.junk += d2.x + d2.y + B[k].z; continue; }     // ablation only (INVR_KNN_DBG=32)
                 t.push(d2.x, __float_as_int(B[k].z));
                 t.push(d2.y, __float_as_int(B[k].w));
             }
@@ -356,7 +352,6 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w, 
         float px = 0, py = 0, pz = 0;
         if (live) sample_pose_point(a, w.active_idx[slot], px, py, pz, nullptr, nullptr);
         unsigned flags = 0, farflags = 0;
-        int dbg_subs = 0, dbg_tests = 0, dbg_scans = 0;     // INVR_KNN_DBG=64: work counters -> stats[13..15]
         int4 res_nn[INVR_NUM_PARTS];
         float4 res_w[INVR_NUM_PARTS];
 #pragma unroll
@@ -365,7 +360,7 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w, 
             if (len < KNN_K) continue;                     // reference: inf distances -> NaN dist -> unflagged
             const float* bb = ix.part_aabb + p * 6;
             const float lbp = aabb_dist2(px, py, pz, make_float4(bb[0], bb[1], bb[2], 0.f), make_float4(bb[3], bb[4], bb[5], 0.f));
-            if (__ballot(live && !(lbp > KNN_DFAR2)) == 0 || (dbg & 16)) {          // whole wave far from this part
+            if (__ballot(live && !(lbp > KNN_DFAR2)) == 0) {          // whole wave far from this part
                 if (live) farflags |= 1u << p;
                 continue;
             }
@@ -390,9 +385,7 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w, 
             }
             const bool is_far = lb2 > KNN_DFAR2;
             const bool unflagged = lb2 >= a.scene.near_hi2 && ub2 <= a.scene.band_lo2;
-            bool scan = live && !is_far && !unflagged;
-            if ((dbg & 4) && lb2 >= a.scene.near_hi2) scan = false;      // ablation: drop band-type scans
-            if ((dbg & 8) && lb2 < a.scene.near_hi2) scan = false;       // ablation: drop near-type scans
+            const bool scan = live && !is_far && !unflagged;
             if (live && is_far) farflags |= 1u << p;
             if (__ballot(scan) == 0 || (dbg & 1)) continue;
             // exact 4-NN: seed with the cluster of the wave's first scanning lane, then a pruned sweep that
@@ -406,7 +399,6 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w, 
             const int seed_c = __builtin_amdgcn_readlane(seed, __ffsll((long long)__ballot(scan)) - 1);
 #pragma unroll 1
             for (int s4 = 0; s4 < 4; ++s4) scan_sub16(sv + seed_c * 64 + s4 * 16, px2, py2, pz2, t);
-            dbg_subs += 4; dbg_scans += 1;
 #pragma unroll 1
             for (int k = 1; (seed_c + k < ncl || seed_c - k >= 0) && !(dbg & 2); ++k) {
 #pragma unroll 1
@@ -414,29 +406,23 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w, 
                     const int c = side ? seed_c - k : seed_c + k;
                     if (c < 0 || c >= ncl) continue;
                     const bool need = scan && aabb_dist2(px, py, pz, lds_ld4(cl + c * 3), lds_ld4(cl + c * 3 + 1)) <= t.worst();
-                    dbg_tests += 1;
                     if (__ballot(need) == 0) continue;
 #pragma unroll 1
                     for (int s4 = 0; s4 < 4; ++s4) {
                         const bool need_s = need && aabb_dist2(px, py, pz, lds_ld4(sb + c * 8 + s4 * 2), lds_ld4(sb + c * 8 + s4 * 2 + 1)) <= t.worst();
                         if (__ballot(need_s) == 0) continue;
-                        dbg_subs += 1;
-                        if (dbg & 32) scan_sub16<true>(sv + c * 64 + s4 * 16, px2, py2, pz2, t);
-                        else scan_sub16(sv + c * 64 + s4 * 16, px2, py2, pz2, t);
+                        scan_sub16(sv + c * 64 + s4 * 16, px2, py2, pz2, t);
                     }
                 }
             }
             t.finish();
             float wt[KNN_K];
             const float ds = knn_weights(t, wt);
-            if (scan && ds < a.scene.thresh && t.junk != 123.456f) {   // pflag (inb_part_network_multiassign.py:90)
+            if (scan && ds < a.scene.thresh) {                        // pflag (inb_part_network_multiassign.py:90)
                 flags |= 1u << p;
                 res_nn[p] = make_int4(t.i[0], t.i[1], t.i[2], t.i[3]);
                 res_w[p] = make_float4(wt[0], wt[1], wt[2], wt[3]);
             }
-        }
-        if ((dbg & 64) && lane == 0) {
-            atomicAdd(&w.counters[13], dbg_subs); atomicAdd(&w.counters[14], dbg_tests); atomicAdd(&w.counters[15], dbg_scans);
         }
         // list append, aggregated per workgroup-tile: 5 global atomics per 1024 points instead of one
         // returned atomic per wave per part (whose contended latency dominated the kernel)
