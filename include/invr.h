@@ -119,7 +119,7 @@ typedef struct InvrScene {
 const char* invr_last_error(void);
 int invr_version(void);
 /* sizeof() of the ABI structs as compiled (0 InvrGrid, 1 InvrMlp, 2 InvrPart, 3 InvrModel,
- * 4 InvrScene): lets a binding verify its struct mirrors. */
+ * 4 InvrScene, 5 InvrWsLayout, 6 InvrMlpBwdOut, 7 InvrAdamTensor): lets a binding verify its struct mirrors. */
 size_t invr_sizeof(int32_t which);
 
 /* Bytes of workspace invr_render_fwd needs for n_rays x n_samples with at most max_active

@@ -94,7 +94,7 @@ def lib():
         L.invr_version.restype = C.c_int
         L.invr_sizeof.restype = C.c_size_t
         L.invr_sizeof.argtypes = [C.c_int32]
-        for i, t in enumerate((InvrGrid, InvrMlp, InvrPart, InvrModel, InvrScene)):
+        for i, t in enumerate((InvrGrid, InvrMlp, InvrPart, InvrModel, InvrScene, InvrWsLayout, InvrMlpBwdOut, InvrAdamTensor)):
             if L.invr_sizeof(i) != C.sizeof(t):
                 raise RuntimeError('libinvr ABI mismatch: struct %s is %d bytes in the library, %d in the binding'
                                    % (t.__name__, L.invr_sizeof(i), C.sizeof(t)))

@@ -26,6 +26,9 @@ extern "C" size_t invr_sizeof(int32_t which) {
         case 2: return sizeof(InvrPart);
         case 3: return sizeof(InvrModel);
         case 4: return sizeof(InvrScene);
+        case 5: return sizeof(InvrWsLayout);
+        case 6: return sizeof(InvrMlpBwdOut);
+        case 7: return sizeof(InvrAdamTensor);
         default: return 0;
     }
 }

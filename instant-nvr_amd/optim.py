@@ -75,4 +75,8 @@ class FusedAdam(torch.optim.Optimizer):
         ct, ci = self._plan(entries)
         _abi.check(_abi.lib().invr_adam_step(C.c_void_p(table.data_ptr()), _abi.ptr(ct, torch.int32), _abi.ptr(ci, torch.int32),
                                              ct.numel(), betas[0], betas[1], eps, _abi.stream_ptr()))
+        for p, _ in entries:          # the kernel wrote through raw pointers: tell autograd / version-keyed caches (Embedder.row_sums)
+            torch.autograd.graph.increment_version(p)
+            torch.autograd.graph.increment_version(self.state[p]['exp_avg'])
+            torch.autograd.graph.increment_version(self.state[p]['exp_avg_sq'])
         return loss

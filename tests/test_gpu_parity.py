@@ -589,3 +589,27 @@ def test_renderer_adaptive_workspace_capacity(gpu_setup, golden):
     for k in a:
         assert torch.equal(a[k], b[k]) and torch.equal(a[k], c[k]), k
     assert int(r.last_stats[6]) == 0
+
+
+def test_row_sum_tables_follow_weight_updates(small_setup):
+    """The eval-only row-sum tables are derived data: after the tables change (in-place copy, FusedAdam step through
+    raw pointers) the next eval render must rebuild them."""
+    from invr.optim import FusedAdam
+    cfg, sd, batch, extras = small_setup
+    net = Network(cfg=cfg)
+    net.load_state_dict(sd, strict=True)
+    net = net.to(DEV).eval()
+    gb = {k: v.to(DEV) for k, v in batch.items()}
+    r = Renderer(net)
+    a = r.render(dict(gb))['rgb_map']
+    emb = net.tpose_human.part_networks[0].embedder
+    opt = FusedAdam([{'params': [emb.hash, emb.dense], 'lr': 1e-2}], 1e-2, eps=1e-15)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    emb.hash.grad = torch.randn(emb.hash.shape, generator=g, device=DEV)
+    emb.dense.grad = torch.randn(emb.dense.shape, generator=g, device=DEV)
+    opt.step()
+    b = r.render(dict(gb))['rgb_map']
+    with encoder_mode(cfg, False):                           # 64-byte rows: no derived table involved
+        c = r.render(dict(gb))['rgb_map']
+    assert float((a - b).abs().max()) > 1e-3                 # the update is visible
+    assert float((b - c).abs().max()) < 1e-4                 # and the row-sum path agrees with the direct path
