@@ -603,7 +603,7 @@ def test_row_sum_tables_follow_weight_updates(small_setup):
     r = Renderer(net)
     a = r.render(dict(gb))['rgb_map']
     emb = net.tpose_human.part_networks[0].embedder
-    opt = FusedAdam([{'params': [emb.hash, emb.dense], 'lr': 1e-2}], 1e-2, eps=1e-15)
+    opt = FusedAdam([{'params': [emb.hash, emb.dense], 'lr': 0.1}], 0.1, eps=1e-15)
     g = torch.Generator(device=DEV).manual_seed(3)
     emb.hash.grad = torch.randn(emb.hash.shape, generator=g, device=DEV)
     emb.dense.grad = torch.randn(emb.dense.shape, generator=g, device=DEV)
