@@ -1,4 +1,4 @@
-"""Markdown summary of one scratch/prof_all.sh result directory (gpurun_out/<tag>): bench line, rocprofv3
+"""Markdown summary of one tools/prof_all.sh result directory (gpurun_out/<tag>): bench line, rocprofv3
 --kernel-trace --stats table, per-kernel PMC averages and derived utilisations; also writes
 profiles/hbm_traffic_per_launch.json (FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, bytes per launch).
 usage: python tools/prof_summary.py gpurun_out/r1f profiles/r1f_kernel_stats_and_pmc.md "<title>" """
@@ -11,7 +11,7 @@ import sys
 
 R, dst, title = sys.argv[1], sys.argv[2], sys.argv[3]
 out = ['# ' + title + '\n']
-out.append('Commands (MI355X box, `bash scratch/prof_all.sh <tag>`): `python bench.py --steps 20 --warmup 5` (default flags, hipGraph replay), then\n'
+out.append('Commands (MI355X box, `bash tools/prof_all.sh <tag>`): `python bench.py --steps 20 --warmup 5` (default flags, hipGraph replay), then\n'
            '`rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu-baseline --no-graph --steps 10 --warmup 3`, then one\n'
            '`rocprofv3 --kernel-trace --pmc <group> --output-format csv` run per counter group (`--steps 2 --warmup 1`; eager launches).\n')
 out.append('## bench.py (default flags) JSON line\n```\n' + open(R + '/bench.json').read().strip() + '\n```\n')
