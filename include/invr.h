@@ -263,21 +263,17 @@ int invr_grid_row_sums(const InvrGrid* grid, float* out, void* stream);
 /* Training path of the two part MLPs (part_base_network.py:44-63 after the encoder) on SoA inputs:
  * emb_soa (20,n) = the 19 encoder outputs as rows (row 19 = 0), dirs_soa (3,n) canonical view directions.
  * fwd: raw (n,4) = [sigmoid rgb, occ]; count_dev = DEVICE int32 holding n.
- * bwd: recomputes the forward, propagates g_raw (n,4) to the embedding and writes, per layer, the pre-activation
- * gradients g_z and the layer inputs as row-major (n,dim) matrices — the weight gradients are dW = g_z^T a_in, the bias
- * gradients the column sums of g_z (K = n reductions, done by the caller's GEMMs).  x_k is the rgb layer-1 input in
- * the kernel's k-slot order (column 4 s + g, s = 0..17, g = 0..3; see rgb1_col in csrc/mlp_common.h). */
+ * bwd: recomputes the forward, propagates g_raw (n,4) to the embedding and writes, per layer l = 0 occ layer 1, 1 occ
+ * layer 2, 2 rgb layer 1, 3 rgb layer 2 (3-linear colour nets only), 4 rgb head, the gradient w.r.t. the layer's
+ * output before the activation into gz[l] (n_pad,64) and the layer's input into a[l] (n_pad,72); the caller zero-fills
+ * both.  Weight gradients are dW_l = gz[l]^T a[l] (first out_l rows / in_l columns), bias gradients the column sums of
+ * gz[l] — K = n reductions left to the caller's batched GEMM.  a[2] is in the kernel's k-slot order (column 4 s + g,
+ * s = 0..17, g = 0..3; rgb1_col in csrc/mlp_common.h). */
 typedef struct InvrMlpBwdOut {
     float* g_emb;     /* (20,n) rows 0..18 written */
-    float* go;        /* (n,3)  d/d rgb pre-activation */
-    float* gz_last;   /* (n,64) last hidden rgb layer */
-    float* gz_r1;     /* (n,64) rgb layer 1, 3-linear colour nets only (else NULL) */
-    float* g_out2;    /* (n,17) [logit, 16 features] of occ layer 2 */
-    float* gz_h1;     /* (n,64) occ hidden layer */
-    float* a_last;    /* (n,64) input of the rgb head */
-    float* a_r1;      /* (n,64) input of rgb layer 2 (3-linear nets only) */
-    float* a_h1;      /* (n,64) input of occ layer 2 */
-    float* x_k;       /* (n,72) input of rgb layer 1, k-slot order */
+    float* gz;        /* (5,n_pad,64) */
+    float* a;         /* (5,n_pad,72) */
+    int64_t n_pad;    /* >= n */
     float* g_latent;  /* (8) accumulated (caller pre-zeroes) */
 } InvrMlpBwdOut;
 int invr_part_mlp_fwd(const InvrModel* model, int32_t pid, const int64_t* latent_index, const float* emb_soa,

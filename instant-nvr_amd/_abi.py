@@ -30,7 +30,7 @@ class InvrGrid(C.Structure):
 
 
 class InvrMlpBwdOut(C.Structure):
-    _fields_ = [(k, C.c_void_p) for k in ('g_emb', 'go', 'gz_last', 'gz_r1', 'g_out2', 'gz_h1', 'a_last', 'a_r1', 'a_h1', 'x_k', 'g_latent')]
+    _fields_ = [('g_emb', C.c_void_p), ('gz', C.c_void_p), ('a', C.c_void_p), ('n_pad', C.c_int64), ('g_latent', C.c_void_p)]
 
 
 class InvrAdamTensor(C.Structure):

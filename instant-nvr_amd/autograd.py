@@ -207,27 +207,29 @@ class PartMlpFn(torch.autograd.Function):
     def backward(ctx, g_raw):
         emb_soa, dirs_soa, li, rgb_latent = ctx.saved_tensors
         n, dev, three = emb_soa.shape[1], emb_soa.device, ctx.n_rgb == 3
-        E = lambda *sh: torch.empty(*sh, device=dev)
-        o = dict(g_emb=E(20, n), go=E(n, 3), gz_last=E(n, 64), g_out2=E(n, 17), gz_h1=E(n, 64), a_last=E(n, 64), a_h1=E(n, 64),
-                 x_k=E(n, 72), g_latent=torch.zeros(8, device=dev), gz_r1=E(n, 64) if three else None, a_r1=E(n, 64) if three else None)
+        n_pad = (n + _SPLIT_ROWS - 1) // _SPLIT_ROWS * _SPLIT_ROWS
+        gz = torch.zeros(5, n_pad, 64, device=dev)
+        a = torch.zeros(5, n_pad, 72, device=dev)
+        g_emb_soa = torch.empty(20, n, device=dev)
+        g_latent = torch.zeros(8, device=dev)
         out = _abi.InvrMlpBwdOut()
-        for k, v in o.items():
-            setattr(out, k, None if v is None else v.data_ptr())
+        out.g_emb, out.gz, out.a, out.n_pad, out.g_latent = g_emb_soa.data_ptr(), gz.data_ptr(), a.data_ptr(), n_pad, g_latent.data_ptr()
         g_raw = g_raw.to(torch.float32).contiguous()
         _abi.check(_abi.lib().invr_part_mlp_bwd(C.byref(ctx.model), ctx.pid, _abi.ptr(li, torch.int64), _abi.ptr(emb_soa), _abi.ptr(dirs_soa),
                                                 n, _abi.ptr(g_raw), C.byref(out), _abi.stream_ptr()))
-        g_emb = o['g_emb'][:19].t()
-        emb = emb_soa[:19].t()
+        # all weight gradients of the part in ONE slab-batched GEMM: (5 S, 64, 2048) x (5 S, 2048, 72), summed over the S slabs
+        S = n_pad // _SPLIT_ROWS
+        dW = torch.bmm(gz.view(5 * S, _SPLIT_ROWS, 64).transpose(1, 2), a.view(5 * S, _SPLIT_ROWS, 72)).view(5, S, 64, 72).sum(1)
+        db = gz.sum(1)
         col = torch.as_tensor(_SLOT_OF_COL, device=dev)
         # parameter order: occ W0 b0 W1 b1, rgb W0 b0 [W1 b1] Wout bout
-        grads = [_splitk(o['gz_h1'], emb), o['gz_h1'].sum(0), _splitk(o['g_out2'], o['a_h1']), o['g_out2'].sum(0)]
-        gz_first = o['gz_r1'] if three else o['gz_last']
-        grads += [_splitk(gz_first, o['x_k'])[:, col], gz_first.sum(0)]
+        grads = [dW[0, :, :19], db[0], dW[1, :17, :64], db[1, :17], dW[2][:, col], db[2]]
         if three:
-            grads += [_splitk(o['gz_last'], o['a_r1']), o['gz_last'].sum(0)]
-        grads += [_splitk(o['go'], o['a_last']), o['go'].sum(0)]
+            grads += [dW[3, :, :64], db[3]]
+        grads += [dW[4, :3, :64], db[4, :3]]
+        g_emb = g_emb_soa[:19].t()
         g_lat = torch.zeros_like(rgb_latent)
-        g_lat[li[0]] = o['g_latent']
+        g_lat[li[0]] = g_latent
         return (g_emb, None, None, None, None, g_lat) + tuple(grads)
 
 

@@ -551,14 +551,12 @@ extern "C" int invr_part_mlp_bwd(const InvrModel* model, int32_t pid, const int6
     INVR_CHECK(model && latent_index && pid >= 0 && pid < INVR_NUM_PARTS && out, "invr_part_mlp_bwd: bad model/pid/out");
     if (n == 0) return 0;
     PartMlpDev pm = make_part_mlp(model, pid, latent_index);
-    const bool three = pm.rgb.n_linear == 3;
-    INVR_CHECK(emb_soa && dirs_soa && g_raw && out->g_emb && out->go && out->gz_last && out->g_out2 && out->gz_h1 && out->a_last &&
-               out->a_h1 && out->x_k && out->g_latent && (!three || (out->gz_r1 && out->a_r1)), "invr_part_mlp_bwd: null pointer");
+    INVR_CHECK(emb_soa && dirs_soa && g_raw && out->g_emb && out->gz && out->a && out->g_latent && out->n_pad >= n, "invr_part_mlp_bwd: null pointer / n_pad < n");
     const MlpDev& oc = pm.occ;
     const MlpDev& r = pm.rgb;
     INVR_CHECK(oc.n_linear == 2 && oc.dims[0] == 19 && oc.dims[1] == 64 && oc.dims[2] == 17 && (r.n_linear == 2 || r.n_linear == 3) &&
                r.dims[0] == 70 && r.dims[1] == 64 && r.dims[r.n_linear] == 3 && pm.n_freq == 4 && pm.latent_dim == 8 && pm.geo_dim == 16,
                "invr_part_mlp_bwd: supports occ 19-64-17 and rgb 70-64(-64)-3");
-    MlpBwdOut o{out->g_emb, out->go, out->gz_last, out->gz_r1, out->g_out2, out->gz_h1, out->a_last, out->a_r1, out->a_h1, out->x_k, out->g_latent};
+    MlpBwdOut o{out->g_emb, out->gz, out->a, out->n_pad, out->g_latent};
     return launch_part_mlp_bwd(pm, emb_soa, dirs_soa, n, g_raw, o, (hipStream_t)stream);
 }

@@ -15,12 +15,12 @@
 // are column sums of g_z; the latent-code gradient is accumulated here.
 #include "mlp_common.h"
 
-// MlpBwdOut (pipeline.h): all matrices row-major with n rows —
-//   g_emb (20,n) SoA, rows 0..18 written (k-slot order = embedding column); go (n,3) d/d rgb pre-activation;
-//   gz_last (n,64) d/d pre-activation of the last hidden rgb layer; gz_r1 (n,64) same for rgb layer 1 (3-linear nets);
-//   g_out2 (n,17) d/d output of occ layer 2 ([logit, 16 features]); gz_h1 (n,64) d/d pre-activation of the occ hidden
-//   layer; a_last / a_r1 / a_h1 (n,64) the matching layer inputs; x_k (n,72) rgb layer-1 input in k-slot order
-//   (column 4 s + g); g_latent (8) accumulated with atomics (pre-zeroed by the caller).
+// MlpBwdOut (pipeline.h): g_emb (20,n) SoA, rows 0..18 written (k-slot order = embedding column); gz (5, n_pad, 64) and
+// a (5, n_pad, 72): per layer [0 occ1, 1 occ2, 2 rgb1, 3 rgb2 (3-linear colour nets only), 4 rgb head] the gradient
+// w.r.t. the layer's pre-activation / output and the layer's input, row-major and zero-padded by the caller, so that ONE
+// batched GEMM gz^T a over 2048-row slabs yields all weight gradients of the part (bias gradients = column sums of gz).
+// The rgb1 input is stored in k-slot order (column 4 s + g, rgb1_col in mlp_common.h).  g_latent (8) is accumulated
+// with atomics (pre-zeroed by the caller).
 
 __device__ __forceinline__ f32x4 dsoftplus4(f32x4 gin, f32x4 act) {    // softplus'(z) = sigmoid(z) = 1 - exp(-softplus(z))
     f32x4 r;
@@ -45,6 +45,8 @@ __global__ __launch_bounds__(MLP_BLOCK, 1) void k_part_mlp_bwd(PartMlpDev pm, co
     const float misc2 = g < 3 ? lat[5 + g] : 0.0f;
     const float fmul = (float)(1 << g);
     f32x4 lat_acc = {0.f, 0.f, 0.f, 0.f};
+#define G(l) (o.gz + (int64_t)(l) * o.n_pad * 64)
+#define A(l) (o.a + (int64_t)(l) * o.n_pad * 72)
 
     const int64_t per_block = (MLP_BLOCK / 64) * 16;
     for (int64_t t0 = (int64_t)blockIdx.x * per_block + (int64_t)wv * 16; t0 < n; t0 += (int64_t)gridDim.x * per_block) {
@@ -87,7 +89,10 @@ __global__ __launch_bounds__(MLP_BLOCK, 1) void k_part_mlp_bwd(PartMlpDev pm, co
         for (int r = 0; r < 4; ++r) kb[14 + r] = feat[r];
         if (live) {
 #pragma unroll
-            for (int s = 0; s < RGB1_STEPS; ++s) o.x_k[pair * 72 + 4 * s + g] = kb[s];
+            for (int s = 0; s < RGB1_STEPS; ++s) A(2)[pair * 72 + 4 * s + g] = kb[s];
+#pragma unroll
+            for (int s = 0; s < EMB_STEPS; ++s)
+                if (4 * s + g < 19) A(0)[pair * 72 + 4 * s + g] = eb[s];
         }
         f32x4 hr1[4];
 #pragma unroll
@@ -134,11 +139,11 @@ __global__ __launch_bounds__(MLP_BLOCK, 1) void k_part_mlp_bwd(PartMlpDev pm, co
             gz[mt] = dsoftplus4(gz[mt], hl[mt]);
         }
         if (live) {
-            if (g == 0) { o.go[pair * 3] = go[0]; o.go[pair * 3 + 1] = go[1]; o.go[pair * 3 + 2] = go[2]; }
+            if (g == 0) { G(4)[pair * 64] = go[0]; G(4)[pair * 64 + 1] = go[1]; G(4)[pair * 64 + 2] = go[2]; }
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
-                store4(o.gz_last + pair * 64 + 16 * mt + 4 * g, gz[mt]);
-                store4(o.a_last + pair * 64 + 16 * mt + 4 * g, hl[mt]);
+                store4(G(NRGB == 3 ? 3 : 2) + pair * 64 + 16 * mt + 4 * g, gz[mt]);
+                store4(A(4) + pair * 72 + 16 * mt + 4 * g, hl[mt]);
             }
         }
         if (NRGB == 3) {                                          // rgb2^T: g_hr1 = W2^T gz ; gz <- g_hr1 * softplus'(.)
@@ -157,8 +162,8 @@ __global__ __launch_bounds__(MLP_BLOCK, 1) void k_part_mlp_bwd(PartMlpDev pm, co
             if (live) {
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
-                    store4(o.gz_r1 + pair * 64 + 16 * mt + 4 * g, gz[mt]);
-                    store4(o.a_r1 + pair * 64 + 16 * mt + 4 * g, hr1[mt]);
+                    store4(G(2) + pair * 64 + 16 * mt + 4 * g, gz[mt]);
+                    store4(A(3) + pair * 72 + 16 * mt + 4 * g, hr1[mt]);
                 }
             }
         }
@@ -191,14 +196,14 @@ __global__ __launch_bounds__(MLP_BLOCK, 1) void k_part_mlp_bwd(PartMlpDev pm, co
             gh[mi] = dsoftplus4(gh[mi], h1[mi]);
         }
         if (live) {
-            float* q = o.g_out2 + pair * 17;
+            float* q = G(1) + pair * 64;
             if (g == 0) q[0] = g_lg;
 #pragma unroll
             for (int r = 0; r < 4; ++r) q[1 + 4 * g + r] = gfeat[r];
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
-                store4(o.gz_h1 + pair * 64 + 16 * mt + 4 * g, gh[mt]);
-                store4(o.a_h1 + pair * 64 + 16 * mt + 4 * g, h1[mt]);
+                store4(G(0) + pair * 64 + 16 * mt + 4 * g, gh[mt]);
+                store4(A(1) + pair * 72 + 16 * mt + 4 * g, h1[mt]);
             }
         }
         // occ layer 1^T into the same embedding-slot tiles
@@ -226,6 +231,9 @@ __global__ __launch_bounds__(MLP_BLOCK, 1) void k_part_mlp_bwd(PartMlpDev pm, co
         if (col == 0 && g < 2) atomicAdd(o.g_latent + 4 * g + r, v);
     }
 }
+
+#undef G
+#undef A
 
 int launch_part_mlp_bwd(const PartMlpDev& pm, const float* emb_soa, const float* d_soa, int64_t n, const float* g_raw,
                         const MlpBwdOut& o, hipStream_t st) {

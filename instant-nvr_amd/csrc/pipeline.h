@@ -131,8 +131,7 @@ int launch_part_mlp(const PartMlpDev& pm, const float* emb, const float* d_soa, 
                     const int32_t* l_slot, const int32_t* count, int64_t cap, float4* raws, int part,
                     float4* raw_direct, hipStream_t st);
 struct MlpBwdOut {                 // k_mlp_bwd.hip; mirrors InvrMlpBwdOut
-    float* g_emb; float* go; float* gz_last; float* gz_r1; float* g_out2; float* gz_h1;
-    float* a_last; float* a_r1; float* a_h1; float* x_k; float* g_latent;
+    float* g_emb; float* gz; float* a; int64_t n_pad; float* g_latent;
 };
 int launch_part_mlp_bwd(const PartMlpDev& pm, const float* emb_soa, const float* d_soa, int64_t n, const float* g_raw,
                         const MlpBwdOut& o, hipStream_t st);

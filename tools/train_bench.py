@@ -38,4 +38,4 @@ if os.environ.get('PROF'):
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
         for i in range(3): step(20 + i)
         torch.cuda.synchronize()
-    print(prof.key_averages().table(sort_by='cuda_time_total', row_limit=28, max_name_column_width=60))
+    print(prof.key_averages().table(sort_by=os.environ.get('PROF_SORT', 'cuda_time_total'), row_limit=28, max_name_column_width=60))
