@@ -72,6 +72,30 @@ def cpu_baseline(net, cfg, batch_cpu, n_rays, S, seed=0):
                       % (n_rays, S, torch.__version__, dt)}
 
 
+def train_probe(net, dev, S, iters):
+    """BASELINE configs[4]-shaped training iteration on this GPU: a 32x32 patch (1024 rays) x S samples, forward +
+    backward (HIP kernels behind autograd) + the fused Adam step over all parameters; informational extra object."""
+    from invr import driver
+    from invr.trainer import NetworkWrapper
+    bnp, _ = scene_mod.make_scene(512, 512, seed=0, cam_dist=1.8, crop=(240, 240, 32, 32))
+    batch = {k: v.to(dev) for k, v in scene_mod.to_torch(bnp).items()}
+    net.train()
+    wrap = NetworkWrapper(net)
+    opt = driver.make_optimizer(net)
+    for i in range(2):
+        driver.train_step(wrap, opt, batch, i + 2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(iters):
+        loss, _ = driver.train_step(wrap, opt, batch, i + 4)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    net.eval()
+    return {'ms_per_iter': dt * 1e3, 'rays_per_iter': int(batch['ray_o'].shape[1]), 'samples_per_ray': S,
+            'ray_samples_per_sec': batch['ray_o'].shape[1] * S / dt, 'optimizer': type(opt).__name__,
+            'parameters_updated': int(sum(p.numel() for p in net.parameters() if p.requires_grad)), 'final_loss': loss}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -86,6 +110,7 @@ def main():
     ap.add_argument('--cpu-rays', type=int, default=128, help='rays in the bounded CPU-baseline sample')
     ap.add_argument('--full-rows', action='store_true', help='read the trainable 64-byte table rows instead of the eval-mode row-sum tables')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--train-iters', type=int, default=10, help='iterations of the informational training-step probe (0 = skip; N=1 only)')
     ap.add_argument('--no-graph', action='store_true', help='launch the ~25 kernels of a frame eagerly instead of replaying one captured hipGraph')
     ap.add_argument('--shard-of', type=int, default=0, help='debug (1 GPU): render only rank 0\'s ray shard of a W-way split')
     args = ap.parse_args()
@@ -263,6 +288,11 @@ def main():
             ],
             'stage_ms_per_step': {k: v / per for k, v in stage_ms.items()},
         }
+        if world == 1 and args.train_iters > 0 and not args.shard_of:
+            try:
+                line['train_step'] = train_probe(net, dev, S, args.train_iters)
+            except Exception as e:          # informational only: never lose the bench line over it
+                line['train_step'] = {'error': repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(net, cfg, batch_cpu, min(args.cpu_rays, n_rays), S)
         else:

@@ -182,6 +182,15 @@ for _s in range(18):
             _SLOT_OF_COL[_rgb1_col(_s, _g)] = 4 * _s + _g
 
 
+_slot_cache = {}
+
+
+def _slot_of_col(dev):
+    if dev not in _slot_cache:
+        _slot_cache[dev] = torch.as_tensor(_SLOT_OF_COL, device=dev)
+    return _slot_cache[dev]
+
+
 class PartMlpFn(torch.autograd.Function):
     """The two MLPs of one part (part_base_network.py:44-63 after the encoder) on the matrix cores in both directions:
     invr_part_mlp_fwd / invr_part_mlp_bwd.  The backward kernel recomputes the forward, returns the embedding gradient
@@ -221,7 +230,7 @@ class PartMlpFn(torch.autograd.Function):
         S = n_pad // _SPLIT_ROWS
         dW = torch.bmm(gz.view(5 * S, _SPLIT_ROWS, 64).transpose(1, 2), a.view(5 * S, _SPLIT_ROWS, 72)).view(5, S, 64, 72).sum(1)
         db = gz.sum(1)
-        col = torch.as_tensor(_SLOT_OF_COL, device=dev)
+        col = _slot_of_col(dev)
         # parameter order: occ W0 b0 W1 b1, rgb W0 b0 [W1 b1] Wout bout
         grads = [dW[0, :, :19], db[0], dW[1, :17, :64], db[1, :17], dW[2][:, col], db[2]]
         if three:
