@@ -284,13 +284,19 @@ static int render_impl(const InvrScene* scene, const InvrModel* model,
     a.R = n_rays; a.S = n_samples; a.N = N;
 
     // fork: KNN index build (k_part_prepare, 5 workgroups, ~60 us) on a side stream beside the cull kernels
-    static thread_local hipStream_t side = nullptr;
-    static thread_local hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    if (!side) {
-        INVR_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
-        INVR_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-        INVR_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    struct SideStream { hipStream_t side = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+    static thread_local SideStream side_of_device[16];            // one per device this thread renders on
+    int dev_id = 0;
+    INVR_HIP(hipGetDevice(&dev_id));
+    INVR_CHECK(dev_id >= 0 && dev_id < 16, "invr_render_fwd: device index %d out of range", dev_id);
+    SideStream& ss = side_of_device[dev_id];
+    if (!ss.side) {
+        INVR_HIP(hipStreamCreateWithFlags(&ss.side, hipStreamNonBlocking));
+        INVR_HIP(hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming));
+        INVR_HIP(hipEventCreateWithFlags(&ss.join, hipEventDisableTiming));
     }
+    hipStream_t side = ss.side;
+    hipEvent_t ev_fork = ss.fork, ev_join = ss.join;
     INVR_HIP(hipEventRecord(ev_fork, st));
     INVR_HIP(hipStreamWaitEvent(side, ev_fork, 0));
     if (launch_knn_prepare(a, w, side)) return 1;
