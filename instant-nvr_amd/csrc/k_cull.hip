@@ -37,6 +37,7 @@ __global__ void k_cull_cells(VolDev v, float thresh_hi, uint8_t* __restrict__ ma
 
 // distance channel of the pose-space volume at (px,py,pz): sample_volume_dev<1> (same arithmetic, bit for bit)
 // with the cell-mask early-out; returns +inf for samples in masked-out cells (they fail pn < thresh either way)
+template <typename IDX>        // IDX = uint32_t when dx*dy*dz*c < 2^31 (host-checked): 64-bit index multiplies are quarter rate
 __device__ __forceinline__ float cull_distance(const VolDev& v, const uint8_t* __restrict__ mask, float px, float py, float pz) {
     const float b0x = v.bounds[0], b0y = v.bounds[1], b0z = v.bounds[2];
     const float b1x = v.bounds[3], b1y = v.bounds[4], b1z = v.bounds[5];
@@ -51,7 +52,7 @@ __device__ __forceinline__ float cull_distance(const VolDev& v, const uint8_t* _
     iz = fminf(fmaxf(iz, 0.0f), (float)(v.dz - 1));
     const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
     const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
-    if (!mask[((int64_t)x0 * v.dy + y0) * v.dz + z0]) return __builtin_inff();
+    if (!mask[((IDX)x0 * (IDX)v.dy + (IDX)y0) * (IDX)v.dz + (IDX)z0]) return __builtin_inff();
     const float tx = ix - fx, ty = iy - fy, tz = iz - fz;
     const int x1 = min(x0 + 1, v.dx - 1), y1 = min(y0 + 1, v.dy - 1), z1 = min(z0 + 1, v.dz - 1);
     float out = 0.0f;
@@ -59,15 +60,18 @@ __device__ __forceinline__ float cull_distance(const VolDev& v, const uint8_t* _
     for (int k = 0; k < 8; ++k) {
         const int xx = (k & 4) ? x1 : x0, yy = (k & 2) ? y1 : y0, zz = (k & 1) ? z1 : z0;
         const float wk = ((k & 4) ? tx : 1.0f - tx) * ((k & 2) ? ty : 1.0f - ty) * ((k & 1) ? tz : 1.0f - tz);
-        out = fmaf(wk, v.data[(((int64_t)xx * v.dy + yy) * v.dz + zz) * v.c + (v.c - 1)], out);
+        out = fmaf(wk, v.data[(((IDX)xx * (IDX)v.dy + (IDX)yy) * (IDX)v.dz + (IDX)zz) * (IDX)v.c + (IDX)(v.c - 1)], out);
     }
     return out;
 }
 
 // tile of 1024 consecutive ray-samples per workgroup: sub-tile k holds samples base + k*256 + tid,
 // one 64-bit survivor mask per (sub-tile, wave): mask word index = tile*16 + k*4 + wave
-template <bool MASKED>
-__global__ __launch_bounds__(CULL_BLOCK) void k_cull_flag(RenderArgs a, Workspace w) {
+// FAST (rays, no jitter, N < 2^31, small volume): 32-bit sample / ray / volume indices — the generic path spends a
+// third of its instructions on a 64-bit division by S and 64-bit index multiplies (quarter-rate integer ops).  The
+// float arithmetic is the same op sequence as sample_pose_point / sample_z / linspace01, bit for bit.
+template <bool MASKED, bool FAST>
+__global__ __launch_bounds__(CULL_BLOCK) void k_cull_flag(RenderArgs a, Workspace w, double inv_S, float lin_step) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     __shared__ int cnt[CULL_PER * (CULL_BLOCK / 64)];
 #pragma unroll
@@ -76,10 +80,29 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_cull_flag(RenderArgs a, Workspac
         bool keep = false;
         if (i < a.N) {
             float px, py, pz, z;
-            sample_pose_point(a, i, px, py, pz, &z, nullptr);
+            if (FAST) {
+                const unsigned iu = (unsigned)i, S = (unsigned)a.S;
+                unsigned ray = (unsigned)((double)iu * inv_S);            // floor(i / S), possibly one too small
+                unsigned s = iu - ray * S;
+                if (s >= S) { ++ray; s -= S; }
+                const float near = a.near[ray], far = a.far[ray];
+                const float t = ((int)s < a.S / 2) ? lin_step * (float)(int)s : 1.0f - lin_step * (float)(a.S - 1 - (int)s);   // linspace01
+                z = near * (1.0f - t) + far * t;                          // sample_z
+                const unsigned r3 = ray * 3u;
+                const float dx = a.ray_d[r3], dy = a.ray_d[r3 + 1], dz = a.ray_d[r3 + 2];
+                const float wx = a.ray_o[r3] + dx * z, wy = a.ray_o[r3 + 1] + dy * z, wz = a.ray_o[r3 + 2] + dz * z;   // pts = o + d*z
+                const float* R = a.scene.R;
+                const float* Th = a.scene.Th;
+                const float qx = wx - Th[0], qy = wy - Th[1], qz = wz - Th[2];                                         // (p - Th) @ R
+                px = qx * R[0] + qy * R[3] + qz * R[6];
+                py = qx * R[1] + qy * R[4] + qz * R[7];
+                pz = qx * R[2] + qy * R[5] + qz * R[8];
+            } else {
+                sample_pose_point(a, i, px, py, pz, &z, nullptr);
+            }
             if (a.z_vals) a.z_vals[i] = z;
             float pn;
-            if (MASKED) pn = cull_distance(a.scene.pbw, w.cullmask, px, py, pz);
+            if (MASKED) pn = FAST ? cull_distance<uint32_t>(a.scene.pbw, w.cullmask, px, py, pz) : cull_distance<int64_t>(a.scene.pbw, w.cullmask, px, py, pz);
             else sample_volume_dev<1>(a.scene.pbw, a.scene.pbw.c - 1, px, py, pz, &pn);   // distance channel
             keep = pn < a.scene.thresh;                                               // :135
         }
@@ -175,12 +198,16 @@ int launch_cull(const RenderArgs& a, const Workspace& w, int64_t max_active, hip
     const VolDev& v = a.scene.pbw;
     const int64_t cells = (int64_t)v.dx * v.dy * v.dz;
     static const bool no_mask = getenv("INVR_NO_CULLMASK") != nullptr;
+    const double inv_S = 1.0 / (double)a.S;
+    const float lin_step = 1.0f / (float)(a.S - 1);                // linspace01's step, the same IEEE division
     if (cells <= CULL_MASK_MAX && a.N >= 4 * cells && !no_mask) {        // the mask pays for itself on full frames only
         hipLaunchKernelGGL(k_cull_cells, dim3((unsigned)cdiv(cells, 256)), dim3(256), 0, st, v, a.scene.thresh * (1.0f + 1e-5f), w.cullmask);
         INVR_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_cull_flag<true>, dim3((unsigned)nb), dim3(CULL_BLOCK), 0, st, a, w);
+        const bool fast = !a.wpts && !a.jitter && a.N < (1ll << 31) && cells * v.c < (1ll << 31) && a.S >= 2;
+        if (fast) hipLaunchKernelGGL((k_cull_flag<true, true>), dim3((unsigned)nb), dim3(CULL_BLOCK), 0, st, a, w, inv_S, lin_step);
+        else hipLaunchKernelGGL((k_cull_flag<true, false>), dim3((unsigned)nb), dim3(CULL_BLOCK), 0, st, a, w, inv_S, lin_step);
     } else {
-        hipLaunchKernelGGL(k_cull_flag<false>, dim3((unsigned)nb), dim3(CULL_BLOCK), 0, st, a, w);
+        hipLaunchKernelGGL((k_cull_flag<false, false>), dim3((unsigned)nb), dim3(CULL_BLOCK), 0, st, a, w, inv_S, lin_step);
     }
     INVR_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(SCAN_T), 0, st, w, nb, max_active);
