@@ -166,7 +166,9 @@ typedef struct InvrWsLayout {
     int64_t cap, lcap;
     int64_t counters;                      /* int32[16]: INVR_STAT_* layout                        */
     int64_t active_idx;                    /* int32[lcap]: ray-sample index of each survivor slot  */
-    int64_t slot_of_sample;                /* int32[n_rays*n_samples]: survivor slot or -1         */
+    int64_t word_off;                      /* int32[ceil(N/1024)*16]: rank of the first survivor of each 64-sample mask word */
+    int64_t mask;                          /* uint64[ceil(N/1024)*16]: survivor bit of ray-sample i = bit i&63 of word i>>6;
+                                              slot of a surviving sample = word_off[i>>6] + popcount(lower bits)     */
     int64_t pflags, farflags;              /* uint8[lcap]: bit p = (slot, part p) listed / far     */
     int64_t l_slot[INVR_NUM_PARTS];        /* int32[lcap]: survivor slot of each listed pair       */
     int64_t l_nn[INVR_NUM_PARTS];          /* int32[lcap*4]                                        */

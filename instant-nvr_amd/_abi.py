@@ -64,7 +64,7 @@ class InvrScene(C.Structure):
 
 class InvrWsLayout(C.Structure):
     _fields_ = [('cap', C.c_int64), ('lcap', C.c_int64), ('counters', C.c_int64), ('active_idx', C.c_int64),
-                ('slot_of_sample', C.c_int64), ('pflags', C.c_int64), ('farflags', C.c_int64),
+                ('word_off', C.c_int64), ('mask', C.c_int64), ('pflags', C.c_int64), ('farflags', C.c_int64),
                 ('l_slot', C.c_int64 * NUM_PARTS), ('l_nn', C.c_int64 * NUM_PARTS), ('l_w', C.c_int64 * NUM_PARTS),
                 ('l_x', C.c_int64 * NUM_PARTS), ('l_d', C.c_int64 * NUM_PARTS), ('l_r', C.c_int64 * NUM_PARTS),
                 ('emb', C.c_int64 * 2), ('raws', C.c_int64)]
@@ -181,7 +181,8 @@ def ws_views(ws, n_rays, S, max_active, n_active=None):
     v = {'cap': lay.cap, 'lcap': lc,
          'counters': view(lay.counters, 16, torch.int32),
          'active_idx': view(lay.active_idx, lc, torch.int32),
-         'slot_of_sample': view(lay.slot_of_sample, n_rays * S, torch.int32),
+         'word_off': view(lay.word_off, (n_rays * S + 1023) // 1024 * 16, torch.int32),
+         'mask': view(lay.mask, (n_rays * S + 1023) // 1024 * 16, torch.int64),
          'pflags': view(lay.pflags, lc, torch.uint8), 'farflags': view(lay.farflags, lc, torch.uint8),
          'raws': view(lay.raws, lc * NUM_PARTS * 4, torch.float32).view(lc, NUM_PARTS, 4)}
     for k in ('l_slot', 'l_x', 'l_d', 'l_r'):

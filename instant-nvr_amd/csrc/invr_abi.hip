@@ -186,7 +186,7 @@ static size_t carve(Workspace& w, void* base, int64_t N, int64_t cap) {
     w.block_cnt = c.take<int32_t>(nb);
     w.block_off = c.take<int32_t>(nb);
     w.active_idx = c.take<int32_t>(lc);
-    w.slot_of_sample = c.take<int32_t>(N);
+    w.word_off = c.take<int32_t>(nb * 16);
     w.pflags = c.take<uint8_t>(lc);
     w.farflags = c.take<uint8_t>(lc);
     for (int p = 0; p < INVR_NUM_PARTS; ++p) {
@@ -214,7 +214,7 @@ extern "C" int invr_workspace_layout(int64_t n_rays, int32_t n_samples, int64_t 
     carve(w, base, N > 0 ? N : 1, max_active);
     auto off = [&](const void* p) { return (int64_t)(reinterpret_cast<const char*>(p) - base); };
     o->cap = w.cap; o->lcap = w.lcap;
-    o->counters = off(w.counters); o->active_idx = off(w.active_idx); o->slot_of_sample = off(w.slot_of_sample);
+    o->counters = off(w.counters); o->active_idx = off(w.active_idx); o->word_off = off(w.word_off); o->mask = off(w.mask);
     o->pflags = off(w.pflags); o->farflags = off(w.farflags);
     for (int p = 0; p < INVR_NUM_PARTS; ++p) {
         o->l_slot[p] = off(w.l_slot[p]); o->l_nn[p] = off(w.l_nn[p]); o->l_w[p] = off(w.l_w[p]);

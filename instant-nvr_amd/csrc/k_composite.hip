@@ -29,13 +29,17 @@ struct DenseRaw {      // raw (R,S,4) given
     __device__ __forceinline__ float4 get(int64_t i) const { return raw[i]; }
 };
 struct MergedRaw {     // merge per-part results of the survivor slot of sample i
-    const int32_t* slot_of_sample;
+    const unsigned long long* mask;      // survivor bit of sample i: bit i&63 of word i>>6
+    const int32_t* word_off;             // rank of the first survivor of every word
     const uint8_t* pflags;
     const uint8_t* farflags;
     const float4* raws;
     int64_t const_slot;
     __device__ __forceinline__ float4 get(int64_t i) const {
-        const int slot = slot_of_sample[i];
+        const unsigned long long m = mask[i >> 6];
+        const int bit = (int)(i & 63);
+        int slot = ((m >> bit) & 1ull) ? word_off[i >> 6] + __popcll(m & ((1ull << bit) - 1ull)) : -1;
+        if (slot >= const_slot) slot = -1;                   // survivor beyond max_active (reported in stats[6])
         float4 best = make_float4(0.f, 0.f, 0.f, 0.f);
         if (slot >= 0) {
             const unsigned fl = pflags[slot], ff = farflags[slot];
@@ -97,7 +101,7 @@ int launch_composite(const float* raw, int64_t n_rays, int S, float* weights, fl
 int launch_merge_composite(const RenderArgs& a, const Workspace& w, float* rgb_map, float* acc_map, float* raw,
                            float* occ, float* weights, hipStream_t st) {
     if (a.R == 0) return 0;
-    MergedRaw src{w.slot_of_sample, w.pflags, w.farflags, w.raws, w.cap};
+    MergedRaw src{w.mask, w.word_off, w.pflags, w.farflags, w.raws, w.cap};
     hipLaunchKernelGGL(k_composite<MergedRaw>, dim3((unsigned)cdiv(a.R, CMP_BLOCK / 64)), dim3(CMP_BLOCK), 0, st,
                        src, a.R, a.S, weights, rgb_map, acc_map, reinterpret_cast<float4*>(raw), occ);
     INVR_LAUNCH_CHECK();

@@ -181,14 +181,8 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_compact(RenderArgs a, Workspace 
         const unsigned long long m = mk[k * (CULL_BLOCK / 64) + wv];
         const bool keep = (m >> lane) & 1ull;
         const int rank = woff + __popcll(m & ((1ull << lane) - 1ull));
-        if (i < a.N) {
-            int slot = -1;
-            if (keep && rank < max_active) {
-                slot = rank;
-                w.active_idx[rank] = (int32_t)i;
-            }
-            w.slot_of_sample[i] = slot;
-        }
+        if (lane == 0) w.word_off[(int64_t)blockIdx.x * (CULL_TILE / 64) + k * (CULL_BLOCK / 64) + wv] = woff;
+        if (i < a.N && keep && rank < max_active) w.active_idx[rank] = (int32_t)i;
         for (int j = 0; j < CULL_BLOCK / 64; ++j) off += __popcll(mk[k * (CULL_BLOCK / 64) + j]);
     }
 }

@@ -42,7 +42,8 @@ struct Workspace {
     int32_t* block_off;           // ceil(N/256)
     int32_t* counters;            // CNT_LEN
     int32_t* active_idx;          // cap: ray-sample index of every survivor (ordered)
-    int32_t* slot_of_sample;      // N: survivor slot or -1
+    int32_t* word_off;            // ceil(N/64): rank of the first survivor of every 64-sample mask word (slot of sample i =
+                                  // word_off[i>>6] + popcount(mask[i>>6] below bit i&63); 2 MB instead of a 131 MB slot-per-sample array)
     uint8_t* pflags;              // cap: bit p set if (slot, part p) is flagged and listed
     uint8_t* farflags;            // cap: bit p set if (slot, part p) is a far pair (takes the part constant)
     KnnIndex knn;
