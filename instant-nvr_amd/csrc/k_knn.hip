@@ -352,12 +352,27 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w, 
         float px = 0, py = 0, pz = 0;
         if (live) sample_pose_point(a, w.active_idx[slot], px, py, pz, nullptr, nullptr);
         unsigned flags = 0, farflags = 0;
+        // class of the lattice cell the point lies in (0 = undecided for every part when outside / disabled)
+        unsigned vcls = 0;
+        if (ix.voxcls && live) {
+            const VolDev& v = a.scene.pbw;
+            const float ux = (px - v.bounds[0]) / (v.bounds[3] - v.bounds[0]) * (float)(v.dx - 1);
+            const float uy = (py - v.bounds[1]) / (v.bounds[4] - v.bounds[1]) * (float)(v.dy - 1);
+            const float uz = (pz - v.bounds[2]) / (v.bounds[5] - v.bounds[2]) * (float)(v.dz - 1);
+            if (ux >= 0.0f && uy >= 0.0f && uz >= 0.0f && ux <= (float)(v.dx - 1) && uy <= (float)(v.dy - 1) && uz <= (float)(v.dz - 1))
+                vcls = ix.voxcls[((int)ux * v.dy + (int)uy) * v.dz + (int)uz];
+        }
         int4 res_nn[INVR_NUM_PARTS];
         float4 res_w[INVR_NUM_PARTS];
 #pragma unroll
         for (int p = 0; p < INVR_NUM_PARTS; ++p) {
             const int len = L.len[p];
             if (len < KNN_K) continue;                     // reference: inf distances -> NaN dist -> unflagged
+            const unsigned c2 = (vcls >> (2 * p)) & 3u;
+            if (__ballot(live && c2 == 0) == 0) {                   // every live lane sits in a decided cell
+                if (c2 == 1) farflags |= 1u << p;
+                continue;
+            }
             const float* bb = ix.part_aabb + p * 6;
             const float lbp = aabb_dist2(px, py, pz, make_float4(bb[0], bb[1], bb[2], 0.f), make_float4(bb[3], bb[4], bb[5], 0.f));
             if (__ballot(live && !(lbp > KNN_DFAR2)) == 0) {          // whole wave far from this part
@@ -472,6 +487,59 @@ __global__ void k_append_const_pairs(Workspace w) {
     reinterpret_cast<float4*>(w.l_w[p])[pos] = make_float4(0.f, 0.f, 0.f, 0.f);
     w.counters[CNT_PAIRS + p] = pos + 1;
     if (p == 0) w.active_idx[w.cap] = 0;
+}
+
+// Per-frame classification of the distance-volume lattice cells (side stream, after k_part_prepare): for every cell
+// and part, from the box-to-box distance to the cluster AABBs and the cell-centre distance to the cluster
+// representatives, whether EVERY point of the cell is a far pair (lower bound > 0.68 m) or provably unflagged
+// (lower bound >= near_hi and some vertex within band_lo) — the same two tests k_knn_pairs applies per point, so a
+// definite cell class is exactly what the per-point classification would conclude; undecided cells (class 0) and
+// points outside the lattice run the per-point cluster loop.  17x fewer cells than survivors on the bench frame.
+__global__ void k_knn_voxel_class(SceneDev s, KnnIndex ix) {
+    const VolDev& v = s.pbw;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= v.dx * v.dy * v.dz) return;
+    const int z0 = idx % v.dz, y0 = (idx / v.dz) % v.dy, x0 = idx / (v.dz * v.dy);
+    const int c0[3] = {x0, y0, z0}, dims[3] = {v.dx, v.dy, v.dz};
+    float lo[3], hi[3], ce[3], h2 = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float b0 = v.bounds[a], e = v.bounds[3 + a] - b0, den = (float)(dims[a] - 1);
+        lo[a] = b0 + e * ((float)c0[a] / den) - 1e-4f;                        // inflated: the point -> cell map below is approximate
+        hi[a] = b0 + e * ((float)min(c0[a] + 1, dims[a] - 1) / den) + 1e-4f;
+        ce[a] = 0.5f * (lo[a] + hi[a]);
+        h2 += 0.25f * (hi[a] - lo[a]) * (hi[a] - lo[a]);
+    }
+    const float h = sqrtf(h2) * 1.0001f;
+    unsigned cls = 0;
+    for (int p = 0; p < INVR_NUM_PARTS; ++p) {
+        const int len = min((int)s.lengths2[p], PREP_MAX), ncl = (len + 63) >> 6;
+        float lb2 = __builtin_inff(), ub2 = __builtin_inff();
+        for (int c = 0; c < ncl; ++c) {
+            const float4 klo = ix.cl[((int64_t)p * ix.cpad + c) * 3], khi = ix.cl[((int64_t)p * ix.cpad + c) * 3 + 1];
+            const float4 rep = ix.cl[((int64_t)p * ix.cpad + c) * 3 + 2];
+            const float gx = fmaxf(fmaxf(klo.x - hi[0], lo[0] - khi.x), 0.0f);
+            const float gy = fmaxf(fmaxf(klo.y - hi[1], lo[1] - khi.y), 0.0f);
+            const float gz = fmaxf(fmaxf(klo.z - hi[2], lo[2] - khi.z), 0.0f);
+            lb2 = fminf(lb2, (gx * gx + gy * gy + gz * gz) * 0.9999f);
+            const float dx = ce[0] - rep.x, dy = ce[1] - rep.y, dz = ce[2] - rep.z;
+            const float u = sqrtf(dx * dx + dy * dy + dz * dz) + h;
+            ub2 = fminf(ub2, u * u * 1.0001f);
+        }
+        if (len >= KNN_K) {
+            if (lb2 > KNN_DFAR2) cls |= 1u << (2 * p);
+            else if (lb2 >= s.near_hi2 && ub2 <= s.band_lo2) cls |= 2u << (2 * p);
+        }
+    }
+    ix.voxcls[idx] = (uint16_t)cls;
+}
+
+int launch_knn_voxel_class(const RenderArgs& a, const Workspace& w, hipStream_t st) {
+    const VolDev& v = a.scene.pbw;
+    const int64_t cells = (int64_t)v.dx * v.dy * v.dz;
+    hipLaunchKernelGGL(k_knn_voxel_class, dim3((unsigned)cdiv(cells, 256)), dim3(256), 0, st, a.scene, w.knn);
+    INVR_LAUNCH_CHECK();
+    return 0;
 }
 
 // The per-frame KNN index only depends on the posed vertices, not on the rays: it is built on a side stream

@@ -30,6 +30,7 @@ struct KnnIndex {
     float4* cl;          // P*cpad*3 : per 64-vertex cluster {AABB min, AABB max, first vertex (an upper
                          //            bound of the nearest distance)}
     float* part_aabb;    // P*6
+    uint16_t* voxcls;    // per cell of the distance-volume lattice: 2 bits per part (0 maybe, 1 far, 2 unflagged); NULL = off
     float4* vmat;        // P*mpad*6 : per vertex, rows 0..2 of sum_j pbw[v][j] A_j and of sum_j pbw[v][j] big_A_j
     int32_t mpad, cpad;
 };
@@ -110,6 +111,7 @@ __device__ __forceinline__ void sample_pose_point(const RenderArgs& a, int64_t i
 int launch_cull(const RenderArgs& a, const Workspace& w, int64_t max_active, hipStream_t st);
 int launch_knn_prepare(const RenderArgs& a, const Workspace& w, hipStream_t st);
 int launch_vertex_mats(const RenderArgs& a, const Workspace& w, hipStream_t st);
+int launch_knn_voxel_class(const RenderArgs& a, const Workspace& w, hipStream_t st);
 int launch_knn_pairs(const RenderArgs& a, const Workspace& w, hipStream_t st);
 int launch_warp_pairs(const RenderArgs& a, const Workspace& w, const GridDev& dg, const MlpDev& dm, hipStream_t st);
 int launch_part_encode(const GridDev& g, const float* x_soa, int64_t stride, const int32_t* count, int64_t cap,
