@@ -130,6 +130,15 @@ __device__ __forceinline__ void sincos_f(float a, float* sn, float* cs) {
     *cs = ((q + 1) & 2) ? -cc : cc;
 }
 
+// sin and cos on the hardware pipes (v_sin_f32 / v_cos_f32 take revolutions): 3 issue slots instead of ~20.  The scaling
+// multiply costs up to |a| * 1e-8 revolutions = 6e-8 |a| rad, the pipes ~1e-6 absolute: |error| <= 2e-6 for the view-direction
+// encoding's arguments (|a| <= 8 |d|) — used where the value only feeds an MLP input (weights O(0.1), pixel budget 1e-4).
+__device__ __forceinline__ void sincos_hw(float a, float* sn, float* cs) {
+    const float r = a * 0.15915494309189535f;
+    *sn = __builtin_amdgcn_sinf(r);
+    *cs = __builtin_amdgcn_cosf(r);
+}
+
 // torch.linspace(0,1,S)[i] in float32 (symmetric fill used by ATen's CPU/GPU kernels)
 __device__ __forceinline__ float linspace01(int i, int S) {
     float step = 1.0f / (float)(S - 1);

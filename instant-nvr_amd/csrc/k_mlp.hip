@@ -97,7 +97,7 @@ __device__ __forceinline__ void mlp_part(float* lds, const PartMlpDev& pm, const
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 float sn, cs;
-                sincos_f(dv[cb][c] * fmul, &sn, &cs);
+                sincos_hw(dv[cb][c] * fmul, &sn, &cs);
                 kb[cb][5 + 2 * c] = sn;
                 kb[cb][6 + 2 * c] = cs;
             }

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(MLP_BLOCK, 1) void k_part_mlp_bwd(PartMlpDev pm, co
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             float sn, cs;
-            sincos_f(dv[c] * fmul, &sn, &cs);
+            sincos_hw(dv[c] * fmul, &sn, &cs);
             kb[5 + 2 * c] = sn;
             kb[6 + 2 * c] = cs;
         }
