@@ -108,13 +108,17 @@ __device__ __forceinline__ f32x4 bias4(const float* b, int mt, int g) {
 }
 // dot of the 16 hidden values this lane holds with slot-ordered head weights, summed over the 4 lane groups
 __device__ __forceinline__ float head_dot(const f32x4* h, const float* wv, int g) {
-    float acc = 0.0f;
+    // two products per issue slot (v_pk_fma_f32); the slot-ordered weights of this lane group are 16 contiguous floats
+    const mlp_v2f* w2 = reinterpret_cast<const mlp_v2f*>(wv + g * 16);
+    mlp_v2f acc = {0.0f, 0.0f};
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc = fmaf(wv[g * 16 + mt * 4 + r], h[mt][r], acc);
-    acc += __shfl_xor(acc, 16);
-    acc += __shfl_xor(acc, 32);
-    return acc;
+    for (int mt = 0; mt < 4; ++mt) {
+        const mlp_v2f lo = {h[mt][0], h[mt][1]}, hi = {h[mt][2], h[mt][3]};
+        acc = __builtin_elementwise_fma(w2[mt * 2], lo, acc);
+        acc = __builtin_elementwise_fma(w2[mt * 2 + 1], hi, acc);
+    }
+    float r = acc.x + acc.y;
+    r += __shfl_xor(r, 16);
+    r += __shfl_xor(r, 32);
+    return r;
 }
-
