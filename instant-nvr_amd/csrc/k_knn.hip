@@ -354,13 +354,14 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w, 
         unsigned flags = 0, farflags = 0;
         // class of the lattice cell the point lies in (0 = undecided for every part when outside / disabled)
         unsigned vcls = 0;
+        int vcell = -1;
         if (ix.voxcls && live) {
             const VolDev& v = a.scene.pbw;
             const float ux = (px - v.bounds[0]) / (v.bounds[3] - v.bounds[0]) * (float)(v.dx - 1);
             const float uy = (py - v.bounds[1]) / (v.bounds[4] - v.bounds[1]) * (float)(v.dy - 1);
             const float uz = (pz - v.bounds[2]) / (v.bounds[5] - v.bounds[2]) * (float)(v.dz - 1);
             if (ux >= 0.0f && uy >= 0.0f && uz >= 0.0f && ux <= (float)(v.dx - 1) && uy <= (float)(v.dy - 1) && uz <= (float)(v.dz - 1))
-                vcls = ix.voxcls[((int)ux * v.dy + (int)uy) * v.dz + (int)uz];
+                vcell = ((int)ux * v.dy + (int)uy) * v.dz + (int)uz, vcls = ix.voxcls[vcell];
         }
         int4 res_nn[INVR_NUM_PARTS];
         float4 res_w[INVR_NUM_PARTS];
@@ -382,24 +383,48 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w, 
             const int ncl = (len + 63) >> 6;
             const float4* cl = lds + L.coff[p];                       // records {lo, hi, rep}
             const float4* sv = lds + L.voff[p];
+            // candidate clusters of the wave: OR of the lattice-cell masks of its undecided lanes (all ones when a lane is
+            // outside the lattice, the masks are off or the part has more than 64 clusters).  Lanes in decided cells take the
+            // cell's class and request nothing.
+            const bool maybe = live && c2 == 0;
+            unsigned long long mym = 0ull;
+            if (maybe) mym = (ix.voxmask && vcell >= 0) ? ix.voxmask[(int64_t)vcell * INVR_NUM_PARTS + p] : ~0ull;
+            unsigned mlo = (unsigned)mym, mhi = (unsigned)(mym >> 32);
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { mlo |= __shfl_xor(mlo, d); mhi |= __shfl_xor(mhi, d); }
+            const unsigned long long M = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)mhi) << 32) |
+                                         (unsigned)__builtin_amdgcn_readfirstlane((int)mlo);
+            const bool full = M == ~0ull || ncl > 64;
+            const unsigned long long Mc = ncl >= 64 ? M : (M & ((1ull << ncl) - 1ull));
             // bounds on the nearest-vertex distance from the cluster records
             float lb2 = __builtin_inff(), ub2 = __builtin_inff();
             int seed = 0;
-            for (int c0 = 0; c0 < ncl; c0 += 4) {
-                float4 rec[12];
+            if (full) {
+                for (int c0 = 0; c0 < ncl; c0 += 4) {
+                    float4 rec[12];
 #pragma unroll
-                for (int k = 0; k < 12; ++k) rec[k] = lds_ld4(cl + min(c0 + k / 3, ncl - 1) * 3 + (k % 3));    // wave-uniform
+                    for (int k = 0; k < 12; ++k) rec[k] = lds_ld4(cl + min(c0 + k / 3, ncl - 1) * 3 + (k % 3));    // wave-uniform
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float4 r = rec[k * 3 + 2];
+                    for (int k = 0; k < 4; ++k) {
+                        const float4 r = rec[k * 3 + 2];
+                        const float dx = px - r.x, dy = py - r.y, dz = pz - r.z;
+                        const float u = dx * dx + dy * dy + dz * dz;
+                        if (u < ub2) { ub2 = u; seed = min(c0 + k, ncl - 1); }
+                        lb2 = fminf(lb2, aabb_dist2(px, py, pz, rec[k * 3], rec[k * 3 + 1]));
+                    }
+                }
+            } else {
+                for (unsigned long long it = Mc; it; it &= it - 1ull) {
+                    const int c = __ffsll((long long)it) - 1;
+                    const float4 klo = lds_ld4(cl + c * 3), khi = lds_ld4(cl + c * 3 + 1), r = lds_ld4(cl + c * 3 + 2);
                     const float dx = px - r.x, dy = py - r.y, dz = pz - r.z;
                     const float u = dx * dx + dy * dy + dz * dz;
-                    if (u < ub2) { ub2 = u; seed = min(c0 + k, ncl - 1); }
-                    lb2 = fminf(lb2, aabb_dist2(px, py, pz, rec[k * 3], rec[k * 3 + 1]));
+                    if (u < ub2) { ub2 = u; seed = c; }
+                    lb2 = fminf(lb2, aabb_dist2(px, py, pz, klo, khi));
                 }
             }
-            const bool is_far = lb2 > KNN_DFAR2;
-            const bool unflagged = lb2 >= a.scene.near_hi2 && ub2 <= a.scene.band_lo2;
+            const bool is_far = maybe ? lb2 > KNN_DFAR2 : (live && c2 == 1);
+            const bool unflagged = maybe ? (lb2 >= a.scene.near_hi2 && ub2 <= a.scene.band_lo2) : (c2 == 2);
             const bool scan = live && !is_far && !unflagged;
             if (live && is_far) farflags |= 1u << p;
             if (__ballot(scan) == 0 || (dbg & 1)) continue;
@@ -420,6 +445,7 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w, 
                 for (int side = 0; side < 2; ++side) {
                     const int c = side ? seed_c - k : seed_c + k;
                     if (c < 0 || c >= ncl) continue;
+                    if (!full && !((Mc >> c) & 1ull)) continue;                   // no lane of the wave can have a neighbour there
                     const bool need = scan && aabb_dist2(px, py, pz, lds_ld4(cl + c * 3), lds_ld4(cl + c * 3 + 1)) <= t.worst();
                     if (__ballot(need) == 0) continue;
 #pragma unroll 1
@@ -500,6 +526,19 @@ __global__ void k_knn_voxel_class(SceneDev s, KnnIndex ix) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= v.dx * v.dy * v.dz) return;
     const int z0 = idx % v.dz, y0 = (idx / v.dz) % v.dy, x0 = idx / (v.dz * v.dy);
+    {   // survivors of the cull only exist in cells with a corner below the threshold (the trilinear value is a convex
+        // combination of the corners, k_cull.hip): all other cells are never looked up — 93 % of the lattice on the bench frame
+        const int x1 = min(x0 + 1, v.dx - 1), y1 = min(y0 + 1, v.dy - 1), z1 = min(z0 + 1, v.dz - 1);
+        float m = __builtin_inff();
+        bool nan = false;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float d = v.data[((((int64_t)((k & 4) ? x1 : x0)) * v.dy + ((k & 2) ? y1 : y0)) * v.dz + ((k & 1) ? z1 : z0)) * v.c + (v.c - 1)];
+            nan = nan || d != d;
+            m = fminf(m, d);
+        }
+        if (!(m < s.thresh * (1.0f + 1e-5f) || nan)) return;
+    }
     const int c0[3] = {x0, y0, z0}, dims[3] = {v.dx, v.dy, v.dz};
     float lo[3], hi[3], ce[3], h2 = 0.0f;
 #pragma unroll
@@ -526,9 +565,42 @@ __global__ void k_knn_voxel_class(SceneDev s, KnnIndex ix) {
             const float u = sqrtf(dx * dx + dy * dy + dz * dz) + h;
             ub2 = fminf(ub2, u * u * 1.0001f);
         }
+        unsigned pc = 0;
         if (len >= KNN_K) {
-            if (lb2 > KNN_DFAR2) cls |= 1u << (2 * p);
-            else if (lb2 >= s.near_hi2 && ub2 <= s.band_lo2) cls |= 2u << (2 * p);
+            if (lb2 > KNN_DFAR2) pc = 1;
+            else if (lb2 >= s.near_hi2 && ub2 <= s.band_lo2) pc = 2;
+        }
+        cls |= pc << (2 * p);
+        if (ix.voxmask) {
+            // undecided cell: which clusters can hold one of the 4 nearest vertices of ANY point x of the cell?  d4(x) <=
+            // D4(centre) + h, so only clusters whose box comes within that of the cell box; the cluster of x's nearest
+            // vertex is always among them, so min-over-candidates of the per-point box bounds equals the min over all.
+            unsigned long long mask = ~0ull;
+            if (pc == 0 && len >= KNN_K && ncl <= 64 && s.thresh < 1e8f) {      // (dense stress mode: every cell holds survivors, masks off)
+                // upper bound of the 4th-nearest distance from the cell centre: every 16-vertex sub-cluster box with >= 4 real
+                // vertices holds 4 vertices within the distance to its farthest corner
+                float k3 = __builtin_inff();
+                for (int c = 0; c < ncl; ++c)
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        if (len - (c * 64 + s4 * 16) < KNN_K) continue;
+                        const float4 slo = ix.sub[((int64_t)p * ix.cpad + c) * 8 + s4 * 2], shi = ix.sub[((int64_t)p * ix.cpad + c) * 8 + s4 * 2 + 1];
+                        const float fx = fmaxf(fabsf(ce[0] - slo.x), fabsf(ce[0] - shi.x));
+                        const float fy = fmaxf(fabsf(ce[1] - slo.y), fabsf(ce[1] - shi.y));
+                        const float fz = fmaxf(fabsf(ce[2] - slo.z), fabsf(ce[2] - shi.z));
+                        k3 = fminf(k3, (fx * fx + fy * fy + fz * fz) * 1.0001f);
+                    }
+                const float u = sqrtf(k3) + h;
+                const float u2 = u * u * 1.0002f;
+                mask = 0ull;
+                for (int c = 0; c < ncl; ++c) {
+                    const float4 klo = ix.cl[((int64_t)p * ix.cpad + c) * 3], khi = ix.cl[((int64_t)p * ix.cpad + c) * 3 + 1];
+                    const float gx = fmaxf(fmaxf(klo.x - hi[0], lo[0] - khi.x), 0.0f);
+                    const float gy = fmaxf(fmaxf(klo.y - hi[1], lo[1] - khi.y), 0.0f);
+                    const float gz = fmaxf(fmaxf(klo.z - hi[2], lo[2] - khi.z), 0.0f);
+                    if ((gx * gx + gy * gy + gz * gz) * 0.9999f <= u2) mask |= 1ull << c;
+                }
+            }
+            ix.voxmask[(int64_t)idx * INVR_NUM_PARTS + p] = mask;
         }
     }
     ix.voxcls[idx] = (uint16_t)cls;

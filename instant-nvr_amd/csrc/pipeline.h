@@ -5,6 +5,7 @@
 enum { CNT_ACTIVE = 0, CNT_PAIRS = 1 /* ..5 */, CNT_OVERFLOW = 6, CNT_FAR = 7 /* ..11 */, CNT_TICKET = 12, CNT_LEN = 16 };
 
 #define CULL_MASK_MAX (4 << 20)   // cells of the per-frame cull mask (bytes); larger distance volumes run unmasked
+#define VOXMASK_MAX_CELLS (1 << 20)  // lattice cells with per-part candidate-cluster masks (40 B each)
 #define DF_SLICE_MAX 4096  // float2 entries of the deformer's per-frame (u,v) slice tables (32 KB of LDS)
 #define EMB_K 20            // 19-d encoder output padded to 5 MFMA k-steps
 
@@ -30,6 +31,8 @@ struct KnnIndex {
     float4* cl;          // P*cpad*3 : per 64-vertex cluster {AABB min, AABB max, first vertex (an upper
                          //            bound of the nearest distance)}
     float* part_aabb;    // P*6
+    unsigned long long* voxmask;  // per lattice cell and part: bit c set if cluster c can hold one of the 4 nearest vertices of a
+                         //            point of the cell (undecided cells of parts with <= 64 clusters; all ones otherwise); NULL = off
     uint16_t* voxcls;    // per cell of the distance-volume lattice: 2 bits per part (0 maybe, 1 far, 2 unflagged); NULL = off
     float4* vmat;        // P*mpad*6 : per vertex, rows 0..2 of sum_j pbw[v][j] A_j and of sum_j pbw[v][j] big_A_j
     int32_t mpad, cpad;
