@@ -182,7 +182,7 @@ static size_t carve(Workspace& w, void* base, int64_t N, int64_t cap) {
     w.knn.cl = c.take<float4>((size_t)INVR_NUM_PARTS * w.knn.cpad * 3);
     w.knn.sub = c.take<float4>((size_t)INVR_NUM_PARTS * w.knn.cpad * 8);
     w.knn.vmat = c.take<float4>((size_t)INVR_NUM_PARTS * w.knn.mpad * 6);
-    w.knn.voxcls = c.take<uint16_t>(CULL_MASK_MAX);
+    w.knn.voxcls = c.take<uint8_t>((size_t)VOXMASK_MAX_CELLS * INVR_NUM_PARTS);
     w.knn.voxmask = c.take<unsigned long long>((size_t)VOXMASK_MAX_CELLS * INVR_NUM_PARTS);
     w.mask = c.take<unsigned long long>(nb * 16);
     w.block_cnt = c.take<int32_t>(nb);
@@ -303,8 +303,8 @@ static int render_impl(const InvrScene* scene, const InvrModel* model,
     INVR_HIP(hipStreamWaitEvent(side, ev_fork, 0));
     if (launch_knn_prepare(a, w, side)) return 1;
     if (launch_vertex_mats(a, w, side)) return 1;
-    if ((int64_t)a.scene.pbw.dx * a.scene.pbw.dy * a.scene.pbw.dz > VOXMASK_MAX_CELLS || getenv("INVR_NO_VOXMASK")) w.knn.voxmask = nullptr;
-    if ((int64_t)a.scene.pbw.dx * a.scene.pbw.dy * a.scene.pbw.dz > CULL_MASK_MAX || getenv("INVR_NO_VOXCLS")) { w.knn.voxcls = nullptr; w.knn.voxmask = nullptr; }
+    if (getenv("INVR_NO_VOXMASK")) w.knn.voxmask = nullptr;
+    if ((int64_t)a.scene.pbw.dx * a.scene.pbw.dy * a.scene.pbw.dz > VOXMASK_MAX_CELLS || getenv("INVR_NO_VOXCLS")) { w.knn.voxcls = nullptr; w.knn.voxmask = nullptr; }
     else if (launch_knn_voxel_class(a, w, side)) return 1;
     INVR_HIP(hipEventRecord(ev_join, side));
     {

@@ -353,7 +353,6 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w, 
         if (live) sample_pose_point(a, w.active_idx[slot], px, py, pz, nullptr, nullptr);
         unsigned flags = 0, farflags = 0;
         // class of the lattice cell the point lies in (0 = undecided for every part when outside / disabled)
-        unsigned vcls = 0;
         int vcell = -1;
         if (ix.voxcls && live) {
             const VolDev& v = a.scene.pbw;
@@ -361,7 +360,7 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w, 
             const float uy = (py - v.bounds[1]) / (v.bounds[4] - v.bounds[1]) * (float)(v.dy - 1);
             const float uz = (pz - v.bounds[2]) / (v.bounds[5] - v.bounds[2]) * (float)(v.dz - 1);
             if (ux >= 0.0f && uy >= 0.0f && uz >= 0.0f && ux <= (float)(v.dx - 1) && uy <= (float)(v.dy - 1) && uz <= (float)(v.dz - 1))
-                vcell = ((int)ux * v.dy + (int)uy) * v.dz + (int)uz, vcls = ix.voxcls[vcell];
+                vcell = ((int)ux * v.dy + (int)uy) * v.dz + (int)uz;
         }
         int4 res_nn[INVR_NUM_PARTS];
         float4 res_w[INVR_NUM_PARTS];
@@ -369,7 +368,7 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w, 
         for (int p = 0; p < INVR_NUM_PARTS; ++p) {
             const int len = L.len[p];
             if (len < KNN_K) continue;                     // reference: inf distances -> NaN dist -> unflagged
-            const unsigned c2 = (vcls >> (2 * p)) & 3u;
+            const unsigned c2 = vcell >= 0 ? ix.voxcls[(int64_t)vcell * INVR_NUM_PARTS + p] : 0u;
             if (__ballot(live && c2 == 0) == 0) {                   // every live lane sits in a decided cell
                 if (c2 == 1) farflags |= 1u << p;
                 continue;
@@ -550,8 +549,8 @@ __global__ void k_knn_voxel_class(SceneDev s, KnnIndex ix) {
         h2 += 0.25f * (hi[a] - lo[a]) * (hi[a] - lo[a]);
     }
     const float h = sqrtf(h2) * 1.0001f;
-    unsigned cls = 0;
-    for (int p = 0; p < INVR_NUM_PARTS; ++p) {
+    {
+        const int p = blockIdx.y;                       // one thread per (cell, part)
         const int len = min((int)s.lengths2[p], PREP_MAX), ncl = (len + 63) >> 6;
         float lb2 = __builtin_inff(), ub2 = __builtin_inff();
         for (int c = 0; c < ncl; ++c) {
@@ -570,7 +569,7 @@ __global__ void k_knn_voxel_class(SceneDev s, KnnIndex ix) {
             if (lb2 > KNN_DFAR2) pc = 1;
             else if (lb2 >= s.near_hi2 && ub2 <= s.band_lo2) pc = 2;
         }
-        cls |= pc << (2 * p);
+        ix.voxcls[(int64_t)idx * INVR_NUM_PARTS + p] = (uint8_t)pc;
         if (ix.voxmask) {
             // undecided cell: which clusters can hold one of the 4 nearest vertices of ANY point x of the cell?  d4(x) <=
             // D4(centre) + h, so only clusters whose box comes within that of the cell box; the cluster of x's nearest
@@ -603,13 +602,12 @@ __global__ void k_knn_voxel_class(SceneDev s, KnnIndex ix) {
             ix.voxmask[(int64_t)idx * INVR_NUM_PARTS + p] = mask;
         }
     }
-    ix.voxcls[idx] = (uint16_t)cls;
 }
 
 int launch_knn_voxel_class(const RenderArgs& a, const Workspace& w, hipStream_t st) {
     const VolDev& v = a.scene.pbw;
     const int64_t cells = (int64_t)v.dx * v.dy * v.dz;
-    hipLaunchKernelGGL(k_knn_voxel_class, dim3((unsigned)cdiv(cells, 256)), dim3(256), 0, st, a.scene, w.knn);
+    hipLaunchKernelGGL(k_knn_voxel_class, dim3((unsigned)cdiv(cells, 256), INVR_NUM_PARTS), dim3(256), 0, st, a.scene, w.knn);
     INVR_LAUNCH_CHECK();
     return 0;
 }
