@@ -522,6 +522,15 @@ __global__ void k_append_const_pairs(Workspace w) {
 // points outside the lattice run the per-point cluster loop.  17x fewer cells than survivors on the bench frame.
 __global__ void k_knn_voxel_class(SceneDev s, KnnIndex ix) {
     const VolDev& v = s.pbw;
+    // cluster {lo, hi, rep} and sub-cluster {lo, hi} records of this block's part, staged once (wave-uniform reads below)
+    __shared__ float4 s_cl[(PREP_MAX / 64) * 3];
+    __shared__ float4 s_sub[(PREP_MAX / 64) * 8];
+    {
+        const int pp = blockIdx.y, ncl_p = (min((int)s.lengths2[pp], PREP_MAX) + 63) >> 6;
+        for (int j = threadIdx.x; j < ncl_p * 3; j += blockDim.x) s_cl[j] = ix.cl[(int64_t)pp * ix.cpad * 3 + j];
+        for (int j = threadIdx.x; j < ncl_p * 8; j += blockDim.x) s_sub[j] = ix.sub[(int64_t)pp * ix.cpad * 8 + j];
+    }
+    __syncthreads();
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= v.dx * v.dy * v.dz) return;
     const int z0 = idx % v.dz, y0 = (idx / v.dz) % v.dy, x0 = idx / (v.dz * v.dy);
@@ -554,8 +563,8 @@ __global__ void k_knn_voxel_class(SceneDev s, KnnIndex ix) {
         const int len = min((int)s.lengths2[p], PREP_MAX), ncl = (len + 63) >> 6;
         float lb2 = __builtin_inff(), ub2 = __builtin_inff();
         for (int c = 0; c < ncl; ++c) {
-            const float4 klo = ix.cl[((int64_t)p * ix.cpad + c) * 3], khi = ix.cl[((int64_t)p * ix.cpad + c) * 3 + 1];
-            const float4 rep = ix.cl[((int64_t)p * ix.cpad + c) * 3 + 2];
+            const float4 klo = s_cl[c * 3], khi = s_cl[c * 3 + 1];
+            const float4 rep = s_cl[c * 3 + 2];
             const float gx = fmaxf(fmaxf(klo.x - hi[0], lo[0] - khi.x), 0.0f);
             const float gy = fmaxf(fmaxf(klo.y - hi[1], lo[1] - khi.y), 0.0f);
             const float gz = fmaxf(fmaxf(klo.z - hi[2], lo[2] - khi.z), 0.0f);
@@ -582,7 +591,7 @@ __global__ void k_knn_voxel_class(SceneDev s, KnnIndex ix) {
                 for (int c = 0; c < ncl; ++c)
                     for (int s4 = 0; s4 < 4; ++s4) {
                         if (len - (c * 64 + s4 * 16) < KNN_K) continue;
-                        const float4 slo = ix.sub[((int64_t)p * ix.cpad + c) * 8 + s4 * 2], shi = ix.sub[((int64_t)p * ix.cpad + c) * 8 + s4 * 2 + 1];
+                        const float4 slo = s_sub[c * 8 + s4 * 2], shi = s_sub[c * 8 + s4 * 2 + 1];
                         const float fx = fmaxf(fabsf(ce[0] - slo.x), fabsf(ce[0] - shi.x));
                         const float fy = fmaxf(fabsf(ce[1] - slo.y), fabsf(ce[1] - shi.y));
                         const float fz = fmaxf(fabsf(ce[2] - slo.z), fabsf(ce[2] - shi.z));
@@ -592,7 +601,7 @@ __global__ void k_knn_voxel_class(SceneDev s, KnnIndex ix) {
                 const float u2 = u * u * 1.0002f;
                 mask = 0ull;
                 for (int c = 0; c < ncl; ++c) {
-                    const float4 klo = ix.cl[((int64_t)p * ix.cpad + c) * 3], khi = ix.cl[((int64_t)p * ix.cpad + c) * 3 + 1];
+                    const float4 klo = s_cl[c * 3], khi = s_cl[c * 3 + 1];
                     const float gx = fmaxf(fmaxf(klo.x - hi[0], lo[0] - khi.x), 0.0f);
                     const float gy = fmaxf(fmaxf(klo.y - hi[1], lo[1] - khi.y), 0.0f);
                     const float gz = fmaxf(fmaxf(klo.z - hi[2], lo[2] - khi.z), 0.0f);
