@@ -184,6 +184,7 @@ static size_t carve(Workspace& w, void* base, int64_t N, int64_t cap) {
     w.knn.vmat = c.take<float4>((size_t)INVR_NUM_PARTS * w.knn.mpad * 6);
     w.knn.voxcls = c.take<uint8_t>((size_t)VOXMASK_MAX_CELLS * INVR_NUM_PARTS);
     w.knn.voxmask = c.take<unsigned long long>((size_t)VOXMASK_MAX_CELLS * INVR_NUM_PARTS);
+    w.knn.voxu2 = c.take<float>((size_t)VOXMASK_MAX_CELLS * INVR_NUM_PARTS);
     w.mask = c.take<unsigned long long>(nb * 16);
     w.block_cnt = c.take<int32_t>(nb);
     w.block_off = c.take<int32_t>(nb);

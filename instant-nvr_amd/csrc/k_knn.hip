@@ -433,15 +433,24 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w, 
             // 16-vertex sub-cluster
             Top4 t;
             t.init();
+            if (!full && scan) {
+                // lattice cell bound: at least 4 vertices of the part lie within sqrt(u2) of every point of the cell, so four
+                // placeholder entries (u2, row 0xFFFFFFFF) prune from the first vertex on and are all evicted by real ones
+                const unsigned long long ph = ((unsigned long long)__float_as_uint(ix.voxu2[(int64_t)vcell * INVR_NUM_PARTS + p]) << 32) | 0xFFFFFFFFull;
+#pragma unroll
+                for (int j = 0; j < KNN_K; ++j) t.k[j] = ph;
+            }
             const float4* sb = lds + L.soff[p];
             const v2f px2 = {px, px}, py2 = {py, py}, pz2 = {pz, pz};
             const int seed_c = __builtin_amdgcn_readlane(seed, __ffsll((long long)__ballot(scan)) - 1);
+            if (full) {                                  // no bound to start from: the seed cluster is scanned unconditionally
 #pragma unroll 1
-            for (int s4 = 0; s4 < 4; ++s4) scan_sub16(sv + seed_c * 64 + s4 * 16, px2, py2, pz2, t);
+                for (int s4 = 0; s4 < 4; ++s4) scan_sub16(sv + seed_c * 64 + s4 * 16, px2, py2, pz2, t);
+            }
 #pragma unroll 1
-            for (int k = 1; (seed_c + k < ncl || seed_c - k >= 0) && !(dbg & 2); ++k) {
+            for (int k = full ? 1 : 0; (seed_c + k < ncl || seed_c - k >= 0) && !(dbg & 2); ++k) {
 #pragma unroll 1
-                for (int side = 0; side < 2; ++side) {
+                for (int side = 0; side < (k ? 2 : 1); ++side) {
                     const int c = side ? seed_c - k : seed_c + k;
                     if (c < 0 || c >= ncl) continue;
                     if (!full && !((Mc >> c) & 1ull)) continue;                   // no lane of the wave can have a neighbour there
@@ -456,6 +465,8 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w, 
                 }
             }
             t.finish();
+#pragma unroll
+            for (int j = 0; j < KNN_K; ++j) t.i[j] = min(t.i[j] & 0x7FFFFFFF, len - 1);      // (a surviving placeholder would be a bug; never index out of the part)
             float wt[KNN_K];
             const float ds = knn_weights(t, wt);
             if (scan && ds < a.scene.thresh) {                        // pflag (inb_part_network_multiassign.py:90)
@@ -584,6 +595,7 @@ __global__ void k_knn_voxel_class(SceneDev s, KnnIndex ix) {
             // D4(centre) + h, so only clusters whose box comes within that of the cell box; the cluster of x's nearest
             // vertex is always among them, so min-over-candidates of the per-point box bounds equals the min over all.
             unsigned long long mask = ~0ull;
+            float u2_out = __builtin_inff();
             if (pc == 0 && len >= KNN_K && ncl <= 64 && s.thresh < 1e8f) {      // (dense stress mode: every cell holds survivors, masks off)
                 // upper bound of the 4th-nearest distance from the cell centre: every 16-vertex sub-cluster box with >= 4 real
                 // vertices holds 4 vertices within the distance to its farthest corner
@@ -599,6 +611,7 @@ __global__ void k_knn_voxel_class(SceneDev s, KnnIndex ix) {
                     }
                 const float u = sqrtf(k3) + h;
                 const float u2 = u * u * 1.0002f;
+                u2_out = u2;
                 mask = 0ull;
                 for (int c = 0; c < ncl; ++c) {
                     const float4 klo = s_cl[c * 3], khi = s_cl[c * 3 + 1];
@@ -609,6 +622,7 @@ __global__ void k_knn_voxel_class(SceneDev s, KnnIndex ix) {
                 }
             }
             ix.voxmask[(int64_t)idx * INVR_NUM_PARTS + p] = mask;
+            ix.voxu2[(int64_t)idx * INVR_NUM_PARTS + p] = u2_out;
         }
     }
 }
