@@ -600,6 +600,8 @@ __global__ void k_knn_voxel_class(SceneDev s, KnnIndex ix) {
                 // upper bound of the 4th-nearest distance from the cell centre: every 16-vertex sub-cluster box with >= 4 real
                 // vertices holds 4 vertices within the distance to its farthest corner
                 float k3 = __builtin_inff();
+                float b0 = __builtin_inff(), b1 = b0, b2 = b0;          // the three sub-clusters with the smallest farthest-corner distance
+                int i0 = -1, i1 = -1, i2 = -1;
                 for (int c = 0; c < ncl; ++c)
                     for (int s4 = 0; s4 < 4; ++s4) {
                         if (len - (c * 64 + s4 * 16) < KNN_K) continue;
@@ -607,8 +609,36 @@ __global__ void k_knn_voxel_class(SceneDev s, KnnIndex ix) {
                         const float fx = fmaxf(fabsf(ce[0] - slo.x), fabsf(ce[0] - shi.x));
                         const float fy = fmaxf(fabsf(ce[1] - slo.y), fabsf(ce[1] - shi.y));
                         const float fz = fmaxf(fabsf(ce[2] - slo.z), fabsf(ce[2] - shi.z));
-                        k3 = fminf(k3, (fx * fx + fy * fy + fz * fz) * 1.0001f);
+                        const float f2 = (fx * fx + fy * fy + fz * fz) * 1.0001f;
+                        k3 = fminf(k3, f2);
+                        const int id = c * 4 + s4;
+                        if (f2 < b2) {
+                            b2 = f2; i2 = id;
+                            if (b2 < b1) { const float tf = b1; b1 = b2; b2 = tf; const int ti = i1; i1 = i2; i2 = ti; }
+                            if (b1 < b0) { const float tf = b0; b0 = b1; b1 = tf; const int ti = i0; i0 = i1; i1 = ti; }
+                        }
                     }
+                {   // tighten: the 4th-smallest exact distance among the (up to 48) vertices of those three sub-clusters is still an
+                    // upper bound of the 4th-nearest distance from the centre, usually the exact one
+                    const float* svf = reinterpret_cast<const float*>(ix.sverts + (int64_t)p * ix.mpad);
+                    float e0 = __builtin_inff(), e1 = e0, e2 = e0, e3 = e0;
+                    const int ids[3] = {i0, i1, i2};
+                    for (int t3 = 0; t3 < 3; ++t3) {
+                        if (ids[t3] < 0) continue;
+                        for (int j = ids[t3] * 16; j < ids[t3] * 16 + 16; ++j) {
+                            const float* q = svf + (j >> 1) * 8 + (j & 1);
+                            const float dx = ce[0] - q[0], dy = ce[1] - q[2], dz = ce[2] - q[4];
+                            const float d = dx * dx + dy * dy + dz * dz;
+                            if (d < e3) {
+                                e3 = d;
+                                if (e3 < e2) { const float tf = e2; e2 = e3; e3 = tf; }
+                                if (e2 < e1) { const float tf = e1; e1 = e2; e2 = tf; }
+                                if (e1 < e0) { const float tf = e0; e0 = e1; e1 = tf; }
+                            }
+                        }
+                    }
+                    k3 = fminf(k3, e3 * 1.0001f);
+                }
                 const float u = sqrtf(k3) + h;
                 const float u2 = u * u * 1.0002f;
                 u2_out = u2;
