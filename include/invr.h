@@ -176,7 +176,7 @@ typedef struct InvrWsLayout {
     int64_t l_x[INVR_NUM_PARTS];           /* float[3*lcap] SoA: canonical point incl. residual    */
     int64_t l_d[INVR_NUM_PARTS];           /* float[3*lcap] SoA: canonical view direction          */
     int64_t l_r[INVR_NUM_PARTS];           /* float[3*lcap] SoA: residual (resd)                   */
-    int64_t emb[2];                        /* float[20*lcap] SoA: encoder output of parts 0 and 1 */
+    int64_t emb[INVR_NUM_PARTS];           /* float[20*lcap] SoA [k][pair]: encoder output (19 values + pad) of every listed pair */
     int64_t raws;                          /* float4[lcap*5]: [rgb, occ] per (slot, part)          */
 } InvrWsLayout;
 int invr_workspace_layout(int64_t n_rays, int32_t n_samples, int64_t max_active, InvrWsLayout* out);
@@ -216,6 +216,20 @@ int invr_sample_volume(const float* vol, const int32_t dims[3], int32_t channels
  * bw (n,P,24), dist (n,P).  Exact brute-force 4-NN per part. */
 int invr_knn_blend(const InvrScene* scene, const float* pose_pts, int64_t n, float* bw, float* dist,
                    void* stream);
+
+/* The same brute force, returning the neighbours themselves: nn (n,P,4) int32 rows inside part_pts[p] in ascending
+ * (squared distance, row) order, d2 (n,P,4) squared distances, w (n,P,4) normalised gaussian weights (blend_utils.py:745-748),
+ * dist (n,P).  The reference for the render pipeline's pruned search (k_knn_pairs), whose per-pair results must be identical. */
+int invr_knn_neighbors(const InvrScene* scene, const float* pose_pts, int64_t n, int32_t* nn, float* d2, float* w,
+                       float* dist, void* stream);
+
+/* get_wsampling_points (inb_renderer.py:15-31) + world_points_to_pose_points / world_dirs_to_pose_dirs
+ * (blend_utils.py:366-382) for selected ray-samples, through the device function the render kernels use (bit-identical
+ * points): sample_idx (n) int32 = ray*n_samples + s, or NULL for all n = n_rays*n_samples in order; jitter as in
+ * invr_render_fwd -> pose_pts (n,3), pose_dirs (n,3) (NULL to skip). */
+int invr_pose_points(const InvrScene* scene, const float* ray_o, const float* ray_d, const float* near, const float* far,
+                     const float* jitter, int64_t n_rays, int32_t n_samples, const int32_t* sample_idx, int64_t n,
+                     float* pose_pts, float* pose_dirs, void* stream);
 
 /* Network.pose_points_to_tpose_points (inb_part_network_multiassign.py:77-120): LBS inverse warp
  * to the big pose + residual deformer for flagged pairs.  pose_pts, pose_dirs (n,3); bw (n,P,24);

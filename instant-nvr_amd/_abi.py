@@ -67,7 +67,7 @@ class InvrWsLayout(C.Structure):
                 ('word_off', C.c_int64), ('mask', C.c_int64), ('pflags', C.c_int64), ('farflags', C.c_int64),
                 ('l_slot', C.c_int64 * NUM_PARTS), ('l_nn', C.c_int64 * NUM_PARTS), ('l_w', C.c_int64 * NUM_PARTS),
                 ('l_x', C.c_int64 * NUM_PARTS), ('l_d', C.c_int64 * NUM_PARTS), ('l_r', C.c_int64 * NUM_PARTS),
-                ('emb', C.c_int64 * 2), ('raws', C.c_int64)]
+                ('emb', C.c_int64 * NUM_PARTS), ('raws', C.c_int64)]
 
 
 EXPORTS = ['invr_last_error', 'invr_version', 'invr_sizeof', 'invr_workspace_bytes', 'invr_render_fwd',
@@ -76,7 +76,8 @@ EXPORTS = ['invr_last_error', 'invr_version', 'invr_sizeof', 'invr_workspace_byt
            'invr_profile_enable', 'invr_profile_read', 'invr_workspace_layout', 'invr_deform_fwd',
            'invr_distortion_fwd', 'invr_grid_encode_bwd', 'invr_composite_bwd',
            'invr_field_workspace_bytes', 'invr_field_fwd', 'invr_geometry_fwd', 'invr_generate_rays',
-           'invr_rigid_transformation', 'invr_pack_parts', 'invr_grid_row_sums_len', 'invr_grid_row_sums', 'invr_adam_chunk_elems', 'invr_adam_step', 'invr_part_mlp_fwd', 'invr_part_mlp_bwd']
+           'invr_rigid_transformation', 'invr_pack_parts', 'invr_grid_row_sums_len', 'invr_grid_row_sums', 'invr_adam_chunk_elems', 'invr_adam_step', 'invr_part_mlp_fwd', 'invr_part_mlp_bwd',
+           'invr_knn_neighbors', 'invr_pose_points']
 NUM_STAGES = 14
 STAGE_NAMES = ['cull', 'knn', 'warp'] + ['encode_%d' % p for p in range(5)] + ['mlp_%d' % p for p in range(5)] + ['composite']
 
@@ -108,6 +109,10 @@ def lib():
         L.invr_grid_encode_fwd.argtypes = [C.POINTER(InvrGrid), vp, C.c_int64, vp, vp]
         L.invr_sample_volume.argtypes = [vp, C.c_int32 * 3, C.c_int32, C.c_int32, C.c_int32, vp, vp, C.c_int64, vp, vp]
         L.invr_knn_blend.argtypes = [C.POINTER(InvrScene), vp, C.c_int64, vp, vp, vp]
+        L.invr_knn_neighbors.argtypes = [C.POINTER(InvrScene), vp, C.c_int64, vp, vp, vp, vp, vp]
+        L.invr_knn_neighbors.restype = C.c_int
+        L.invr_pose_points.argtypes = [C.POINTER(InvrScene), vp, vp, vp, vp, vp, C.c_int64, C.c_int32, vp, C.c_int64, vp, vp, vp]
+        L.invr_pose_points.restype = C.c_int
         L.invr_warp_deform.argtypes = [C.POINTER(InvrScene), C.POINTER(InvrModel), vp, vp, vp, vp, C.c_int64, vp, vp, vp, vp]
         L.invr_part_field_fwd.argtypes = [C.POINTER(InvrModel), C.c_int32, vp, vp, vp, C.c_int64, vp, vp, C.c_size_t, vp]
         L.invr_composite_fwd.argtypes = [vp, C.c_int64, C.c_int32, vp, vp, vp, vp]
@@ -191,6 +196,9 @@ def ws_views(ws, n_rays, S, max_active, n_active=None):
             v[k] = [view(offs[p], lc, torch.int32) for p in range(NUM_PARTS)]
         else:
             v[k] = [view(offs[p], 3 * lc, torch.float32).view(3, lc) for p in range(NUM_PARTS)]
+    v['l_nn'] = [view(lay.l_nn[p], 4 * lc, torch.int32).view(lc, 4) for p in range(NUM_PARTS)]      # neighbour rows inside part_pts[p]
+    v['l_w'] = [view(lay.l_w[p], 4 * lc, torch.float32).view(lc, 4) for p in range(NUM_PARTS)]       # normalised gaussian weights
+    v['emb'] = [view(lay.emb[p], 20 * lc, torch.float32).view(20, lc) for p in range(NUM_PARTS)]      # encoder outputs, SoA [k][pair]
     return v
 
 

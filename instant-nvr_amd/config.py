@@ -76,7 +76,9 @@ DEFAULTS = {
     'resd_loss_weight': 0.1,
     'train_hip_mlp': True,   # training: part MLPs forward + backward on the HIP kernels (False: torch ops, autograd.part_field)
     'eval_row_sums': True,   # eval-mode renders read the part grids through derived row-sum tables (invr_grid_row_sums)
-    'use_lpips': False,      # the reference yaml sets True (VGG19 from torchvision); absent on this image
+    # image loss: configs/inb/inb_377.yaml sets use_lpips True (VGG19 from torchvision, absent on this image).  The stand-alone
+    # default is the plain MSE; adopt() takes the host's value and NetworkWrapper raises if no perceptual loss can be had.
+    'use_lpips': False, 'use_ssim': False, 'use_fourier': False, 'use_tv_image': False, 'vgg19_weights': None,
     'network': {'occ': {'d_hidden': 64, 'n_layers': 1}},
     'viewdir_embedder': {'kwargs': {'res': 4, 'input_dims': 3}},
     'tpose_deformer': {'embedder': {'kwargs': dict(

@@ -239,7 +239,8 @@ int launch_grid_encode_bwd_generic(const GridDev& g, const float* xyz, const flo
 int launch_composite_bwd(const float* raw, const float* g_rgb, const float* g_acc, const float* g_w, int64_t n_rays, int S,
                          float* g_raw, hipStream_t st);
 int launch_sample_volume(const VolDev& v, int c0, int nc, const float* pts, int64_t n, float* out, hipStream_t st);
-int launch_knn_blend_dense(const SceneDev& s, const float* pose_pts, int64_t n, float* bw, float* dist, hipStream_t st);
+int launch_knn_blend_dense(const SceneDev& s, const float* pose_pts, int64_t n, float* bw, float* dist, int32_t* nn, float* d2,
+                           float* w, hipStream_t st);
 int launch_warp_deform_dense(const SceneDev& s, const GridDev& dg, const MlpDev& dm, const float* pose_pts,
                              const float* pose_dirs, const float* bw, const uint8_t* flag, int64_t n,
                              float* tpose, float* tdirs, float* resd, hipStream_t st);

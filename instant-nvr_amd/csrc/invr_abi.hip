@@ -6,6 +6,8 @@
 #include <stdio.h>
 #include <string.h>
 #include <math.h>
+#include <stdlib.h>
+#include <vector>
 #include "pipeline.h"
 
 static thread_local char g_err[512] = "";
@@ -223,7 +225,8 @@ extern "C" int invr_workspace_layout(int64_t n_rays, int32_t n_samples, int64_t 
         o->l_slot[p] = off(w.l_slot[p]); o->l_nn[p] = off(w.l_nn[p]); o->l_w[p] = off(w.l_w[p]);
         o->l_x[p] = off(w.l_x[p]); o->l_d[p] = off(w.l_d[p]); o->l_r[p] = off(w.l_r[p]);
     }
-    o->emb[0] = off(w.emb[0]); o->emb[1] = off(w.emb[1]); o->raws = off(w.raws);
+    for (int p = 0; p < INVR_NUM_PARTS; ++p) o->emb[p] = off(w.emb[p]);
+    o->raws = off(w.raws);
     return 0;
 }
 
@@ -288,10 +291,11 @@ static int render_impl(const InvrScene* scene, const InvrModel* model,
 
     // fork: KNN index build (k_part_prepare, 5 workgroups, ~60 us) on a side stream beside the cull kernels
     struct SideStream { hipStream_t side = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
-    static thread_local SideStream side_of_device[16];            // one per device this thread renders on
+    static thread_local std::vector<SideStream> side_of_device;   // one per device this thread renders on (CPX mode: up to 64)
     int dev_id = 0;
     INVR_HIP(hipGetDevice(&dev_id));
-    INVR_CHECK(dev_id >= 0 && dev_id < 16, "invr_render_fwd: device index %d out of range", dev_id);
+    INVR_CHECK(dev_id >= 0 && dev_id < 4096, "invr_render_fwd: device index %d out of range", dev_id);
+    if ((size_t)dev_id >= side_of_device.size()) side_of_device.resize((size_t)dev_id + 1);
     SideStream& ss = side_of_device[dev_id];
     if (!ss.side) {
         INVR_HIP(hipStreamCreateWithFlags(&ss.side, hipStreamNonBlocking));
@@ -304,8 +308,11 @@ static int render_impl(const InvrScene* scene, const InvrModel* model,
     INVR_HIP(hipStreamWaitEvent(side, ev_fork, 0));
     if (launch_knn_prepare(a, w, side)) return 1;
     if (launch_vertex_mats(a, w, side)) return 1;
-    if (getenv("INVR_NO_VOXMASK")) w.knn.voxmask = nullptr;
-    if ((int64_t)a.scene.pbw.dx * a.scene.pbw.dy * a.scene.pbw.dz > VOXMASK_MAX_CELLS || getenv("INVR_NO_VOXCLS")) { w.knn.voxcls = nullptr; w.knn.voxmask = nullptr; }
+    // ablation switches: the environment is read once per process, not per frame
+    static const bool no_voxmask = getenv("INVR_NO_VOXMASK") != nullptr, no_voxcls = getenv("INVR_NO_VOXCLS") != nullptr,
+                      no_merge = getenv("INVR_NO_MERGE") != nullptr;
+    if (no_voxmask) w.knn.voxmask = nullptr;
+    if ((int64_t)a.scene.pbw.dx * a.scene.pbw.dy * a.scene.pbw.dz > VOXMASK_MAX_CELLS || no_voxcls) { w.knn.voxcls = nullptr; w.knn.voxmask = nullptr; }
     else if (launch_knn_voxel_class(a, w, side)) return 1;
     INVR_HIP(hipEventRecord(ev_join, side));
     {
@@ -324,7 +331,7 @@ static int render_impl(const InvrScene* scene, const InvrModel* model,
         MlpDev dm = make_mlp_dev(&model->deform_mlp);
         if (launch_warp_pairs(a, w, dg, dm, st)) return 1;
     }
-    bool merged = !geometry_only && getenv("INVR_NO_MERGE") == nullptr;
+    bool merged = !geometry_only && !no_merge;
     for (int p = 0; p < INVR_NUM_PARTS; ++p) merged = merged && model->part[p].grid.row_sums != nullptr;
     if (merged) {
         // eval path: the five parts in one encoder launch and one MLP launch (stage times are booked on part 0)
@@ -426,7 +433,27 @@ extern "C" int invr_sample_volume(const float* vol, const int32_t dims[3], int32
 
 extern "C" int invr_knn_blend(const InvrScene* scene, const float* pose_pts, int64_t n, float* bw, float* dist, void* stream) {
     INVR_CHECK(scene && (n == 0 || (pose_pts && bw && dist)), "invr_knn_blend: null pointer");
-    return launch_knn_blend_dense(make_scene_dev(scene), pose_pts, n, bw, dist, (hipStream_t)stream);
+    return launch_knn_blend_dense(make_scene_dev(scene), pose_pts, n, bw, dist, nullptr, nullptr, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int invr_knn_neighbors(const InvrScene* scene, const float* pose_pts, int64_t n, int32_t* nn, float* d2, float* w,
+                                  float* dist, void* stream) {
+    INVR_CHECK(scene && (n == 0 || (pose_pts && nn && d2 && w && dist)), "invr_knn_neighbors: null pointer");
+    return launch_knn_blend_dense(make_scene_dev(scene), pose_pts, n, nullptr, dist, nn, d2, w, (hipStream_t)stream);
+}
+
+extern "C" int invr_pose_points(const InvrScene* scene, const float* ray_o, const float* ray_d, const float* near, const float* far,
+                                const float* jitter, int64_t n_rays, int32_t n_samples, const int32_t* sample_idx, int64_t n,
+                                float* pose_pts, float* pose_dirs, void* stream) {
+    INVR_CHECK(scene && (n == 0 || (ray_o && ray_d && near && far && pose_pts)), "invr_pose_points: null pointer");
+    INVR_CHECK(n_rays >= 0 && n_samples >= 2 && n_rays * (int64_t)n_samples < (1ll << 31), "invr_pose_points: bad n_rays / n_samples");
+    INVR_CHECK(sample_idx || n == n_rays * (int64_t)n_samples, "invr_pose_points: without sample_idx n must be n_rays*n_samples");
+    RenderArgs a;
+    memset(&a, 0, sizeof(a));
+    a.scene = make_scene_dev(scene);
+    a.ray_o = ray_o; a.ray_d = ray_d; a.near = near; a.far = far; a.jitter = jitter;
+    a.R = n_rays; a.S = n_samples; a.N = n_rays * (int64_t)n_samples;
+    return launch_pose_points(a, sample_idx, n, pose_pts, pose_dirs, (hipStream_t)stream);
 }
 
 extern "C" int invr_warp_deform(const InvrScene* scene, const InvrModel* model, const float* pose_pts,

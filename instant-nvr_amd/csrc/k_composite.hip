@@ -142,17 +142,22 @@ int launch_distortion(const float* weights, const float* z, int64_t n_rays, int 
 }
 
 // ---- backward of the compositing (net_utils.py:12-44 under autograd) ------------------------------
-// w_i = a_i T_i, T_i = prod_{j<i}(1-a_j).  With G_i = dL/dw_i (from rgb_map, acc_map and any direct
-// weight gradient):  dL/da_i = G_i T_i - (sum_{k>i} G_k w_k) / (1 - a_i);  dL/drgb_i = w_i * g_rgb.
-// One wave per ray; T by the same shuffle product scan as the forward, the suffix sum by a
-// reverse shuffle scan, 64 samples per pass walked back to front.
-__device__ __forceinline__ float wave_incl_sum_rev(float x, int lane) {      // suffix sum, inclusive
+// w_k = a_k T_k, T_k = prod_{j<k}(1-a_j).  With G_k = dL/dw_k (from rgb_map, acc_map and any direct
+// weight gradient):
+//     dL/da_i = T_i (G_i - Q_i),   Q_i = sum_{k>i} G_k a_k prod_{i<j<k}(1-a_j)
+// (the product EXCLUDES factor i, so nothing is divided by 1-a_i: alpha == 1 — reachable, 1-exp(-softplus(h))
+// rounds to 1 for h >~ 17 — gives the finite gradient torch's zero-aware cumprod backward gives, and alpha close to 1
+// has no cancellation).  Q obeys the backward recurrence Q_i = G_{i+1} a_{i+1} + (1-a_{i+1}) Q_{i+1}, Q_{S-1} = 0:
+// a composition of affine maps f_k(x) = b_k + m_k x, which is associative -> one wave suffix scan over (m, b) pairs per
+// 64-sample pass, passes walked back to front with a carried Q.  dL/drgb_i = w_i * g_rgb.
+struct Affine { float m, b; };
+__device__ __forceinline__ Affine wave_suffix_compose(Affine f, int lane) {     // F_l = f_l o f_{l+1} o ... o f_63
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-        float y = __shfl_down(x, d);
-        if (lane + d < 64) x += y;
+        const float m2 = __shfl_down(f.m, d), b2 = __shfl_down(f.b, d);
+        if (lane + d < 64) { f.b = fmaf(f.m, b2, f.b); f.m *= m2; }
     }
-    return x;
+    return f;
 }
 
 __global__ __launch_bounds__(CMP_BLOCK) void k_composite_bwd(const float4* __restrict__ raw, const float* __restrict__ g_rgb,
@@ -164,17 +169,15 @@ __global__ __launch_bounds__(CMP_BLOCK) void k_composite_bwd(const float4* __res
     const float gr = g_rgb[ray * 3], gg = g_rgb[ray * 3 + 1], gb = g_rgb[ray * 3 + 2];
     const float ga = g_acc ? g_acc[ray] : 0.0f;
     const int npass = (S + 63) / 64;
-    // forward transmittance at the start of every pass
-    float T0[8];            // up to 512 samples per ray
-    float T_run = 1.0f;
-    for (int ps = 0; ps < npass; ++ps) {
-        T0[ps] = T_run;
-        const int s = ps * 64 + lane;
-        const float a = s < S ? raw[ray * S + s].w : 0.0f;
-        T_run *= __shfl(wave_incl_prod(1.0f - a, lane), 63);
-    }
-    float tail = 0.0f;      // sum_{k in later passes} G_k w_k
+    float carry = 0.0f;     // Q of the last sample of the current pass
     for (int ps = npass - 1; ps >= 0; --ps) {
+        // transmittance at the start of this pass: product over the earlier passes (recomputed per pass — S is a
+        // few passes at most, and no per-thread array bounds the sample count)
+        float T0 = 1.0f;
+        for (int q = 0; q < ps; ++q) {
+            const float aq = raw[ray * S + q * 64 + lane].w;
+            T0 *= __shfl(wave_incl_prod(1.0f - aq, lane), 63);
+        }
         const int s = ps * 64 + lane;
         const bool live = s < S;
         float4 v = live ? raw[ray * S + s] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -182,26 +185,26 @@ __global__ __launch_bounds__(CMP_BLOCK) void k_composite_bwd(const float4* __res
         const float incl = wave_incl_prod(1.0f - a, lane);
         float excl = __shfl_up(incl, 1);
         if (lane == 0) excl = 1.0f;
-        const float T = T0[ps] * excl;
+        const float T = T0 * excl;
         const float wgt = a * T;
         const float G = live ? (gr * v.x + gg * v.y + gb * v.z + ga + (g_w ? g_w[ray * S + s] : 0.0f)) : 0.0f;
-        const float Gw = G * wgt;
-        const float suf_incl = wave_incl_sum_rev(Gw, lane);
-        const float after = suf_incl - Gw + tail;                   // sum_{k>i} G_k w_k
+        const Affine F = wave_suffix_compose(Affine{1.0f - a, G * a}, lane);       // dead lanes: identity map
+        float Mn = __shfl_down(F.m, 1), Bn = __shfl_down(F.b, 1);
+        if (lane == 63) { Mn = 1.0f; Bn = 0.0f; }
+        const float Q = fmaf(Mn, carry, Bn);
         if (live) {
             float4 o;
             o.x = wgt * gr; o.y = wgt * gg; o.z = wgt * gb;
-            o.w = G * T - after / (1.0f - a);
+            o.w = T * (G - Q);
             g_raw[ray * S + s] = o;
         }
-        tail += __shfl(suf_incl, 0);
+        carry = fmaf(__shfl(F.m, 0), carry, __shfl(F.b, 0));
     }
 }
 
 int launch_composite_bwd(const float* raw, const float* g_rgb, const float* g_acc, const float* g_w, int64_t n_rays, int S,
                          float* g_raw, hipStream_t st) {
     if (n_rays == 0) return 0;
-    if (S > 512) { invr_set_error("invr_composite_bwd: n_samples <= 512 supported (got %d)", S); return 1; }
     hipLaunchKernelGGL(k_composite_bwd, dim3((unsigned)cdiv(n_rays, CMP_BLOCK / 64)), dim3(CMP_BLOCK), 0, st,
                        reinterpret_cast<const float4*>(raw), g_rgb, g_acc, g_w, n_rays, S, reinterpret_cast<float4*>(g_raw));
     INVR_LAUNCH_CHECK();

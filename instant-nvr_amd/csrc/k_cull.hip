@@ -231,3 +231,22 @@ int launch_sample_volume(const VolDev& v, int c0, int nc, const float* pts, int6
     INVR_LAUNCH_CHECK();
     return 0;
 }
+
+// ---- stand-alone sampler + world->pose of selected ray-samples (invr_pose_points) ---------------------------------
+// inb_renderer.py:15-31 + blend_utils.py:366-382 through sample_pose_point, the device function the render kernels use:
+// a caller (tests, the training path) gets bit-identical pose points / directions for any ray-sample index.
+__global__ void k_pose_points(RenderArgs a, const int32_t* __restrict__ idx, int64_t n, float* __restrict__ pts, float* __restrict__ dirs) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    float px, py, pz, pd[3];
+    sample_pose_point(a, idx ? (int64_t)idx[j] : j, px, py, pz, nullptr, dirs ? pd : nullptr);
+    pts[j * 3] = px; pts[j * 3 + 1] = py; pts[j * 3 + 2] = pz;
+    if (dirs) { dirs[j * 3] = pd[0]; dirs[j * 3 + 1] = pd[1]; dirs[j * 3 + 2] = pd[2]; }
+}
+
+int launch_pose_points(const RenderArgs& a, const int32_t* idx, int64_t n, float* pts, float* dirs, hipStream_t st) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_pose_points, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, a, idx, n, pts, dirs);
+    INVR_LAUNCH_CHECK();
+    return 0;
+}

@@ -90,7 +90,8 @@ __device__ __forceinline__ float knn_weights(const Top4& t, float* w) {
 
 // ---- dense brute-force variant (invr_knn_blend): every (point, part) -> bw (n,P,24), dist (n,P) ----
 #define KNN_TILE 2048
-__global__ __launch_bounds__(KNN_BLOCK) void k_knn_dense(SceneDev s, const float* pose_pts, int64_t n, float* bw, float* dist) {
+__global__ __launch_bounds__(KNN_BLOCK) void k_knn_dense(SceneDev s, const float* pose_pts, int64_t n, float* bw, float* dist,
+                                                        int32_t* nn_out, float* d2_out, float* w_out) {
     __shared__ float4 sv[KNN_TILE];
     int64_t i = (int64_t)blockIdx.x * KNN_BLOCK + threadIdx.x;
     bool live = i < n;
@@ -121,6 +122,15 @@ __global__ __launch_bounds__(KNN_BLOCK) void k_knn_dense(SceneDev s, const float
         float w[KNN_K];
         float ds = knn_weights(t, w);
         dist[i * INVR_NUM_PARTS + p] = ds;
+        if (nn_out) {                                             // invr_knn_neighbors: the neighbours themselves, in (distance,row) order
+#pragma unroll
+            for (int k = 0; k < KNN_K; ++k) {
+                nn_out[(i * INVR_NUM_PARTS + p) * KNN_K + k] = t.i[k];
+                d2_out[(i * INVR_NUM_PARTS + p) * KNN_K + k] = t.d[k];
+                w_out[(i * INVR_NUM_PARTS + p) * KNN_K + k] = w[k];
+            }
+        }
+        if (!bw) continue;
         float* o = bw + (i * INVR_NUM_PARTS + p) * INVR_NUM_JOINTS;
         const float* pb = s.part_pbw + (int64_t)p * s.M * INVR_NUM_JOINTS;
 #pragma unroll
@@ -133,9 +143,10 @@ __global__ __launch_bounds__(KNN_BLOCK) void k_knn_dense(SceneDev s, const float
     }
 }
 
-int launch_knn_blend_dense(const SceneDev& s, const float* pose_pts, int64_t n, float* bw, float* dist, hipStream_t st) {
+int launch_knn_blend_dense(const SceneDev& s, const float* pose_pts, int64_t n, float* bw, float* dist, int32_t* nn, float* d2,
+                           float* w, hipStream_t st) {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(k_knn_dense, dim3((unsigned)cdiv(n, KNN_BLOCK)), dim3(KNN_BLOCK), 0, st, s, pose_pts, n, bw, dist);
+    hipLaunchKernelGGL(k_knn_dense, dim3((unsigned)cdiv(n, KNN_BLOCK)), dim3(KNN_BLOCK), 0, st, s, pose_pts, n, bw, dist, nn, d2, w);
     INVR_LAUNCH_CHECK();
     return 0;
 }

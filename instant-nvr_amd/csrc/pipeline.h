@@ -113,6 +113,7 @@ __device__ __forceinline__ void sample_pose_point(const RenderArgs& a, int64_t i
 
 // ---- pipeline stage launchers ------------------------------------------------------------------
 int launch_cull(const RenderArgs& a, const Workspace& w, int64_t max_active, hipStream_t st);
+int launch_pose_points(const RenderArgs& a, const int32_t* idx, int64_t n, float* pts, float* dirs, hipStream_t st);
 int launch_knn_prepare(const RenderArgs& a, const Workspace& w, hipStream_t st);
 int launch_vertex_mats(const RenderArgs& a, const Workspace& w, hipStream_t st);
 int launch_knn_voxel_class(const RenderArgs& a, const Workspace& w, hipStream_t st);

@@ -53,9 +53,26 @@ class Embedder(nn.Module):
     def grid_struct(self, keep):
         return _abi.make_grid(self.spec, self.dense if self.separate_dense else None, self.hash, self.bounds, keep)
 
+    def invalidate_row_sums(self):
+        """Drop the cached row-sum table (rebuilt by the next eval render: one cheap kernel).  Call after writing the
+        tables through a path the tensor version counters do not see (p.data.copy_(), raw-pointer kernels)."""
+        self._rs_key = None
+        self._rs = None
+
+    def train(self, mode=True):
+        # every train <-> eval transition rebuilds the derived table: in-place writes through .data (its own version
+        # counter) or external kernels during training would otherwise leave eval rendering from stale row sums
+        self.invalidate_row_sums()
+        return super().train(mode)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self.invalidate_row_sums()
+        return super()._load_from_state_dict(*args, **kwargs)
+
     def row_sums(self):
         """Inference-only derived table (invr_grid_row_sums): one float per table row = sum of its F
-        features.  Cached; rebuilt when the tables were written to (tensor version counters) or moved."""
+        features.  Cached; rebuilt when the tables were written to (tensor version counters) or moved, on every
+        train()/eval() switch, on load_state_dict and after invalidate_row_sums()."""
         tabs = [self.hash] + ([self.dense] if self.separate_dense else [])
         key = tuple((t.data_ptr(), t._version, str(t.device)) for t in tabs)
         if getattr(self, '_rs_key', None) != key:

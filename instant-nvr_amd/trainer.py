@@ -3,8 +3,14 @@
 Same constructor / ``forward(batch, epoch=-1, split='train')`` signature and return tuple
 ``(ret, loss, scalar_stats, image_stats)``; the loss terms the INB configs produce are assembled as
 the reference does (pair regulariser :45-48 with crit.reg_raw_crit, distortion :84-87, offset
-:89-92, image loss :176-214).  The LPIPS branch needs torchvision's VGG19 (absent on this image):
-with cfg.use_lpips the plain MSE is used and ``scalar_stats['lpips_loss']`` is not produced.
+:89-92, image loss :176-214 incl. the patch branch :188-214).
+
+cfg.use_lpips (True in configs/inb/inb_377.yaml): the patch is re-assembled from `mask_at_box` exactly as the
+reference does and handed to a perceptual-loss module — `NetworkWrapper(net, perceptual_loss=...)`, else the host
+application's own `lib.train.trainers.loss.perceptual_loss.PerceptualLoss` when this wrapper runs inside the reference
+(torchvision present), else `invr.losses.PerceptualLoss(weights=cfg.vgg19_weights)`.  With none of the three the
+constructor RAISES: the wrapper never trains a different objective silently.  use_ssim / use_fourier / use_tv_image are
+resolved from the host application the same way (they are off in every INB config) or rejected.
 """
 import numpy as np
 import torch
@@ -22,13 +28,59 @@ def reg_raw_crit(x):
     return (vector[:, n_pts:, :] - vector[:, :n_pts, :]).norm(dim=-1).mean()
 
 
+def _host_loss(module, cls):
+    """A loss class of the hosting reference application (lib.train.trainers.loss.*), or None when not hosted."""
+    import importlib
+    import sys
+    if 'lib.config' not in sys.modules:
+        return None
+    try:
+        return getattr(importlib.import_module(module), cls)
+    except Exception:
+        return None
+
+
+def assemble_patch(values, mask_at_box, H, W):
+    """inb_trainer.py:196-203: `img = zeros(H,W,C); img[mask_at_box] = values` for values (1,Nr,C) / (Nr,C) of the rays
+    inside the body AABB, in mask order.  Written as a gather by the running count of the mask, so that no boolean
+    indexing (a host-syncing nonzero) is involved and the gradient flows to `values`."""
+    v = values.reshape(-1, values.shape[-1])
+    m = mask_at_box.reshape(-1).to(v.device).bool()
+    idx = (torch.cumsum(m.to(torch.int64), 0) - 1).clamp_(min=0)
+    if v.shape[0] == 0:
+        return torch.zeros(H, W, v.shape[-1], device=v.device, dtype=v.dtype)
+    img = v[idx.clamp_(max=v.shape[0] - 1)] * m[:, None].to(v.dtype)
+    return img.reshape(H, W, v.shape[-1])
+
+
 class NetworkWrapper(nn.Module):
-    def __init__(self, net):
+    def __init__(self, net, perceptual_loss=None):
         super().__init__()
         self.net = net
         self.renderer = Renderer(self.net)
-        self.cfg = getattr(net, 'cfg', global_cfg)
+        self.cfg = cfg = getattr(net, 'cfg', global_cfg)
         self.img2mse = lambda x, y: torch.mean((x - y) ** 2)
+        if cfg.get('use_lpips', False):                                                  # inb_trainer.py:28-29
+            if perceptual_loss is None:
+                host = _host_loss('lib.train.trainers.loss.perceptual_loss', 'PerceptualLoss')
+                if host is not None:
+                    perceptual_loss = host()
+                elif cfg.get('vgg19_weights', None):
+                    from .losses import PerceptualLoss
+                    perceptual_loss = PerceptualLoss(weights=cfg.vgg19_weights)
+                else:
+                    raise RuntimeError('cfg.use_lpips is set (configs/inb/inb_377.yaml:196) but no perceptual loss is available: pass '
+                                       'NetworkWrapper(net, perceptual_loss=module), set cfg.vgg19_weights to a torchvision VGG19 '
+                                       'state_dict, run inside the reference (torchvision), or set use_lpips False for the plain MSE')
+            self.perceptual_loss = perceptual_loss
+        for flag, mod, cls, attr in (('use_ssim', 'lib.utils.loss_utils', 'SSIM', 'ssim_loss'),
+                                     ('use_fourier', 'lib.train.trainers.loss.fourier_loss', 'FourierLoss', 'fourier_loss'),
+                                     ('use_tv_image', 'lib.train.trainers.loss.tv_image_loss', 'TVImageLoss', 'tv_image_loss')):
+            if cfg.get(flag, False):                                                     # :31-38, off in every INB config
+                host = _host_loss(mod, cls)
+                if host is None:
+                    raise RuntimeError('cfg.%s is set but %s.%s is only available inside the reference application' % (flag, mod, cls))
+                setattr(self, attr, host(window_size=11) if flag == 'use_ssim' else host())
 
     def forward(self, batch, epoch=-1, split='train'):
         cfg = self.cfg
@@ -65,7 +117,29 @@ class NetworkWrapper(nn.Module):
             err = torch.abs(rgb_map - batch['rgb']).sum(dim=-1).detach().cpu()
             psnr = -10 * np.log(img_loss.item()) / np.log(10)
             scalar_stats.update({'img_loss': img_loss, 'psnr': torch.Tensor([psnr])})
-            loss = loss + img_loss
+            if cfg.get('use_lpips', False) or cfg.get('use_ssim', False) or cfg.get('use_fourier', False) or cfg.get('use_tv_image', False):
+                H, W = int(batch['H'].item()), int(batch['W'].item())                   # :188-203: the rays of a patch back on its pixels
+                img_pred = assemble_patch(rgb_map, batch['mask_at_box'][0], H, W)
+                img_gt = assemble_patch(batch['rgb'], batch['mask_at_box'][0], H, W)
+                if cfg.get('use_lpips', False):                                          # :206-209: NO separate MSE term
+                    lp = self.perceptual_loss(img_pred.permute(2, 0, 1)[None], img_gt.permute(2, 0, 1)[None])
+                    scalar_stats['lpips_loss'] = lp
+                    loss = loss + lp
+                elif cfg.get('use_ssim', False):
+                    ss = 1 - self.ssim_loss(img_pred.permute(2, 0, 1)[None], img_gt.permute(2, 0, 1)[None])
+                    scalar_stats['ssim_loss'] = ss
+                    loss = loss + 0.1 * ss + img_loss
+                elif cfg.get('use_fourier', False):
+                    fl = self.fourier_loss(img_pred, img_gt)
+                    scalar_stats['fourier_loss'] = fl
+                    loss = loss + 0.1 * fl + img_loss
+                else:
+                    mask_gt = assemble_patch(batch['occupancy'].to(rgb_map.dtype)[..., None], batch['mask_at_box'][0], H, W)[..., 0] > 0
+                    tv = self.tv_image_loss(img_pred, img_gt, mask_gt)
+                    scalar_stats['tv_loss'] = tv
+                    loss = loss + 0.01 * tv + img_loss
+            else:
+                loss = loss + img_loss
             scalar_stats['loss'] = loss
             ret['error'] = err
         else:

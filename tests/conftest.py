@@ -31,3 +31,25 @@ def small_setup(golden):
     sd = params.init_state_dict(cfg, seed=int(meta['param_seed']))
     batch_np, extras = scene.make_scene(int(meta['H']), int(meta['W']), seed=int(meta['scene_seed']))
     return cfg, sd, scene.to_torch(batch_np), extras
+
+
+@pytest.fixture(scope='session')
+def full_net():
+    """inb_377 at its real size on cuda:0 (285,993,711 parameters, 1.09 GB tables ~N(0,0.1^2)); shared by the
+    full-size GPU test modules.  Returns (cfg, net)."""
+    import torch
+    import invr  # noqa: F401
+    from invr.config import make_cfg
+    from invr.network import Network
+    dev = 'cuda:0'
+    cfg = make_cfg(N_samples=128)
+    with torch.device(dev):
+        net = Network(cfg=cfg)
+    net = net.to(dev).eval()
+    g = torch.Generator(device=dev).manual_seed(0)
+    with torch.no_grad():
+        for name, p in net.named_parameters():
+            if name.endswith('embedder.dense') or name.endswith('embedder.hash'):
+                p.normal_(0.0, 0.1, generator=g)
+    assert sum(p.numel() for p in net.parameters()) == 285993711
+    return cfg, net

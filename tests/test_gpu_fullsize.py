@@ -16,17 +16,8 @@ DEV = 'cuda:0'
 
 
 @pytest.fixture(scope='module')
-def full():
-    cfg = make_cfg(N_samples=128)
-    with torch.device(DEV):
-        net = Network(cfg=cfg)
-    net = net.to(DEV).eval()
-    g = torch.Generator(device=DEV).manual_seed(0)
-    with torch.no_grad():
-        for name, p in net.named_parameters():
-            if name.endswith('embedder.dense') or name.endswith('embedder.hash'):
-                p.normal_(0.0, 0.1, generator=g)
-    assert sum(p.numel() for p in net.parameters()) == 285993711
+def full(full_net):
+    cfg, net = full_net
     bnp, _ = scene.make_scene(512, 512, seed=0, cam_dist=1.8)
     bc = scene.to_torch(bnp)
     gb = {k: v.to(DEV) for k, v in bc.items()}

@@ -217,6 +217,43 @@ def test_composite_random(gpu_setup):
         assert maxerr(wo, w) < 2e-6 and maxerr(ro, rgb) < 5e-6 and maxerr(ao, acc) < 5e-6
 
 
+def test_composite_backward_saturated_alphas(gpu_setup):
+    """invr_composite_bwd vs torch autograd of volume_rendering / render_weights (net_utils.py:12-44, epsilon 0) with
+    alphas of EXACTLY 0.0 and 1.0 in the ray (1 - exp(-softplus(h)) rounds to 1 for h >~ 17): torch's cumprod backward is
+    zero-aware and stays finite there, and so must the kernel (no division by 1 - alpha)."""
+    from invr import autograd as AG
+    g = torch.Generator().manual_seed(9)
+    for R, S in ((5, 1), (40, 64), (33, 65), (17, 200), (3, 700)):
+        raw = torch.rand(R, S, 4, generator=g)
+        u = torch.rand(R, S, generator=g)
+        a = raw[..., 3].clone()
+        a[u < 0.25] = 0.0
+        a[(u > 0.9)] = 1.0                                   # several exact ones per ray, also consecutive / first / last
+        a[0] = 0.0
+        if S > 1:
+            a[1, 0] = 1.0; a[2, -1] = 1.0; a[3, S // 2] = 1.0; a[3, S // 2 - 1:S // 2 + 1] = 1.0
+            a[4] = torch.rand(S, generator=g) * 1e-3 + (1 - 1e-3)         # all close to one: catastrophic for a quotient form
+        raw[..., 3] = a
+        g_rgb, g_acc, g_w = torch.randn(R, 3, generator=g), torch.randn(R, generator=g), torch.randn(R, S, generator=g)
+        rc = raw.clone().double().requires_grad_()
+        w, rgb, acc = O.composite(rc[..., :3], rc[..., 3])
+        ((rgb * g_rgb.double()).sum() + (acc * g_acc.double()).sum() + (w * g_w.double()).sum()).backward()
+        rg = cu(raw).requires_grad_()
+        wo, ro, ao = AG.CompositeFn.apply(rg)
+        ((ro * cu(g_rgb)).sum() + (ao * cu(g_acc)).sum() + (wo * cu(g_w)).sum()).backward()
+        got = rg.grad.cpu()
+        assert bool(torch.isfinite(got).all()), (R, S)
+        ref = rc.grad.float()
+        scale = float(ref.abs().max())
+        assert float((got - ref).abs().max()) <= 2e-6 * max(scale, 1.0), (R, S, float((got - ref).abs().max()), scale)
+        # and against torch's own fp32 autograd: same tolerance class
+        rf = raw.clone().requires_grad_()
+        w, rgb, acc = O.composite(rf[..., :3], rf[..., 3])
+        ((rgb * g_rgb).sum() + (acc * g_acc).sum() + (w * g_w).sum()).backward()
+        assert bool(torch.isfinite(rf.grad).all())
+        assert float((got - rf.grad).abs().max()) <= 4e-6 * max(scale, 1.0)
+
+
 @BOTH_ENCODERS
 def test_render_64x64x32_vs_reference_golden(gpu_setup, golden, row_sums):
     """BASELINE config 1 through Renderer.render (eval): <= 1e-4 per pixel vs the reference."""
@@ -364,6 +401,46 @@ def test_network_wrapper_optimisation_steps(gpu_setup, golden):
         losses.append(float(loss.detach()))
         assert set(['reg_dist', 'offset_loss', 'img_loss', 'psnr', 'loss']) <= set(stats.keys())   # pair_loss only when pairs qualify
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
+def test_network_wrapper_lpips_patch_branch(gpu_setup, golden):
+    """inb_trainer.py:188-214 (use_lpips, the inb_377.yaml default): the rays are put back on the patch's pixels through
+    mask_at_box, the perceptual module gets (1,3,H,W) images and its value REPLACES the MSE in the loss."""
+    import copy
+    from invr.trainer import NetworkWrapper
+    from invr.losses import PerceptualLoss
+    cfg, sd, batch, gb, net0 = gpu_setup
+    net = copy.deepcopy(net0).train()
+    net.cfg = copy.deepcopy(cfg)
+    net.cfg.use_lpips = True
+    torch.manual_seed(3)
+    pl = PerceptualLoss(allow_random=True).to(DEV)
+    wrap = NetworkWrapper(net, perceptual_loss=pl)
+    seen = {}
+    def spy(x, t):
+        seen['x'], seen['t'] = x, t
+        return pl(x, t)
+    wrap.perceptual_loss = spy
+    tb = dict(gb)                                    # the whole 64x64 frame as the "patch": mask_at_box has holes
+    tb['iter_step'] = 2
+    ret, loss, stats, _ = wrap(tb, split='train')
+    H, W = int(gb['H']), int(gb['W'])
+    assert seen['x'].shape == (1, 3, H, W) and seen['t'].shape == (1, 3, H, W)
+    m = gb['mask_at_box'][0].reshape(H, W)
+    ref = torch.zeros(H, W, 3, device=DEV)
+    ref[m] = ret['rgb_map'][0].detach()
+    assert torch.equal(seen['x'][0].permute(1, 2, 0).detach(), ref)
+    refg = torch.zeros(H, W, 3, device=DEV)
+    refg[m] = gb['rgb'][0]
+    assert torch.equal(seen['t'][0].permute(1, 2, 0), refg)
+    assert {'lpips_loss', 'img_loss', 'psnr', 'loss'} <= set(stats)
+    other = cfg.reg_dist_weight * stats['reg_dist'] + cfg.resd_loss_weight * stats['offset_loss']
+    if 'pair_loss' in stats:
+        other = other + cfg.pair_loss_weight * stats['pair_loss']
+    assert abs(float(loss) - float(other + stats['lpips_loss'])) < 1e-6        # no separate MSE term (:206-209)
+    loss.backward()
+    gsum = sum(float(p.grad.abs().sum()) for p in net.parameters() if p.grad is not None)
+    assert np.isfinite(gsum) and gsum > 0
 
 
 def test_network_forward_on_points(gpu_setup, golden):
