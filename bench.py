@@ -125,7 +125,7 @@ def train_probe(net, dev, S, iters):
     net.eval()
     return {'ms_per_iter': dt * 1e3, 'rays_per_iter': int(batch['ray_o'].shape[1]), 'samples_per_ray': S,
             'ray_samples_per_sec': batch['ray_o'].shape[1] * S / dt, 'optimizer': type(opt).__name__,
-            'parameters_updated': int(sum(p.numel() for p in net.parameters() if p.requires_grad)), 'final_loss': loss}
+            'parameters_updated': int(sum(p.numel() for p in net.parameters() if p.requires_grad)), 'final_loss': float(loss)}
 
 
 def main():

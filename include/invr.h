@@ -309,8 +309,15 @@ typedef struct InvrAdamTensor {
     float* exp_avg_sq;          /* dev, updated in place */
     int64_t numel;
     float lr, weight_decay, bc1, bc2_sqrt;
+    int32_t grad_shift;         /* 0: grad has numel elements.  s > 0: grad is a ROW-SCALAR gradient of numel >> s floats, element i
+                                   takes grad[i >> s] (sum-over-features hash tables: invr_train_bwd's compact table gradients) */
+    int32_t step;               /* step count kept on the device by invr_adam_advance */
 } InvrAdamTensor;
 int32_t invr_adam_chunk_elems(void);
+/* step += 1 and bc1 / bc2_sqrt = 1 - beta1^step / sqrt(1 - beta2^step) (in double, as torch's host code) for the n entries of a
+ * DEVICE tensor table: a training loop uploads the table once and replays {invr_adam_advance, invr_adam_step} every iteration
+ * without touching the host (torch.optim.Adam computes the corrections on the host per step and per group). */
+int invr_adam_advance(InvrAdamTensor* tensors, int32_t n, float beta1, float beta2, void* stream);
 int invr_adam_step(const InvrAdamTensor* tensors, const int32_t* chunk_tensor, const int32_t* chunk_index,
                    int64_t n_chunks, float beta1, float beta2, float eps, void* stream);
 
@@ -326,6 +333,65 @@ int invr_rigid_transformation(const double* poses, const double* joints, const i
 int invr_pack_parts(const float* ppts, const float* weights, const int64_t* parts, const float* tpose,
                     int32_t n_verts, int32_t n_weights, int32_t stride, float bbox_overlap,
                     float* part_pts, float* part_pbw, int64_t* lengths2, float* bounds, void* stream);
+
+/* ---- training iteration (row f1): forward + backward of the whole path, stream-ordered, no host round trip -------------
+ * Together the two calls are one `loss.backward()`-able evaluation of Renderer.render in train mode
+ * (inb_renderer.py:53-103) with NetworkWrapper's regularisers (inb_trainer.py:45-48,84-92) pre-reduced on the device.
+ *
+ * invr_train_fwd = invr_render_fwd (jitter = the stratified perturbation, 64-byte table rows) plus
+ *   dist_loss (n_rays)           : reg_distortion_loss (inb_renderer.py:96-103), NULL to skip
+ *   terms (INVR_TERM_LEN floats) : [INVR_TERM_OFFSET_SUM] sum over the reference's dense (Na*P,3) resd rows of ||resd||,
+ *                                  [INVR_TERM_OFFSET_ROWS] Na*P (offset_loss = sum / rows, inb_trainer.py:89-92);
+ *                                  [INVR_TERM_PAIR_SUM] sum over the selected pair-regulariser rows (|tocc - 0.5| < 0.02,
+ *                                  inb_renderer.py:80-86) of crit.reg_raw_crit's per-pair term (crit.py:8-18),
+ *                                  [INVR_TERM_PAIR_ROWS] their number n (pair_loss = sum / n when n > 0)
+ *   pair_noise (pair_noise_rows,3): uniform [0,1) per dense (slot, part) row, pair_noise_rows >= survivor capacity * 5
+ *                                  (compute_val_pair_around_range's torch.rand_like, inb_part_network_multiassign.py:41);
+ *                                  NULL = no pair regulariser (cfg.use_pair_reg False)
+ * raw (N,4), weights and z_vals (n_rays,n_samples) are REQUIRED: invr_train_bwd reads them back together with the pair
+ * lists the forward left in the workspace (same buffer, untouched in between; invr_train_workspace_bytes).
+ *
+ * invr_train_bwd: gradients of a scalar loss given its gradients w.r.t. rgb_map (n_rays,3), acc_map (n_rays) [NULL = 0],
+ * dist_loss (n_rays) [NULL = 0], raw (N,4) [NULL = 0] and the two sums of `terms` (DEVICE float[1] each, NULL = 0).
+ * Every gradient is ACCUMULATED into the caller's (pre-zeroed) buffers of InvrTrainGrads; the gradient of a part's
+ * sum-over-features hash tables is the compact row-scalar array (one float per table row, invr_grid_row_sums order:
+ * d out / d table[row][f] is the same for all 16 f) — 16x less gradient traffic for the optimiser and for a data-parallel
+ * all-reduce; invr_expand_row_grad turns it into the dense tensor gradient when one is wanted. */
+#define INVR_TERM_OFFSET_SUM 0
+#define INVR_TERM_OFFSET_ROWS 1
+#define INVR_TERM_PAIR_SUM 2
+#define INVR_TERM_PAIR_ROWS 3
+#define INVR_TERM_LEN 8
+typedef struct InvrPartGrads {
+    float* row_grad;                        /* dev (invr_grid_row_sums_len) */
+    float* occ_w[INVR_MAX_LINEAR];          /* dev, shapes of InvrMlp.weight / bias */
+    float* occ_b[INVR_MAX_LINEAR];
+    float* rgb_w[INVR_MAX_LINEAR];
+    float* rgb_b[INVR_MAX_LINEAR];
+    float* rgb_latent;                      /* dev (num_latent_code, latent_dim): row latent_index receives the gradient */
+} InvrPartGrads;
+typedef struct InvrTrainGrads {
+    InvrPartGrads part[INVR_NUM_PARTS];
+    float* deform_dense;                    /* dev, shapes of the deformer grid's dense / hash tables */
+    float* deform_hash;
+    float* deform_w[INVR_MAX_LINEAR];
+    float* deform_b[INVR_MAX_LINEAR];
+} InvrTrainGrads;
+size_t invr_train_workspace_bytes(int64_t n_rays, int32_t n_samples, int64_t max_active);
+int invr_train_fwd(const InvrScene* scene, const InvrModel* model,
+                   const float* ray_o, const float* ray_d, const float* near, const float* far, const float* jitter,
+                   int64_t n_rays, int32_t n_samples, const float* pair_noise, int64_t pair_noise_rows,
+                   float* rgb_map, float* acc_map, float* raw, float* occ, float* weights, float* z_vals,
+                   float* dist_loss, float* terms, int32_t* stats,
+                   void* workspace, size_t workspace_bytes, int64_t max_active, void* stream);
+int invr_train_bwd(const InvrScene* scene, const InvrModel* model, int64_t n_rays, int32_t n_samples,
+                   const float* raw, const float* weights, const float* z_vals,
+                   const float* g_rgb_map, const float* g_acc_map, const float* g_dist_loss, const float* g_raw,
+                   const float* g_offset_sum, const float* g_pair_sum, const InvrTrainGrads* grads,
+                   void* workspace, size_t workspace_bytes, int64_t max_active, void* stream);
+/* row-scalar table gradient (invr_grid_row_sums order) -> dense gradients g_dense (dense_rows,F) / g_hash (n_hash,T,F) of the
+ * grid's tables (every feature of a row takes the row's scalar); overwrites.  g_dense may be NULL for a non-separate table. */
+int invr_expand_row_grad(const InvrGrid* grid, const float* row_grad, float* g_dense, float* g_hash, void* stream);
 
 /* Backward of invr_composite_fwd: g_rgb_map (n_rays,3), g_acc_map (n_rays) or NULL, g_weights
  * (n_rays,n_samples) or NULL (e.g. from the distortion regulariser) -> g_raw (n_rays,n_samples,4). */

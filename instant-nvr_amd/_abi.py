@@ -35,7 +35,18 @@ class InvrMlpBwdOut(C.Structure):
 
 class InvrAdamTensor(C.Structure):
     _fields_ = [('param', C.c_void_p), ('grad', C.c_void_p), ('exp_avg', C.c_void_p), ('exp_avg_sq', C.c_void_p),
-                ('numel', C.c_int64), ('lr', C.c_float), ('weight_decay', C.c_float), ('bc1', C.c_float), ('bc2_sqrt', C.c_float)]
+                ('numel', C.c_int64), ('lr', C.c_float), ('weight_decay', C.c_float), ('bc1', C.c_float), ('bc2_sqrt', C.c_float),
+                ('grad_shift', C.c_int32), ('step', C.c_int32)]
+
+
+class InvrPartGrads(C.Structure):
+    _fields_ = [('row_grad', C.c_void_p), ('occ_w', C.c_void_p * 4), ('occ_b', C.c_void_p * 4), ('rgb_w', C.c_void_p * 4),
+                ('rgb_b', C.c_void_p * 4), ('rgb_latent', C.c_void_p)]
+
+
+class InvrTrainGrads(C.Structure):
+    _fields_ = [('part', InvrPartGrads * NUM_PARTS), ('deform_dense', C.c_void_p), ('deform_hash', C.c_void_p),
+                ('deform_w', C.c_void_p * 4), ('deform_b', C.c_void_p * 4)]
 
 
 class InvrMlp(C.Structure):
@@ -77,7 +88,8 @@ EXPORTS = ['invr_last_error', 'invr_version', 'invr_sizeof', 'invr_workspace_byt
            'invr_distortion_fwd', 'invr_grid_encode_bwd', 'invr_composite_bwd',
            'invr_field_workspace_bytes', 'invr_field_fwd', 'invr_geometry_fwd', 'invr_generate_rays',
            'invr_rigid_transformation', 'invr_pack_parts', 'invr_grid_row_sums_len', 'invr_grid_row_sums', 'invr_adam_chunk_elems', 'invr_adam_step', 'invr_part_mlp_fwd', 'invr_part_mlp_bwd',
-           'invr_knn_neighbors', 'invr_pose_points']
+           'invr_knn_neighbors', 'invr_pose_points', 'invr_adam_advance', 'invr_train_workspace_bytes', 'invr_train_fwd',
+           'invr_train_bwd', 'invr_expand_row_grad']
 NUM_STAGES = 14
 STAGE_NAMES = ['cull', 'knn', 'warp'] + ['encode_%d' % p for p in range(5)] + ['mlp_%d' % p for p in range(5)] + ['composite']
 
@@ -95,7 +107,7 @@ def lib():
         L.invr_version.restype = C.c_int
         L.invr_sizeof.restype = C.c_size_t
         L.invr_sizeof.argtypes = [C.c_int32]
-        for i, t in enumerate((InvrGrid, InvrMlp, InvrPart, InvrModel, InvrScene, InvrWsLayout, InvrMlpBwdOut, InvrAdamTensor)):
+        for i, t in enumerate((InvrGrid, InvrMlp, InvrPart, InvrModel, InvrScene, InvrWsLayout, InvrMlpBwdOut, InvrAdamTensor, InvrTrainGrads)):
             if L.invr_sizeof(i) != C.sizeof(t):
                 raise RuntimeError('libinvr ABI mismatch: struct %s is %d bytes in the library, %d in the binding'
                                    % (t.__name__, L.invr_sizeof(i), C.sizeof(t)))
@@ -109,6 +121,18 @@ def lib():
         L.invr_grid_encode_fwd.argtypes = [C.POINTER(InvrGrid), vp, C.c_int64, vp, vp]
         L.invr_sample_volume.argtypes = [vp, C.c_int32 * 3, C.c_int32, C.c_int32, C.c_int32, vp, vp, C.c_int64, vp, vp]
         L.invr_knn_blend.argtypes = [C.POINTER(InvrScene), vp, C.c_int64, vp, vp, vp]
+        L.invr_adam_advance.argtypes = [vp, C.c_int32, C.c_float, C.c_float, vp]
+        L.invr_adam_advance.restype = C.c_int
+        L.invr_train_workspace_bytes.restype = C.c_size_t
+        L.invr_train_workspace_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int64]
+        L.invr_train_fwd.argtypes = [C.POINTER(InvrScene), C.POINTER(InvrModel), vp, vp, vp, vp, vp, C.c_int64, C.c_int32, vp, C.c_int64,
+                                     vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, C.c_int64, vp]
+        L.invr_train_fwd.restype = C.c_int
+        L.invr_train_bwd.argtypes = [C.POINTER(InvrScene), C.POINTER(InvrModel), C.c_int64, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                                     C.POINTER(InvrTrainGrads), vp, C.c_size_t, C.c_int64, vp]
+        L.invr_train_bwd.restype = C.c_int
+        L.invr_expand_row_grad.argtypes = [C.POINTER(InvrGrid), vp, vp, vp, vp]
+        L.invr_expand_row_grad.restype = C.c_int
         L.invr_knn_neighbors.argtypes = [C.POINTER(InvrScene), vp, C.c_int64, vp, vp, vp, vp, vp]
         L.invr_knn_neighbors.restype = C.c_int
         L.invr_pose_points.argtypes = [C.POINTER(InvrScene), vp, vp, vp, vp, vp, C.c_int64, C.c_int32, vp, C.c_int64, vp, vp, vp]

@@ -345,3 +345,197 @@ def render_train(net, batch, geo, views, stats, n_rays, S, pair_noise):
     if cfg.use_reg_distortion:
         ret['reg_distortion_loss'] = distortion(weights, geo['z_vals'])[None]
     return ret
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Fused training iteration: invr_train_fwd / invr_train_bwd (csrc/k_train.hip).  No host round trip, no torch op soup.
+# ---------------------------------------------------------------------------------------------------------------------
+TERM_OFFSET_SUM, TERM_OFFSET_ROWS, TERM_PAIR_SUM, TERM_PAIR_ROWS, TERM_LEN = 0, 1, 2, 3, 8
+
+
+class GradArena:
+    """Persistent gradient storage of one Network for the fused training path.
+
+    One flat fp32 buffer holds the gradients of every small parameter (MLPs, latent codes, deformer tables) as views
+    (`p.grad` aliases them); the five part grids keep compact row-scalar gradients (Embedder.row_grad).  The fused backward
+    ACCUMULATES into the arena; `zero()` (FusedAdam.zero_grad / after a step) clears it with a handful of memsets.  Because
+    the addresses never change, the InvrTrainGrads struct and FusedAdam's device tensor table are built once."""
+
+    def __init__(self, net):
+        self.net = net
+        dev = next(net.parameters()).device
+        self.tables = []                                      # part-grid tables: no dense gradient in this mode
+        for pn in net.tpose_human.part_networks:
+            e = pn.embedder
+            self.tables += [e.hash] + ([e.dense] if e.separate_dense else [])
+        tab_ids = {id(t) for t in self.tables}
+        self.small = [p for p in net.parameters() if p.requires_grad and id(p) not in tab_ids]
+        n = sum(p.numel() for p in self.small)
+        self.flat = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.views, o = {}, 0
+        for p in self.small:
+            self.views[id(p)] = self.flat[o:o + p.numel()].view_as(p)
+            o += p.numel()
+        self.embedders = [pn.embedder for pn in net.tpose_human.part_networks]
+        for e in self.embedders:
+            e.row_grad()
+        self.struct = self._build()
+        self.dirty = False
+
+    def grad_of(self, p):
+        return self.views[id(p)]
+
+    def _build(self):
+        net, G = self.net, _abi.InvrTrainGrads()
+        g = lambda p: self.views[id(p)].data_ptr()
+        for i, pn in enumerate(net.tpose_human.part_networks):
+            P = G.part[i]
+            P.row_grad = pn.embedder.row_grad().data_ptr()
+            for k, l in enumerate(pn.occ.linears):
+                P.occ_w[k], P.occ_b[k] = g(l.weight), g(l.bias)
+            for k, l in enumerate(pn.rgb.linears):
+                P.rgb_w[k], P.rgb_b[k] = g(l.weight), g(l.bias)
+            P.rgb_latent = g(pn.rgb_latent)
+        e = net.tpose_deformer.embedder
+        G.deform_hash = g(e.hash)
+        if e.separate_dense:
+            G.deform_dense = g(e.dense)
+        for k, idx in enumerate((0, 2, 4)):
+            G.deform_w[k], G.deform_b[k] = g(net.tpose_deformer.mlp[idx].weight), g(net.tpose_deformer.mlp[idx].bias)
+        return G
+
+    def publish(self):
+        """p.grad of every small parameter = its arena view (aliases, no copy); table parameters keep grad None."""
+        for p in self.small:
+            if p.grad is not self.views[id(p)]:
+                p.grad = self.views[id(p)]
+        for e in self.embedders:
+            e.row_grad_dirty = True
+        self.dirty = True
+
+    def zero(self):
+        self.flat.zero_()
+        for e in self.embedders:
+            e.row_grad().zero_()
+            e.row_grad_dirty = False
+        self.dirty = False
+
+    def expand_tables(self):
+        """Dense .grad of the part tables from the row-scalar gradients (tests, foreign optimisers)."""
+        for e in self.embedders:
+            e.expand_row_grad()
+
+
+class TrainRenderFn(torch.autograd.Function):
+    """Renderer.render in train mode + the regulariser reductions as ONE differentiable node: forward = invr_train_fwd,
+    backward = invr_train_bwd.  `params` are the network's parameters (listed so that autograd connects the node to them).
+    Gradient delivery: with a GradArena (fused mode, FusedAdam) the backward accumulates into the arena and returns None for
+    the parameters; without one it returns fresh dense gradients like any autograd node (any optimiser, DDP hooks)."""
+
+    @staticmethod
+    def forward(ctx, net, rctx, arena, ray_o, ray_d, near, far, n_samples, jitter, pair_noise, max_active, *params):
+        L = _abi.lib()
+        dev = ray_o.device
+        f = lambda t: t.detach().to(torch.float32).contiguous()
+        ray_o, ray_d, near, far = f(ray_o), f(ray_d), f(near), f(far)
+        n, S = ray_o.shape[0], int(n_samples)
+        N = n * S
+        rgb = torch.empty(n, 3, device=dev); acc = torch.empty(n, device=dev)
+        raw = torch.empty(N, 4, device=dev); occ = torch.empty(N, device=dev)
+        weights = torch.empty(n, S, device=dev); z = torch.empty(n, S, device=dev)
+        dist = torch.empty(n, device=dev)
+        terms = torch.empty(TERM_LEN, device=dev)
+        stats = torch.zeros(_abi.STATS_LEN, dtype=torch.int32, device=dev)
+        nbytes = L.invr_train_workspace_bytes(n, S, max_active)
+        ws = net.workspace(nbytes, dev)
+        jit = None if jitter is None else f(jitter)
+        noise = None if pair_noise is None else f(pair_noise)
+        _abi.check(L.invr_train_fwd(C.byref(rctx.scene), C.byref(rctx.model), _abi.ptr(ray_o), _abi.ptr(ray_d), _abi.ptr(near), _abi.ptr(far),
+                                    _abi.ptr(jit), n, S, _abi.ptr(noise), 0 if noise is None else noise.shape[0],
+                                    _abi.ptr(rgb), _abi.ptr(acc), _abi.ptr(raw), _abi.ptr(occ), _abi.ptr(weights), _abi.ptr(z),
+                                    _abi.ptr(dist), _abi.ptr(terms), _abi.ptr(stats, torch.int32),
+                                    C.c_void_p(ws.data_ptr()), nbytes, max_active, _abi.stream_ptr()))
+        ctx.net, ctx.rctx, ctx.arena, ctx.ws, ctx.dims = net, rctx, arena, ws, (n, S, max_active, nbytes)
+        ctx.params = params
+        ctx.save_for_backward(raw, weights, z)
+        ctx.mark_non_differentiable(occ, weights, z, stats)
+        return rgb, acc, raw, dist, terms, occ, weights, z, stats
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_acc, g_raw, g_dist, g_terms, *_unused):
+        L = _abi.lib()
+        raw, weights, z = ctx.saved_tensors
+        net, rctx, arena = ctx.net, ctx.rctx, ctx.arena
+        n, S, max_active, nbytes = ctx.dims
+        dev = raw.device
+        c = lambda t: None if t is None else t.to(torch.float32).contiguous()
+        g_rgb = c(g_rgb) if g_rgb is not None else torch.zeros(n, 3, device=dev)
+        g_terms = c(g_terms)
+        g_off = g_pair = None
+        if g_terms is not None:
+            g_off, g_pair = g_terms[TERM_OFFSET_SUM:TERM_OFFSET_SUM + 1], g_terms[TERM_PAIR_SUM:TERM_PAIR_SUM + 1]
+        own = arena if arena is not None else GradArena(net)       # no arena: a throw-away one, handed to autograd below
+        _abi.check(L.invr_train_bwd(C.byref(rctx.scene), C.byref(rctx.model), n, S, _abi.ptr(raw), _abi.ptr(weights), _abi.ptr(z),
+                                    _abi.ptr(g_rgb), _abi.ptr(c(g_acc)), _abi.ptr(c(g_dist)), _abi.ptr(c(g_raw)),
+                                    C.c_void_p(g_off.data_ptr()) if g_off is not None else None,
+                                    C.c_void_p(g_pair.data_ptr()) if g_pair is not None else None,
+                                    C.byref(own.struct), C.c_void_p(ctx.ws.data_ptr()), nbytes, max_active, _abi.stream_ptr()))
+        head = (None,) * 11
+        if arena is not None:
+            arena.publish()
+            return head + (None,) * len(ctx.params)
+        # standard autograd delivery: dense gradients (the part tables expanded from their row scalars)
+        dense = {}
+        for e in own.embedders:
+            gd, gh = e.expand_row_grad()
+            e.hash.grad = None
+            dense[id(e.hash)] = gh
+            if e.separate_dense:
+                e.dense.grad = None
+                dense[id(e.dense)] = gd
+            e.row_grad().zero_()
+            e.row_grad_dirty = False
+        out = []
+        for p in ctx.params:
+            if id(p) in dense:
+                out.append(dense[id(p)])
+            elif id(p) in own.views:
+                out.append(own.views[id(p)].clone())
+            else:
+                out.append(None)
+        return head + tuple(out)
+
+
+class LazyTrainRet(dict):
+    """The train-mode return dict of Renderer.render.  rgb_map / acc_map / raw / occ / reg_distortion_loss and the fused
+    regulariser terms (offset_loss, pair_loss: differentiable scalars) are present; the reference's dynamic-shape tensors
+    resd / tpts / tocc / oresd are materialised from the workspace on first access (that read-back synchronises with the
+    device, like the reference's own nonzero()s; they are detached — the gradient flows through the fused terms)."""
+    def __init__(self, base, lazy_keys, materialise):
+        super().__init__(base)
+        self._lazy, self._mat, self._done = tuple(lazy_keys), materialise, False
+
+    def _fill(self):
+        if not self._done:
+            self._done = True
+            for k, v in self._mat().items():
+                dict.__setitem__(self, k, v)
+
+    def __contains__(self, k):
+        return dict.__contains__(self, k) or (not self._done and k in self._lazy)
+
+    def __getitem__(self, k):
+        if not dict.__contains__(self, k) and k in self._lazy:
+            self._fill()
+        return dict.__getitem__(self, k)
+
+    def get(self, k, d=None):
+        return self[k] if k in self else d
+
+    def keys(self):
+        self._fill()
+        return dict.keys(self)
+
+    def items(self):
+        self._fill()
+        return dict.items(self)

@@ -7,8 +7,8 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OUT = os.path.join(HERE, 'libinvr.so')
-SOURCES = ['invr_abi.hip', 'k_cull.hip', 'k_knn.hip', 'k_warp.hip', 'k_encode.hip', 'k_mlp.hip', 'k_composite.hip', 'k_rays.hip', 'k_prep.hip', 'k_optim.hip', 'k_mlp_bwd.hip']
-HEADERS = ['common.h', 'pipeline.h', 'grid_generic.h', 'mlp_common.h', os.path.join('..', '..', 'include', 'invr.h')]
+SOURCES = ['invr_abi.hip', 'k_cull.hip', 'k_knn.hip', 'k_warp.hip', 'k_encode.hip', 'k_mlp.hip', 'k_composite.hip', 'k_rays.hip', 'k_prep.hip', 'k_optim.hip', 'k_mlp_bwd.hip', 'k_train.hip']
+HEADERS = ['common.h', 'pipeline.h', 'grid_generic.h', 'mlp_common.h', 'train.h', os.path.join('..', '..', 'include', 'invr.h')]
 # -ffp-contract=off: FMAs only where the source says fmaf(), so the discrete decisions of the path
 # (cull / flag thresholds, integer cell selection) see the same fp32 arithmetic as the reference.
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wall', '-Wno-unused-function']

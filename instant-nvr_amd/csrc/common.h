@@ -235,7 +235,9 @@ __device__ __forceinline__ uint32_t grid_hash_mod(uint64_t x, const GridDev& g) 
 // ---- kernel launchers (defined in the .hip files) ---------------------------------------------
 int launch_grid_encode_generic(const GridDev& g, const float* xyz, int64_t n, float* out, hipStream_t st);
 int launch_grid_encode_bwd_generic(const GridDev& g, const float* xyz, const float* gout, int64_t n, float* g_dense,
-                                   float* g_hash, float* g_xyz, hipStream_t st);
+                                   float* g_hash, float* g_xyz, hipStream_t st, const int32_t* count = nullptr);
+int launch_part_encode_bwd_lists(const GridDev& g, const float* x_soa, const float* gout_soa, float* gx_soa, int64_t stride,
+                                 int64_t n_max, const int32_t* count, float* rowgrad, hipStream_t st);
 int launch_composite_bwd(const float* raw, const float* g_rgb, const float* g_acc, const float* g_w, int64_t n_rays, int S,
                          float* g_raw, hipStream_t st);
 int launch_sample_volume(const VolDev& v, int c0, int nc, const float* pts, int64_t n, float* out, hipStream_t st);
@@ -248,6 +250,7 @@ int launch_deform_points(const SceneDev& s, const GridDev& dg, const MlpDev& dm,
 int launch_distortion(const float* weights, const float* z, int64_t n_rays, int S, float* out, hipStream_t st);
 int launch_generate_rays(const double* kinv, const double* r, const double* t, const double* o, const float* bounds,
                          int H, int W, float* ray_d, float* near, float* far, uint8_t* mask, hipStream_t st);
+int launch_adam_advance(void* tensors, int n, float b1, float b2, hipStream_t st);
 int launch_adam(const void* tensors, const int32_t* chunk_tensor, const int32_t* chunk_index, int64_t n_chunks, float b1, float b2,
                 float eps, hipStream_t st);
 int launch_row_sums(const GridDev& g, float* out, hipStream_t st);

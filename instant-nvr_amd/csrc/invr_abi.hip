@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <vector>
 #include "pipeline.h"
+#include "train.h"
 
 static thread_local char g_err[512] = "";
 
@@ -31,6 +32,7 @@ extern "C" size_t invr_sizeof(int32_t which) {
         case 5: return sizeof(InvrWsLayout);
         case 6: return sizeof(InvrMlpBwdOut);
         case 7: return sizeof(InvrAdamTensor);
+        case 8: return sizeof(InvrTrainGrads);
         default: return 0;
     }
 }
@@ -569,6 +571,11 @@ extern "C" int invr_grid_row_sums(const InvrGrid* grid, float* out, void* stream
 
 extern "C" int32_t invr_adam_chunk_elems(void) { return 16384; }
 
+extern "C" int invr_adam_advance(InvrAdamTensor* tensors, int32_t n, float beta1, float beta2, void* stream) {
+    INVR_CHECK(n == 0 || tensors, "invr_adam_advance: null pointer");
+    return launch_adam_advance(tensors, n, beta1, beta2, (hipStream_t)stream);
+}
+
 extern "C" int invr_adam_step(const InvrAdamTensor* tensors, const int32_t* chunk_tensor, const int32_t* chunk_index,
                               int64_t n_chunks, float beta1, float beta2, float eps, void* stream) {
     INVR_CHECK(n_chunks == 0 || (tensors && chunk_tensor && chunk_index), "invr_adam_step: null pointer");
@@ -596,6 +603,174 @@ extern "C" int invr_part_mlp_bwd(const InvrModel* model, int32_t pid, const int6
     INVR_CHECK(oc.n_linear == 2 && oc.dims[0] == 19 && oc.dims[1] == 64 && oc.dims[2] == 17 && (r.n_linear == 2 || r.n_linear == 3) &&
                r.dims[0] == 70 && r.dims[1] == 64 && r.dims[r.n_linear] == 3 && pm.n_freq == 4 && pm.latent_dim == 8 && pm.geo_dim == 16,
                "invr_part_mlp_bwd: supports occ 19-64-17 and rgb 70-64(-64)-3");
-    MlpBwdOut o{out->g_emb, out->gz, out->a, out->n_pad, out->g_latent};
-    return launch_part_mlp_bwd(pm, emb_soa, dirs_soa, n, g_raw, o, (hipStream_t)stream);
+    MlpBwdOut o{out->g_emb, out->gz, out->a, out->n_pad, out->g_latent, 0};
+    return launch_part_mlp_bwd(pm, emb_soa, dirs_soa, n, n, nullptr, g_raw, nullptr, pid, o, (hipStream_t)stream);
+}
+
+// ---- training iteration (k_train.hip) ----------------------------------------------------------------------------------
+static size_t carve_train(TrainWs& t, void* base, size_t off0, int64_t N, int64_t lcap) {
+    Carver c{(char*)base, off0};
+    t.NB = lcap * INVR_NUM_PARTS;
+    t.DM = lcap * INVR_NUM_PARTS + t.NB;
+    t.pair_of = c.take<int32_t>(lcap * INVR_NUM_PARTS);
+    t.terms = nullptr;                                   // caller-owned (the forward's output)
+    t.nb_x = c.take<float>(t.NB * 3);
+    t.nb_r = c.take<float>(t.NB * 3);
+    t.nb_ref = c.take<int32_t>(t.NB);
+    t.g_w = c.take<float>(N);
+    t.g_rawfull = c.take<float4>(N);
+    t.g_raws = c.take<float4>(lcap * INVR_NUM_PARTS);
+    t.g_emb = c.take<float>(lcap * EMB_K);
+    for (int p = 0; p < INVR_NUM_PARTS; ++p) t.g_x[p] = c.take<float>(lcap * 3);
+    t.gz = c.take<float>(lcap * 5 * 64);
+    t.a = c.take<float>(lcap * 5 * 72);
+    t.d_pts = c.take<float>(t.DM * 3);
+    t.d_g = c.take<float>(t.DM * 3);
+    t.d_uvt = c.take<float>(t.DM * 3);
+    t.d_gfeat = c.take<float>(t.DM * 19);
+    t.d_gz1 = c.take<float>(t.DM * 32);
+    t.d_gz2 = c.take<float>(t.DM * 32);
+    t.d_gz3 = c.take<float>(t.DM * 4);
+    t.d_a0 = c.take<float>(t.DM * 20);
+    t.d_a1 = c.take<float>(t.DM * 32);
+    t.d_a2 = c.take<float>(t.DM * 32);
+    return align_up(c.off, 256);
+}
+
+static int64_t clamp_active(int64_t N, int64_t max_active) {
+    if (max_active <= 0 || max_active > N) max_active = N;
+    return max_active < 1 ? 1 : max_active;
+}
+
+extern "C" size_t invr_train_workspace_bytes(int64_t n_rays, int32_t n_samples, int64_t max_active) {
+    const int64_t N = n_rays * (int64_t)n_samples > 0 ? n_rays * (int64_t)n_samples : 1;
+    const int64_t cap = clamp_active(N, max_active);
+    Workspace w;
+    TrainWs t;
+    const size_t inner = carve(w, nullptr, N, cap);
+    return carve_train(t, nullptr, inner, N, cap + 1);
+}
+
+extern "C" int invr_train_fwd(const InvrScene* scene, const InvrModel* model,
+                              const float* ray_o, const float* ray_d, const float* near, const float* far, const float* jitter,
+                              int64_t n_rays, int32_t n_samples, const float* pair_noise, int64_t pair_noise_rows,
+                              float* rgb_map, float* acc_map, float* raw, float* occ, float* weights, float* z_vals,
+                              float* dist_loss, float* terms, int32_t* stats,
+                              void* workspace, size_t workspace_bytes, int64_t max_active, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    INVR_CHECK(scene && model && terms, "invr_train_fwd: null scene / model / terms");
+    INVR_HIP(hipMemsetAsync(terms, 0, TERM_LEN * sizeof(float), st));
+    if (n_rays == 0) return 0;
+    INVR_CHECK(raw && weights && z_vals, "invr_train_fwd: raw, weights and z_vals are required (the backward reads them)");
+    const int64_t N = n_rays * (int64_t)n_samples;
+    const int64_t cap = clamp_active(N, max_active);
+    INVR_CHECK(workspace && workspace_bytes >= invr_train_workspace_bytes(n_rays, n_samples, max_active), "invr_train_fwd: workspace too small");
+    INVR_CHECK(!pair_noise || pair_noise_rows >= cap * INVR_NUM_PARTS, "invr_train_fwd: pair_noise needs >= %lld rows", (long long)(cap * INVR_NUM_PARTS));
+    for (int p = 0; p < INVR_NUM_PARTS; ++p)
+        INVR_CHECK(model->part[p].grid.row_sums == nullptr, "invr_train_fwd: training reads the trainable 64-byte rows (row_sums must be NULL)");
+    const size_t inner = invr_workspace_bytes(n_rays, n_samples, max_active);
+    if (render_impl(scene, model, ray_o, ray_d, near, far, jitter, nullptr, nullptr, n_rays, n_samples, rgb_map, acc_map, raw, occ, weights,
+                    z_vals, nullptr, workspace, inner, max_active, stream))
+        return 1;
+    Workspace w;
+    TrainWs t;
+    carve(w, workspace, N, cap);
+    carve_train(t, workspace, inner, N, cap + 1);
+    t.terms = terms;
+    if (dist_loss && launch_distortion(weights, z_vals, n_rays, n_samples, dist_loss, st)) return 1;
+    RenderArgs a;
+    memset(&a, 0, sizeof(a));
+    a.scene = make_scene_dev(scene);
+    a.R = n_rays; a.S = n_samples; a.N = N;
+    if (launch_train_terms(a, w, t, make_grid_dev(&model->deform_grid), make_mlp_dev(&model->deform_mlp), pair_noise, st)) return 1;
+    if (stats) {
+        hipLaunchKernelGGL(k_export_stats, dim3(1), dim3(64), 0, st, w.counters, stats);
+        INVR_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+__global__ void k_add_inplace(float* __restrict__ dst, const float* __restrict__ src, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+
+extern "C" int invr_train_bwd(const InvrScene* scene, const InvrModel* model, int64_t n_rays, int32_t n_samples,
+                              const float* raw, const float* weights, const float* z_vals,
+                              const float* g_rgb_map, const float* g_acc_map, const float* g_dist_loss, const float* g_raw,
+                              const float* g_offset_sum, const float* g_pair_sum, const InvrTrainGrads* grads,
+                              void* workspace, size_t workspace_bytes, int64_t max_active, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    INVR_CHECK(scene && model && grads, "invr_train_bwd: null scene / model / grads");
+    if (n_rays == 0) return 0;
+    INVR_CHECK(raw && weights && z_vals && g_rgb_map, "invr_train_bwd: raw, weights, z_vals and g_rgb_map are required");
+    const int64_t N = n_rays * (int64_t)n_samples;
+    const int64_t cap = clamp_active(N, max_active);
+    INVR_CHECK(workspace && workspace_bytes >= invr_train_workspace_bytes(n_rays, n_samples, max_active), "invr_train_bwd: workspace too small");
+    const size_t inner = invr_workspace_bytes(n_rays, n_samples, max_active);
+    Workspace w;
+    TrainWs t;
+    carve(w, workspace, N, cap);
+    carve_train(t, workspace, inner, N, cap + 1);
+    const int64_t lcap = w.lcap;
+    // distortion^T -> compositing^T (-> + direct gradient of raw) -> merge^T
+    if (g_dist_loss && launch_distortion_bwd(weights, z_vals, g_dist_loss, n_rays, n_samples, t.g_w, st)) return 1;
+    if (launch_composite_bwd(raw, g_rgb_map, g_acc_map, g_dist_loss ? t.g_w : nullptr, n_rays, n_samples, reinterpret_cast<float*>(t.g_rawfull), st)) return 1;
+    if (g_raw) {
+        hipLaunchKernelGGL(k_add_inplace, dim3((unsigned)cdiv(N * 4, 256)), dim3(256), 0, st, reinterpret_cast<float*>(t.g_rawfull), g_raw, N * 4);
+        INVR_LAUNCH_CHECK();
+    }
+    if (launch_merge_bwd(w, t.g_rawfull, t.g_raws, st)) return 1;
+    // per part: MLPs^T -> weight gradients -> encoder^T (largest part first)
+    for (int p = 0; p < INVR_NUM_PARTS; ++p) {
+        const InvrPartGrads& G = grads->part[p];
+        PartMlpDev pm = make_part_mlp(model, p, scene->latent_index);
+        const int n_rgb = pm.rgb.n_linear;
+        INVR_CHECK(G.row_grad && G.rgb_latent && G.occ_w[0] && G.occ_b[0] && G.occ_w[1] && G.occ_b[1] && G.rgb_w[0] && G.rgb_b[0] &&
+                   G.rgb_w[n_rgb - 1] && G.rgb_b[n_rgb - 1], "invr_train_bwd: null gradient pointer (part %d)", p);
+        INVR_CHECK(pm.occ.n_linear == 2 && pm.occ.dims[0] == 19 && pm.occ.dims[1] == 64 && pm.occ.dims[2] == 17 && (n_rgb == 2 || n_rgb == 3) &&
+                   pm.rgb.dims[0] == 70 && pm.rgb.dims[1] == 64 && pm.rgb.dims[n_rgb] == 3 && pm.n_freq == 4 && pm.latent_dim == 8 && pm.geo_dim == 16,
+                   "invr_train_bwd: supports occ 19-64-17 and rgb 70-64(-64)-3");
+        const int32_t* count = w.counters + CNT_PAIRS + p;
+        MlpBwdOut o{t.g_emb, t.gz, t.a, lcap, G.rgb_latent, 1};
+        if (launch_part_mlp_bwd(pm, w.emb[p], w.l_d[p], lcap, lcap, count, reinterpret_cast<const float*>(t.g_raws), w.l_slot[p], p, o, st)) return 1;
+        float* dW[5] = {G.occ_w[0], G.occ_w[1], G.rgb_w[0], n_rgb == 3 ? G.rgb_w[1] : nullptr, G.rgb_w[n_rgb - 1]};
+        float* db[5] = {G.occ_b[0], G.occ_b[1], G.rgb_b[0], n_rgb == 3 ? G.rgb_b[1] : nullptr, G.rgb_b[n_rgb - 1]};
+        if (launch_part_wgrad(t.gz, t.a, lcap, n_rgb, dW, db, count, st)) return 1;
+        GridDev g = make_grid_dev(&model->part[p].grid);
+        if (launch_part_encode_bwd_lists(g, w.l_x[p], t.g_emb, t.g_x[p], lcap, lcap, count, G.row_grad, st)) return 1;
+    }
+    // deformer^T over the listed pairs and the pair-regulariser neighbours
+    if (check_grid(&model->deform_grid, "deformer grid") || check_mlp_deform(&model->deform_mlp)) return 1;
+    INVR_CHECK(grads->deform_hash && (!model->deform_grid.separate_dense || grads->deform_dense) && grads->deform_w[0] && grads->deform_w[1] &&
+               grads->deform_w[2] && grads->deform_b[0] && grads->deform_b[1] && grads->deform_b[2], "invr_train_bwd: null deformer gradient pointer");
+    DeformGrads DG{{grads->deform_w[0], grads->deform_w[1], grads->deform_w[2]}, {grads->deform_b[0], grads->deform_b[1], grads->deform_b[2]},
+                   grads->deform_dense, grads->deform_hash};
+    RenderArgs a;
+    memset(&a, 0, sizeof(a));
+    a.scene = make_scene_dev(scene);
+    a.R = n_rays; a.S = n_samples; a.N = N;
+    return launch_deform_bwd(a, w, t, make_grid_dev(&model->deform_grid), make_mlp_dev(&model->deform_mlp), g_offset_sum, g_pair_sum, DG, st);
+}
+
+__global__ void k_expand_row_grad(const float* __restrict__ rg, int64_t rows, int F, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < rows * F) out[i] = rg[i / F];
+}
+
+extern "C" int invr_expand_row_grad(const InvrGrid* grid, const float* row_grad, float* g_dense, float* g_hash, void* stream) {
+    INVR_CHECK(grid && row_grad && g_hash, "invr_expand_row_grad: null pointer");
+    if (check_grid(grid, "grid")) return 1;
+    INVR_CHECK(grid->sum && grid->sum_over_features, "invr_expand_row_grad: only sum && sum_over_features grids have row-scalar gradients");
+    GridDev g = make_grid_dev(grid);
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t hrows = (int64_t)(g.separate_dense ? g.L - g.start_hash : g.L) * g.T;
+    if (g.separate_dense && g.dense_rows) {
+        INVR_CHECK(g_dense, "invr_expand_row_grad: g_dense required");
+        hipLaunchKernelGGL(k_expand_row_grad, dim3((unsigned)cdiv(g.dense_rows * g.F, 256)), dim3(256), 0, st, row_grad, g.dense_rows, g.F, g_dense);
+        INVR_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_expand_row_grad, dim3((unsigned)cdiv(hrows * g.F, 256)), dim3(256), 0, st, row_grad + g.dense_rows, hrows, g.F, g_hash);
+    INVR_LAUNCH_CHECK();
+    return 0;
 }

@@ -75,9 +75,11 @@ int launch_part_encode_bwd(const GridDev& g, const float* xyz, const float* gout
 // hammered by every point (the deformer's (u,v,t) input has a constant t: a 2-D slice of each level
 // receives everything) costs one global atomic per touched entry per workgroup.
 __global__ __launch_bounds__(BWD_BLOCK) void k_grid_encode_bwd_rt(GridDev g, const float* __restrict__ xyz,
-                                                                  const float* __restrict__ gout, int64_t n, int out_dim,
+                                                                  const float* __restrict__ gout, int64_t n_host,
+                                                                  const int32_t* __restrict__ count, int out_dim,
                                                                   float* g_dense, float* g_hash, float* __restrict__ g_xyz) {
     extern __shared__ __attribute__((aligned(16))) float sacc[];
+    const int64_t n = count ? (int64_t)*count : n_host;
     const int off = g.include_input ? 3 : 0;
     const bool rowscalar = g.sum && g.sum_over_features;
     const int Fe = rowscalar ? 1 : g.F;                         // accumulated floats per row
@@ -162,10 +164,10 @@ __global__ void k_expand_rows(float* __restrict__ gtab, int64_t rows, int F) {
 }
 
 int launch_grid_encode_bwd_generic(const GridDev& g, const float* xyz, const float* gout, int64_t n, float* g_dense,
-                                   float* g_hash, float* g_xyz, hipStream_t st) {
+                                   float* g_hash, float* g_xyz, hipStream_t st, const int32_t* count) {
     if (n == 0) return 0;
     int od = (g.sum ? (g.sum_over_features ? g.L : g.F) : g.L * g.F) + (g.include_input ? 3 : 0);
-    const bool fast = g.L == 16 && g.F == 16 && g.sum && g.sum_over_features && g.include_input;
+    const bool fast = g.L == 16 && g.F == 16 && g.sum && g.sum_over_features && g.include_input && !count;
     if (fast) { if (launch_part_encode_bwd(g, xyz, gout, n, g_dense, g_hash, g_xyz, st)) return 1; }
     else {
         static bool attr_set = false;
@@ -178,7 +180,7 @@ int launch_grid_encode_bwd_generic(const GridDev& g, const float* xyz, const flo
             attr_set = true;
         }
         int64_t nb = cdiv(n, BWD_BLOCK);
-        hipLaunchKernelGGL(k_grid_encode_bwd_rt, dim3((unsigned)(nb < 256 ? nb : 256)), dim3(BWD_BLOCK), lds, st, g, xyz, gout, n, od,
+        hipLaunchKernelGGL(k_grid_encode_bwd_rt, dim3((unsigned)(nb < 256 ? nb : 256)), dim3(BWD_BLOCK), lds, st, g, xyz, gout, n, count, od,
                            g_dense, g_hash, g_xyz);
     }
     INVR_LAUNCH_CHECK();
@@ -334,12 +336,27 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_part_encode(GridDev g, const floa
 #define BWD_SMALL_ROWS 1100
 #define BWD_SMALL_FLOATS 6144
 
-__global__ __launch_bounds__(ENC_BLOCK) void k_part_encode_bwd(GridDev g, const float* __restrict__ xyz,
-                                                               const float* __restrict__ gout, int64_t n, int tp,
-                                                               float* g_dense, float* g_hash, float* __restrict__ g_xyz) {
+// Layout-generic: element (point i, component c) of xyz / gout / g_xyz sits at i*ps + c*cs (AoS (n,3)/(n,19): ps = 3/19,
+// cs = 1; the SoA pair lists of the training pipeline: ps = 1, cs = list stride); the point count is `n_host` or, when
+// `count` is given, read on the device.  Table gradients go either into column 0 of the full-size gradient tables
+// (g_dense / g_hash, expanded by k_expand_rows) or — `rowgrad` — into a compact (rows,) array in invr_grid_row_sums
+// order (dense rows, then T per hashed level): the gradient of a sum-over-features table IS one scalar per row.
+struct EncBwdIO {
+    const float* xyz; int64_t x_ps, x_cs;
+    const float* gout; int64_t go_ps, go_cs;
+    float* g_xyz; int64_t gx_ps, gx_cs;
+    int64_t n_host; const int32_t* count;
+    float* g_dense; float* g_hash; float* rowgrad;
+};
+
+__global__ __launch_bounds__(ENC_BLOCK) void k_part_encode_bwd(GridDev g, EncBwdIO io) {
     __shared__ float sgo[ENC_WAVES][64][20];          // g_out tile of the wave
     __shared__ float sgx[ENC_WAVES][64][3];           // per point: gradient w.r.t. the normalised coordinate
     __shared__ float ssmall[BWD_SMALL_FLOATS];        // per-workgroup accumulators of the small dense levels
+    const int64_t n = io.count ? (int64_t)*io.count : io.n_host;
+    if (n <= 0) return;
+    int tp = 64;                                      // points per wave tile: enough waves to fill the GPU, long enough runs to combine
+    while (tp > 16 && n / tp < 4096) tp >>= 1;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int level = lane >> 2, q = lane & 3;
     LaneLevel L;
@@ -349,7 +366,17 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_part_encode_bwd(GridDev g, const 
     const float* tb = g.separate_dense
         ? (L.hashed ? g.hash + (int64_t)(level - g.start_hash) * g.T * 16 : g.dense + g.dense_off[level] * 16)
         : g.hash + (int64_t)level * g.T * 16;
-    float* gtb = g.separate_dense ? (L.hashed ? g_hash + (tb - g.hash) : g_dense + (tb - g.dense)) : g_hash + (tb - g.hash);
+    // gradient base of my level + stride between rows: full-size table (column 0 of a 16-float row) or compact row scalars
+    float* gtb;
+    int gstride;
+    if (io.rowgrad) {
+        gtb = io.rowgrad + (g.separate_dense ? (L.hashed ? g.dense_rows + (int64_t)(level - g.start_hash) * g.T : g.dense_off[level])
+                                             : (int64_t)level * g.T);
+        gstride = 1;
+    } else {
+        gtb = g.separate_dense ? (L.hashed ? io.g_hash + (tb - g.hash) : io.g_dense + (tb - g.dense)) : io.g_hash + (tb - g.hash);
+        gstride = 16;
+    }
     L.tab = reinterpret_cast<const float4*>(tb) + q;
     // LDS slot of my level (small dense levels only), laid out back to back
     int small_off = -1, small_total = 0;
@@ -370,8 +397,14 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_part_encode_bwd(GridDev g, const 
         const int64_t base = tile * tp;
         const int m = (int)min((int64_t)tp, n - base);
         const int64_t pi = base + min(lane, m - 1);
-        const float xi = (xyz[pi * 3] - b0x) / ex, yi = (xyz[pi * 3 + 1] - b0y) / ey, zi = (xyz[pi * 3 + 2] - b0z) / ez;
-        for (int e = lane; e < m * 19; e += 64) sgo[wv][e / 19][e % 19] = gout[base * 19 + e];      // coalesced tile copy
+        const float xi = (io.xyz[pi * io.x_ps] - b0x) / ex, yi = (io.xyz[pi * io.x_ps + io.x_cs] - b0y) / ey,
+                    zi = (io.xyz[pi * io.x_ps + 2 * io.x_cs] - b0z) / ez;
+        if (io.go_cs == 1) {
+            for (int e = lane; e < m * 19; e += 64) sgo[wv][e / 19][e % 19] = io.gout[base * io.go_ps + e];      // coalesced AoS tile copy
+        } else if (lane < m) {
+#pragma unroll
+            for (int k = 0; k < 19; ++k) sgo[wv][lane][k] = io.gout[(base + lane) * io.go_ps + k * io.go_cs];   // coalesced SoA rows
+        }
         // run-length combining: consecutive pairs of the list are consecutive samples of a ray / neighbouring rays and
         // fall into the same cell of the coarse and middle levels, where a 64x64 training patch puts 1e4..1e5
         // contributions on a few dozen rows — their same-address global atomics serialised the kernel (0.6 ms per
@@ -382,7 +415,7 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_part_encode_bwd(GridDev g, const 
         for (int k = 0; k < 8; ++k) { prow[k] = 0xFFFFFFFFu; pval[k] = 0.0f; }
         auto flush = [&](unsigned r, float vsum) {
             if (small_off >= 0) atomicAdd(&ssmall[small_off + r], vsum);
-            else unsafeAtomicAdd(gtb + (size_t)r * 16, vsum);                 // column 0 = row scalar
+            else unsafeAtomicAdd(gtb + (size_t)r * gstride, vsum);          // column 0 = row scalar
         };
         for (int j = 0; j < m; ++j) {
             const float x = rdlane(xi, j), y = rdlane(yi, j), z = rdlane(zi, j);
@@ -444,10 +477,10 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_part_encode_bwd(GridDev g, const 
             for (int k = 0; k < 8; ++k)
                 if (prow[k] != 0xFFFFFFFFu) flush(prow[k], pval[k]);
         }
-        if (g_xyz && lane < m) {
-            g_xyz[(base + lane) * 3 + 0] = (sgx[wv][lane][0] + sgo[wv][lane][0]) / ex;
-            g_xyz[(base + lane) * 3 + 1] = (sgx[wv][lane][1] + sgo[wv][lane][1]) / ey;
-            g_xyz[(base + lane) * 3 + 2] = (sgx[wv][lane][2] + sgo[wv][lane][2]) / ez;
+        if (io.g_xyz && lane < m) {
+            io.g_xyz[(base + lane) * io.gx_ps + 0 * io.gx_cs] = (sgx[wv][lane][0] + sgo[wv][lane][0]) / ex;
+            io.g_xyz[(base + lane) * io.gx_ps + 1 * io.gx_cs] = (sgx[wv][lane][1] + sgo[wv][lane][1]) / ey;
+            io.g_xyz[(base + lane) * io.gx_ps + 2 * io.gx_cs] = (sgx[wv][lane][2] + sgo[wv][lane][2]) / ez;
         }
     }
     __syncthreads();
@@ -457,24 +490,41 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_part_encode_bwd(GridDev g, const 
         const int64_t rows = (int64_t)g.res[l] * g.res[l] * g.res[l];
         const bool small = l < (g.separate_dense ? g.start_hash : 0) && rows <= BWD_SMALL_ROWS && off + rows <= BWD_SMALL_FLOATS;
         if (!small) continue;
-        float* gl_tab = g_dense + g.dense_off[l] * 16;
+        float* gl_tab = io.rowgrad ? io.rowgrad + g.dense_off[l] : io.g_dense + g.dense_off[l] * 16;
         for (int j = threadIdx.x; j < (int)rows; j += ENC_BLOCK) {
             const float vv = ssmall[off + j];
-            if (vv != 0.0f) unsafeAtomicAdd(gl_tab + (size_t)j * 16, vv);
+            if (vv != 0.0f) unsafeAtomicAdd(gl_tab + (size_t)j * gstride, vv);
         }
         off += (int)rows;
     }
 }
 
-int launch_part_encode_bwd(const GridDev& g, const float* xyz, const float* gout, int64_t n, float* g_dense, float* g_hash,
-                           float* g_xyz, hipStream_t st) {
+static int launch_part_encode_bwd_io(const GridDev& g, const EncBwdIO& io, hipStream_t st) {
+    const int64_t n = io.n_host;                             // the count or its upper bound (device count given)
     int tp = 64;
-    while (tp > 16 && n / tp < 4096) tp >>= 1;                // enough waves to fill the GPU, long enough runs to combine
+    while (tp > 16 && n / tp < 4096) tp >>= 1;
     int64_t tiles = cdiv(n, (int64_t)tp * ENC_WAVES);
     unsigned grid = (unsigned)(tiles < 2048 ? (tiles > 0 ? tiles : 1) : 2048);
-    hipLaunchKernelGGL(k_part_encode_bwd, dim3(grid), dim3(ENC_BLOCK), 0, st, g, xyz, gout, n, tp, g_dense, g_hash, g_xyz);
+    hipLaunchKernelGGL(k_part_encode_bwd, dim3(grid), dim3(ENC_BLOCK), 0, st, g, io);
     INVR_LAUNCH_CHECK();
     return 0;
+}
+
+int launch_part_encode_bwd(const GridDev& g, const float* xyz, const float* gout, int64_t n, float* g_dense, float* g_hash,
+                           float* g_xyz, hipStream_t st) {
+    EncBwdIO io{xyz, 3, 1, gout, 19, 1, g_xyz, 3, 1, n, nullptr, g_dense, g_hash, nullptr};
+    return launch_part_encode_bwd_io(g, io, st);
+}
+
+// training pipeline: SoA pair lists (stride `stride`), device count, compact row-scalar gradient
+int launch_part_encode_bwd_lists(const GridDev& g, const float* x_soa, const float* gout_soa, float* gx_soa, int64_t stride,
+                                 int64_t n_max, const int32_t* count, float* rowgrad, hipStream_t st) {
+    if (g.L != 16 || g.F != 16 || !g.sum || !g.sum_over_features || !g.include_input) {
+        invr_set_error("part encoder backward supports n_levels=16, n_features_per_level=16, sum, sum_over_features, include_input");
+        return 1;
+    }
+    EncBwdIO io{x_soa, 1, stride, gout_soa, 1, stride, gx_soa, 1, stride, n_max, count, nullptr, nullptr, rowgrad};
+    return launch_part_encode_bwd_io(g, io, st);
 }
 
 // ---- inference-only row-sum variant -------------------------------------------------------------------

@@ -32,8 +32,13 @@ __device__ __forceinline__ void store4(float* p, f32x4 v) { *reinterpret_cast<fl
 
 template <int NRGB>
 __global__ __launch_bounds__(MLP_BLOCK, 1) void k_part_mlp_bwd(PartMlpDev pm, const float* __restrict__ emb,
-                                                            const float* __restrict__ ds, int64_t n,
-                                                            const float4* __restrict__ g_raw, MlpBwdOut o) {
+                                                            const float* __restrict__ ds, int64_t n_host, int64_t stride,
+                                                            const int32_t* __restrict__ count,
+                                                            const float4* __restrict__ g_raw, const int32_t* __restrict__ l_slot,
+                                                            int part, MlpBwdOut o) {
+    // n pairs (device count when `count` is given: the training pipeline never learns it on the host); SoA inputs /
+    // outputs have `stride` entries per row; g_raw is (n,4) or, with l_slot, the per-(slot, part) array the merge wrote
+    const int64_t n = count ? (int64_t)*count : n_host;
     __shared__ float lds[LDS_FLOATS];
     stage_weights<NRGB>(pm, lds);
     __syncthreads();
@@ -49,15 +54,16 @@ __global__ __launch_bounds__(MLP_BLOCK, 1) void k_part_mlp_bwd(PartMlpDev pm, co
 #define A(l) (o.a + (int64_t)(l) * o.n_pad * 72)
 
     const int64_t per_block = (MLP_BLOCK / 64) * 16;
+    if (n <= 0) return;
     for (int64_t t0 = (int64_t)blockIdx.x * per_block + (int64_t)wv * 16; t0 < n; t0 += (int64_t)gridDim.x * per_block) {
         const int64_t pair = min(t0 + col, n - 1);
         const bool live = t0 + col < n;
         // ---------------- forward recompute (k_part_mlp, one column block) ----------------
         float eb[EMB_STEPS], dv[3];
 #pragma unroll
-        for (int s = 0; s < EMB_STEPS; ++s) eb[s] = emb[(int64_t)(4 * s + g) * n + pair];
+        for (int s = 0; s < EMB_STEPS; ++s) eb[s] = emb[(int64_t)(4 * s + g) * stride + pair];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) dv[c] = ds[(int64_t)c * n + pair];
+        for (int c = 0; c < 3; ++c) dv[c] = ds[(int64_t)c * stride + pair];
         f32x4 h1[4];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) h1[mt] = bias4(lds + O_B_OCC1, mt, g);
@@ -122,7 +128,7 @@ __global__ __launch_bounds__(MLP_BLOCK, 1) void k_part_mlp_bwd(PartMlpDev pm, co
         for (int c = 0; c < 3; ++c) rgb[c] = sigmoid_f(head_dot(hl, lds + O_V_OUT + c * 64, g) + lds[O_V_OUT + 3 * 64 + c]);
 
         // ---------------- backward ----------------
-        const float4 gr = live ? g_raw[pair] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 gr = live ? (l_slot ? g_raw[(int64_t)l_slot[pair] * INVR_NUM_PARTS + part] : g_raw[pair]) : make_float4(0.f, 0.f, 0.f, 0.f);
         float go[3] = {gr.x * rgb[0] * (1.0f - rgb[0]), gr.y * rgb[1] * (1.0f - rgb[1]), gr.z * rgb[2] * (1.0f - rgb[2])};
         const float g_lg = gr.w * (1.0f - occ) * occ;            // occ = 1 - exp(-softplus(lg)): d occ / d lg = (1 - occ) occ
         // rgb head^T (VALU): g_hl[hid] = sum_c Wout[c][hid] go[c]
@@ -219,7 +225,7 @@ __global__ __launch_bounds__(MLP_BLOCK, 1) void k_part_mlp_bwd(PartMlpDev pm, co
         if (live) {
 #pragma unroll
             for (int s = 0; s < EMB_STEPS; ++s)
-                if (4 * s + g < 19) o.g_emb[(int64_t)(4 * s + g) * n + pair] = ge[s >> 2][s & 3];
+                if (4 * s + g < 19) o.g_emb[(int64_t)(4 * s + g) * stride + pair] = ge[s >> 2][s & 3];
         }
     }
     // latent-code gradient: rows 4g+r (< 8) of the latent tile, summed over this wave's pairs and the 16 columns
@@ -228,23 +234,25 @@ __global__ __launch_bounds__(MLP_BLOCK, 1) void k_part_mlp_bwd(PartMlpDev pm, co
         float v = lat_acc[r];
 #pragma unroll
         for (int d = 1; d < 16; d <<= 1) v += __shfl_xor(v, d);
-        if (col == 0 && g < 2) atomicAdd(o.g_latent + 4 * g + r, v);
+        if (col == 0 && g < 2) atomicAdd(o.g_latent + (o.latent_full ? pm.latent_index[0] * pm.latent_dim : 0) + 4 * g + r, v);
     }
 }
 
 #undef G
 #undef A
 
-int launch_part_mlp_bwd(const PartMlpDev& pm, const float* emb_soa, const float* d_soa, int64_t n, const float* g_raw,
-                        const MlpBwdOut& o, hipStream_t st) {
-    if (n == 0) return 0;
+int launch_part_mlp_bwd(const PartMlpDev& pm, const float* emb_soa, const float* d_soa, int64_t n, int64_t stride,
+                        const int32_t* count, const float* g_raw, const int32_t* l_slot, int part, const MlpBwdOut& o, hipStream_t st) {
+    if (n == 0) return 0;                              // n = the pair count, or its upper bound when `count` (device) is given
     const int64_t per_block = (MLP_BLOCK / 64) * 16;
     int64_t tiles = cdiv(n, per_block);
     unsigned grid = (unsigned)(tiles < 256 * 2 ? tiles : 256 * 2);
     if (pm.rgb.n_linear == 3)
-        hipLaunchKernelGGL(k_part_mlp_bwd<3>, dim3(grid), dim3(MLP_BLOCK), 0, st, pm, emb_soa, d_soa, n, reinterpret_cast<const float4*>(g_raw), o);
+        hipLaunchKernelGGL(k_part_mlp_bwd<3>, dim3(grid), dim3(MLP_BLOCK), 0, st, pm, emb_soa, d_soa, n, stride, count,
+                           reinterpret_cast<const float4*>(g_raw), l_slot, part, o);
     else
-        hipLaunchKernelGGL(k_part_mlp_bwd<2>, dim3(grid), dim3(MLP_BLOCK), 0, st, pm, emb_soa, d_soa, n, reinterpret_cast<const float4*>(g_raw), o);
+        hipLaunchKernelGGL(k_part_mlp_bwd<2>, dim3(grid), dim3(MLP_BLOCK), 0, st, pm, emb_soa, d_soa, n, stride, count,
+                           reinterpret_cast<const float4*>(g_raw), l_slot, part, o);
     INVR_LAUNCH_CHECK();
     return 0;
 }

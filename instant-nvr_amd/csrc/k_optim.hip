@@ -11,11 +11,25 @@
 #define ADAM_BLOCK 256
 #define ADAM_CHUNK 16384            // elements per workgroup
 
-struct AdamTensor {                 // device-resident table, one entry per tensor that has a gradient this step
+struct AdamTensor {                 // device-resident table, one entry per tensor that has a gradient this step (InvrAdamTensor)
     float* p; const float* g; float* m; float* v;
     int64_t n;
     float lr, wd, bc1, bc2_sqrt;    // bias corrections 1-b1^step and sqrt(1-b2^step) of THIS tensor's step count
+    int32_t grad_shift;             // > 0: g is a ROW-SCALAR gradient — element i takes g[i >> grad_shift] (the gradient of a
+                                    // sum-over-features table is one scalar per row of 2^shift features, k_encode.hip)
+    int32_t step;                   // device-side step count (invr_adam_advance): host tables need no per-step upload
 };
+
+// One thread per tensor: step += 1 and the bias corrections of the new step, in double like the host does
+// (1 - beta**step, sqrt(1 - beta**step)).  Lets a training loop replay the optimiser step without a host-built table.
+__global__ void k_adam_advance(AdamTensor* tensors, int n, double b1, double b2) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int s = tensors[t].step + 1;
+    tensors[t].step = s;
+    tensors[t].bc1 = (float)(1.0 - pow(b1, (double)s));
+    tensors[t].bc2_sqrt = (float)sqrt(1.0 - pow(b2, (double)s));
+}
 
 __global__ __launch_bounds__(ADAM_BLOCK) void k_adam(const AdamTensor* __restrict__ tensors, const int32_t* __restrict__ chunk_tensor,
                                                      const int32_t* __restrict__ chunk_index, float b1, float b2, float eps) {
@@ -30,6 +44,22 @@ __global__ __launch_bounds__(ADAM_BLOCK) void k_adam(const AdamTensor* __restric
         const float denom = sqrtf(v) / t.bc2_sqrt + eps;
         p = p - step_size * (m / denom);                           // addcdiv_(m, denom, value=-step_size)
     };
+    if (t.grad_shift > 0) {         // row-scalar gradient: 16 B of p / m / v per lane, ONE gradient load per 2^shift elements
+        const int sh = t.grad_shift;
+        const bool vec4 = ((((uintptr_t)t.p | (uintptr_t)t.m | (uintptr_t)t.v) & 15) == 0) && sh >= 2;
+        if (vec4) {
+            for (int64_t i = base + (int64_t)threadIdx.x * 4; i + 3 < end; i += ADAM_BLOCK * 4) {
+                float4 p = *reinterpret_cast<float4*>(t.p + i), m = *reinterpret_cast<float4*>(t.m + i), v = *reinterpret_cast<float4*>(t.v + i);
+                const float g = t.g[i >> sh];
+                upd(p.x, g, m.x, v.x); upd(p.y, g, m.y, v.y); upd(p.z, g, m.z, v.z); upd(p.w, g, m.w, v.w);
+                *reinterpret_cast<float4*>(t.p + i) = p; *reinterpret_cast<float4*>(t.m + i) = m; *reinterpret_cast<float4*>(t.v + i) = v;
+            }
+            for (int64_t i = base + ((end - base) & ~(int64_t)3) + threadIdx.x; i < end; i += ADAM_BLOCK) upd(t.p[i], t.g[i >> sh], t.m[i], t.v[i]);
+        } else {
+            for (int64_t i = base + threadIdx.x; i < end; i += ADAM_BLOCK) upd(t.p[i], t.g[i >> sh], t.m[i], t.v[i]);
+        }
+        return;
+    }
     const bool vec = ((((uintptr_t)t.p | (uintptr_t)t.g | (uintptr_t)t.m | (uintptr_t)t.v) & 15) == 0);
     if (vec) {
         for (int64_t i = base + (int64_t)threadIdx.x * 4; i + 3 < end; i += ADAM_BLOCK * 4) {
@@ -42,6 +72,13 @@ __global__ __launch_bounds__(ADAM_BLOCK) void k_adam(const AdamTensor* __restric
     } else {
         for (int64_t i = base + threadIdx.x; i < end; i += ADAM_BLOCK) upd(t.p[i], t.g[i], t.m[i], t.v[i]);
     }
+}
+
+int launch_adam_advance(void* tensors, int n, float b1, float b2, hipStream_t st) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_adam_advance, dim3((unsigned)cdiv(n, 64)), dim3(64), 0, st, reinterpret_cast<AdamTensor*>(tensors), n, (double)b1, (double)b2);
+    INVR_LAUNCH_CHECK();
+    return 0;
 }
 
 int launch_adam(const void* tensors, const int32_t* chunk_tensor, const int32_t* chunk_index, int64_t n_chunks, float b1, float b2,

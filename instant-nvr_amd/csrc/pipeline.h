@@ -2,7 +2,8 @@
 #pragma once
 #include "common.h"
 
-enum { CNT_ACTIVE = 0, CNT_PAIRS = 1 /* ..5 */, CNT_OVERFLOW = 6, CNT_FAR = 7 /* ..11 */, CNT_TICKET = 12, CNT_LEN = 16 };
+enum { CNT_ACTIVE = 0, CNT_PAIRS = 1 /* ..5 */, CNT_OVERFLOW = 6, CNT_FAR = 7 /* ..11 */, CNT_TICKET = 12,
+       CNT_NB = 13 /* selected pair-regulariser rows */, CNT_DTOT = 14 /* entries of the deformer backward list */, CNT_LEN = 16 };
 
 #define CULL_MASK_MAX (4 << 20)   // cells of the per-frame cull mask (bytes); larger distance volumes run unmasked
 #define VOXMASK_MAX_CELLS (1 << 20)  // lattice cells with per-part candidate-cluster masks (40 B each)
@@ -140,9 +141,10 @@ int launch_part_mlp(const PartMlpDev& pm, const float* emb, const float* d_soa, 
                     float4* raw_direct, hipStream_t st);
 struct MlpBwdOut {                 // k_mlp_bwd.hip; mirrors InvrMlpBwdOut
     float* g_emb; float* gz; float* a; int64_t n_pad; float* g_latent;
+    int latent_full;       // 1: g_latent is the whole (num_latent_code, latent_dim) gradient tensor, row latent_index is accumulated
 };
-int launch_part_mlp_bwd(const PartMlpDev& pm, const float* emb_soa, const float* d_soa, int64_t n, const float* g_raw,
-                        const MlpBwdOut& o, hipStream_t st);
+int launch_part_mlp_bwd(const PartMlpDev& pm, const float* emb_soa, const float* d_soa, int64_t n, int64_t stride,
+                        const int32_t* count, const float* g_raw, const int32_t* l_slot, int part, const MlpBwdOut& o, hipStream_t st);
 struct MlpAllArgs {               // k_part_mlp_all
     PartMlpDev pm[INVR_NUM_PARTS];
     const float* emb[INVR_NUM_PARTS];

@@ -54,7 +54,7 @@ def train_step(wrapper, optimizer, batch, iter_step, epoch=0):
     optimizer.zero_grad(set_to_none=True)
     loss.backward()
     optimizer.step()
-    return float(loss.detach()), stats
+    return loss.detach(), stats          # a device scalar: reading it (float()) is the caller's synchronisation point
 
 
 def make_optimizer(net, lr=5e-4, eps=1e-15, weight_decay=0.0, fused=None):
@@ -64,7 +64,10 @@ def make_optimizer(net, lr=5e-4, eps=1e-15, weight_decay=0.0, fused=None):
         fused = all(p.is_cuda for g in groups for p in g['params'])
     if fused:                      # one HIP launch for all tensors (invr_adam_step) instead of ~8 launches per tensor
         from .optim import FusedAdam
-        return FusedAdam(groups, lr, eps=eps, weight_decay=weight_decay)
+        opt = FusedAdam(groups, lr, eps=eps, weight_decay=weight_decay)
+        if hasattr(net, 'tpose_human') and getattr(net, 'cfg', {}).get('train_fused', True):
+            opt.attach(net)        # persistent gradient arena + row-scalar table gradients for the fused training path
+        return opt
     return torch.optim.Adam(groups, lr, eps=eps, weight_decay=weight_decay)
 
 

@@ -84,6 +84,31 @@ class Embedder(nn.Module):
             self._rs, self._rs_key = rs, key
         return self._rs
 
+    def row_grad(self):
+        """Persistent compact table gradient of a sum-over-features grid (invr_train_bwd): one float per table row in
+        invr_grid_row_sums order; zero-initialised, accumulated by the fused training backward, consumed and re-zeroed by
+        FusedAdam (optim.py).  The dense gradient tensors are d(row)[f] = row_grad[row] for all F features."""
+        rg = getattr(self, '_row_grad', None)
+        if rg is None or rg.device != self.hash.device:
+            keep = []
+            g = self.grid_struct(keep)
+            n = _abi.lib().invr_grid_row_sums_len(C.byref(g))
+            rg = torch.zeros(n, device=self.hash.device, dtype=torch.float32)
+            self._row_grad = rg
+            self.row_grad_dirty = False
+        return rg
+
+    def expand_row_grad(self, accumulate=False):
+        """Dense .grad tensors of the tables from the row-scalar gradient (invr_expand_row_grad)."""
+        keep = []
+        g = self.grid_struct(keep)
+        gh = torch.empty_like(self.hash)
+        gd = torch.empty_like(self.dense) if self.separate_dense else None
+        _abi.check(_abi.lib().invr_expand_row_grad(C.byref(g), _abi.ptr(self.row_grad()), _abi.ptr(gd), _abi.ptr(gh), _abi.stream_ptr()))
+        for p_, g_ in ((self.hash, gh),) + (((self.dense, gd),) if self.separate_dense else ()):
+            p_.grad = g_ if (p_.grad is None or not accumulate) else p_.grad + g_
+        return gd, gh
+
     def forward(self, xyz, batch=None):
         """HashEmbedder.forward (:106-174) through invr_grid_encode_fwd."""
         if batch is not None:
@@ -184,8 +209,16 @@ class Network(nn.Module):
 
     # -- C-ABI glue ---------------------------------------------------------------------------
     def model_struct(self, keep):
-        sd = {k: v for k, v in self.named_parameters()}
-        m = _abi.make_model(sd, self.cfg, keep)
+        # the ctypes view of the 186 parameter tensors is rebuilt only when a storage moved (load_state_dict, .to(),
+        # bounds adoption): building it costs ~1 ms of host time, a third of a training iteration's budget
+        params_now = list(self.named_parameters())
+        key = tuple(p.data_ptr() for _, p in params_now)
+        if getattr(self, '_model_key', None) != key:
+            self._model_keep = []
+            self._model_base = _abi.make_model(dict(params_now), self.cfg, self._model_keep)
+            self._model_key = key
+        keep.extend(self._model_keep)
+        m = _abi.InvrModel.from_buffer_copy(self._model_base)
         if not self.training and self.cfg.get('eval_row_sums', True):
             # eval: the per-part grids are read through their row-sum tables (16x fewer table bytes)
             for i, pn in enumerate(self.tpose_human.part_networks):

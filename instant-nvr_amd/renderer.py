@@ -85,14 +85,94 @@ class Renderer:
     def _pair_noise(self, like):
         return torch.rand_like(like)                       # compute_val_pair_around_range (:41)
 
-    def _render_train(self, batch, jitter):
-        """Forward quantities of a training step: rgb_map/acc_map/raw/occ plus the train-only outputs
-        resd, tpts, tocc (dense (Na*P, .) layouts in the reference's row order), oresd (pair
-        regulariser) and reg_distortion_loss.  Gradients: see DESIGN.md (backward kernels = next row)."""
+    def _pair_noise_dense(self, rows, device):
+        """Fused path: one uniform [0,1)^3 draw per dense (survivor slot, part) row — the reference draws rand_like of the
+        selected rows only (:41); the selection is made on the device, so every candidate row gets a draw."""
+        return torch.rand(rows, 3, device=device, dtype=torch.float32)
+
+    def _render_train_fused(self, batch, jitter):
+        """Train-mode forward as ONE differentiable node (autograd.TrainRenderFn = invr_train_fwd / invr_train_bwd): no host
+        synchronisation, regulariser reductions on the device.  The dynamic-shape outputs of the reference contract (resd,
+        tpts, tocc, oresd) are read back from the workspace only if somebody asks for them (LazyTrainRet)."""
+        from . import autograd as ag
         cfg, net = self.cfg, self.net
         S = int(cfg.N_samples)
         ray_o, ray_d, near, far = batch['ray_o'][0], batch['ray_d'][0], batch['near'][0], batch['far'][0]
         n = ray_o.shape[0]
+        ctx = net.prepare(batch)
+        max_active = 0                                            # capacity = every ray-sample (a training patch is small)
+        noise = self._pair_noise_dense(n * S * NUM_PARTS, ray_o.device) if cfg.use_pair_reg else None
+        params = [p for p in net.parameters() if p.requires_grad]
+        rgb, acc, raw, dist, terms, occ, weights, z, stats = ag.TrainRenderFn.apply(
+            net, ctx, getattr(net, '_grad_arena', None), ray_o, ray_d, near, far, S, jitter, noise, max_active, *params)
+        self.last_stats = stats
+        self.last_train = {'weights': weights, 'z_vals': z, 'terms': terms}
+        base = {'rgb_map': rgb[None], 'acc_map': acc[None], 'raw': raw[None], 'occ': occ[None, :, None]}
+        if cfg.use_reg_distortion:
+            base['reg_distortion_loss'] = dist[None]
+        # inb_trainer.py:89-92 / :45-48 + crit.py:8-18 as differentiable scalars (sum / device-side count)
+        base['offset_loss'] = terms[ag.TERM_OFFSET_SUM] / terms[ag.TERM_OFFSET_ROWS].clamp(min=1.0)
+        lazy = ['resd', 'tpts', 'tocc']
+        if cfg.use_pair_reg:
+            base['pair_loss'] = terms[ag.TERM_PAIR_SUM] / terms[ag.TERM_PAIR_ROWS].clamp(min=1.0)
+            lazy.append('oresd')
+        ws = net._ws
+
+        def materialise():
+            with torch.no_grad():
+                return self._train_extras(net, ctx, ws, stats, n, S, max_active, noise)
+        return ag.LazyTrainRet(base, lazy, materialise)
+
+    def _train_extras(self, net, ctx, ws, stats_dev, n, S, max_active, noise_dense):
+        """resd / tpts / tocc (dense (Na*P, .) layouts in the reference's row order) and oresd from the pair lists of the
+        last forward (host read-back of the counts: synchronises)."""
+        cfg = self.cfg
+        stats = stats_dev.cpu()
+        Na = int(stats[0])
+        v = _abi.ws_views(ws, n, S, max_active)
+        cap, dev, P = v['cap'], ws.device, NUM_PARTS
+        resd = torch.zeros(Na + 1, P, 3, device=dev)
+        tpts = torch.zeros(Na + 1, P, 3, device=dev)
+        tocc = torch.zeros(Na + 1, P, device=dev)
+        raws = v['raws']
+        far = v['farflags'][:Na].to(torch.int32)
+        for p in range(P):
+            cnt = int(stats[1 + p])
+            slots = v['l_slot'][p][:cnt].long()
+            rows = torch.where(slots == cap, torch.full_like(slots, Na), slots)
+            r = v['l_r'][p][:, :cnt].t()
+            resd[rows, p] = r
+            tpts[rows, p] = v['l_x'][p][:, :cnt].t() - r
+            tocc[rows, p] = raws[slots, p, 3]
+            fr = ((far >> p) & 1).nonzero(as_tuple=True)[0]
+            if fr.numel():
+                resd[fr, p] = resd[Na, p]
+                tpts[fr, p] = tpts[Na, p]
+                tocc[fr, p] = tocc[Na, p]
+        resd, tpts, tocc = resd[:Na], tpts[:Na], tocc[:Na]
+        out = {'resd': resd.reshape(1, -1, 3), 'tpts': tpts.reshape(1, -1, 3), 'tocc': tocc.reshape(1, -1, 1)}
+        if cfg.use_pair_reg and noise_dense is not None:
+            reg = ((tocc.reshape(-1) - 0.5).abs() < 0.02).nonzero(as_tuple=True)[0]
+            if reg.numel():
+                reg_tpts = tpts.reshape(-1, 3)[reg][None]
+                neighbor = reg_tpts + (noise_dense[reg][None] - 0.5) * 0.01
+                out['oresd'] = torch.cat([resd.reshape(-1, 3)[reg][None], net.resd(neighbor, ctx)], dim=1)
+            else:
+                out['oresd'] = torch.zeros(1, 0, 3, device=dev)
+        return out
+
+    def _render_train(self, batch, jitter):
+        """Forward quantities of a training step: rgb_map/acc_map/raw/occ plus the train-only outputs
+        resd, tpts, tocc (dense (Na*P, .) layouts in the reference's row order), oresd (pair
+        regulariser) and reg_distortion_loss.  With gradients enabled: the fused HIP forward/backward node
+        (_render_train_fused, cfg.train_fused, default) or — cfg.train_fused False — the op-by-op autograd graph of
+        autograd.render_train on the pair lists (every dense output differentiable; the in-repo cross-check)."""
+        cfg, net = self.cfg, self.net
+        S = int(cfg.N_samples)
+        ray_o, ray_d, near, far = batch['ray_o'][0], batch['ray_d'][0], batch['near'][0], batch['far'][0]
+        n = ray_o.shape[0]
+        if torch.is_grad_enabled() and cfg.get('train_fused', True):
+            return self._render_train_fused(batch, jitter)
         ctx = net.prepare(batch)
         if torch.is_grad_enabled():       # geometry only: the differentiable part is recomputed on the pair lists
             out = net.geometry_pass(ctx, ray_o, ray_d, near, far, S, jitter=jitter)

@@ -88,7 +88,10 @@ class NetworkWrapper(nn.Module):
         scalar_stats = {}
         dev = batch['latent_index'].device
         loss = torch.tensor(0.0, device=dev)
-        if 'oresd' in ret and ret['oresd'].numel():
+        if 'pair_loss' in ret:                      # fused path: crit.reg_raw_crit reduced on the device (0 when no row qualifies)
+            scalar_stats['pair_loss'] = ret['pair_loss']
+            loss = loss + cfg.pair_loss_weight * ret['pair_loss']
+        elif 'oresd' in ret and ret['oresd'].numel():
             oresd = reg_raw_crit(ret['oresd'].to(dev))
             scalar_stats['pair_loss'] = oresd
             loss = loss + cfg.pair_loss_weight * oresd
@@ -96,7 +99,10 @@ class NetworkWrapper(nn.Module):
             rd = ret['reg_distortion_loss'].to(dev).mean()
             scalar_stats['reg_dist'] = rd
             loss = loss + cfg.reg_dist_weight * rd
-        if 'resd' in ret:
+        if 'offset_loss' in ret:                    # fused path: mean over the dense (Na*P) rows, reduced on the device
+            scalar_stats['offset_loss'] = ret['offset_loss']
+            loss = loss + cfg.resd_loss_weight * ret['offset_loss']
+        elif 'resd' in ret:
             off = torch.norm(ret['resd'].to(dev), dim=2).mean()
             scalar_stats['offset_loss'] = off
             loss = loss + cfg.resd_loss_weight * off
@@ -114,9 +120,10 @@ class NetworkWrapper(nn.Module):
         elif split == 'train':
             rgb_map = ret['rgb_map'].to(dev)
             img_loss = self.img2mse(rgb_map, batch['rgb'])
-            err = torch.abs(rgb_map - batch['rgb']).sum(dim=-1).detach().cpu()
-            psnr = -10 * np.log(img_loss.item()) / np.log(10)
-            scalar_stats.update({'img_loss': img_loss, 'psnr': torch.Tensor([psnr])})
+            err = torch.abs(rgb_map - batch['rgb']).sum(dim=-1).detach()
+            # the reference reads img_loss back per iteration for its psnr stat (.item()); here it stays a device scalar
+            psnr = -10.0 * torch.log(img_loss.detach()) / np.log(10)
+            scalar_stats.update({'img_loss': img_loss, 'psnr': psnr.reshape(1)})
             if cfg.get('use_lpips', False) or cfg.get('use_ssim', False) or cfg.get('use_fourier', False) or cfg.get('use_tv_image', False):
                 H, W = int(batch['H'].item()), int(batch['W'].item())                   # :188-203: the rays of a patch back on its pixels
                 img_pred = assemble_patch(rgb_map, batch['mask_at_box'][0], H, W)

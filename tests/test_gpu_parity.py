@@ -223,7 +223,7 @@ def test_composite_backward_saturated_alphas(gpu_setup):
     zero-aware and stays finite there, and so must the kernel (no division by 1 - alpha)."""
     from invr import autograd as AG
     g = torch.Generator().manual_seed(9)
-    for R, S in ((5, 1), (40, 64), (33, 65), (17, 200), (3, 700)):
+    for R, S in ((5, 1), (40, 64), (33, 65), (17, 200), (6, 700)):
         raw = torch.rand(R, S, 4, generator=g)
         u = torch.rand(R, S, generator=g)
         a = raw[..., 3].clone()
@@ -323,33 +323,32 @@ def _golden_grads(golden):
     return out
 
 
-def test_train_step_gradients_vs_reference_golden(gpu_setup, golden):
-    """loss.backward() through the differentiable training forward: every parameter gradient of the
-    reference (autograd of the PyTorch path, 256 rays, fixed jitter) to fp32 tolerance."""
-    cfg, sd, batch, gb, net = gpu_setup
+def _train_batch(gb, golden):
     tsel = torch.from_numpy(golden['train_rays'].astype(np.int64)).to(DEV)
     tb = dict(gb)
     for k in ('ray_o', 'ray_d', 'near', 'far', 'rgb', 'occupancy'):
         tb[k] = gb[k][:, tsel]
-    net.train()
-    try:
-        r = Renderer(net)
-        r._jitter = lambda shape, device: cu(golden['train_jitter'][0])
-        r._pair_noise = lambda like: cu(golden['train_pair_u'])
-        net.zero_grad(set_to_none=True)
-        ret = r.render(tb)
-        assert maxerr(ret['rgb_map'], golden['train_rgb_map']) < 1e-4
-        assert maxerr(ret['resd'], golden['train_resd']) < 5e-6
-        assert maxerr(ret['oresd'], golden['train_oresd']) < 5e-6
-        assert maxerr(ret['reg_distortion_loss'], golden['train_reg_distortion_loss']) < 1e-5
-        loss = ((ret['rgb_map'] - tb['rgb']) ** 2).mean() + 0.1 * ret['reg_distortion_loss'].mean() \
-            + 0.1 * torch.norm(ret['resd'], dim=2).mean()          # the loss make_golden.py differentiated
-        assert abs(float(loss.detach()) - float(golden['train_loss'])) < 1e-5
-        loss.backward()
-    finally:
-        net.eval()
+    return tb
+
+
+def _dense_pair_noise(net, tb, golden, cfg):
+    """The fused path draws one uniform triple per dense (survivor, part) row; the reference draws rand_like of the SELECTED
+    rows (golden['train_pair_u'], in dense-row order).  A gradient-free pass finds the selected rows, the golden draws are
+    scattered to them."""
+    r = Renderer(net)
+    r._jitter = lambda shape, device: cu(golden['train_jitter'][0])
+    r._pair_noise = lambda like: cu(golden['train_pair_u'])
+    with torch.no_grad():
+        ret0 = r.render(dict(tb))
+    reg = ((ret0['tocc'].reshape(-1) - 0.5).abs() < 0.02).nonzero(as_tuple=True)[0]
+    assert reg.numel() == golden['train_pair_u'].shape[1]
+    dense = torch.zeros(tb['ray_o'].shape[1] * cfg.N_samples * 5, 3, device=DEV)
+    dense[reg] = cu(golden['train_pair_u'][0])
+    return dense
+
+
+def _check_golden_grads(params, golden):
     ref = _golden_grads(golden)
-    params = dict(net.named_parameters())
     checked = 0
     for name, entry in ref.items():
         g = params[name].grad
@@ -372,6 +371,87 @@ def test_train_step_gradients_vs_reference_golden(gpu_setup, golden):
     for name, p in params.items():                           # nothing else got a gradient the reference lacks
         if p.grad is not None and name not in ref:
             assert float(p.grad.abs().max()) == 0.0, name
+
+
+@pytest.mark.parametrize('mode', ['fused', 'fused_arena', 'graph'])
+def test_train_step_gradients_vs_reference_golden(gpu_setup, golden, mode):
+    """loss.backward() through the training forward: every parameter gradient of the reference (autograd of the PyTorch
+    path, 256 rays, fixed jitter) to fp32 tolerance — through the fused node (invr_train_fwd / invr_train_bwd) with
+    autograd-delivered dense gradients, through the same node with the persistent gradient arena (row-scalar table
+    gradients, expanded for the comparison), and through the op-by-op autograd graph (cfg.train_fused False)."""
+    import copy
+    from invr.optim import FusedAdam
+    cfg0, sd, batch, gb, net0 = gpu_setup
+    net = copy.deepcopy(net0)
+    net.cfg = copy.deepcopy(cfg0)
+    net.cfg.train_fused = mode != 'graph'
+    cfg = net.cfg
+    tb = _train_batch(gb, golden)
+    net.train()
+    if mode == 'fused_arena':
+        opt = FusedAdam([{'params': [p]} for p in net.parameters() if p.requires_grad], 1e-3, eps=1e-15).attach(net)
+        opt.zero_grad()
+    r = Renderer(net)
+    r._jitter = lambda shape, device: cu(golden['train_jitter'][0])
+    r._pair_noise = lambda like: cu(golden['train_pair_u'])
+    if mode != 'graph':
+        dense = _dense_pair_noise(net, tb, golden, cfg)
+        r._pair_noise_dense = lambda rows, device: dense[:rows]
+    net.zero_grad(set_to_none=True)
+    ret = r.render(tb)
+    assert maxerr(ret['rgb_map'], golden['train_rgb_map']) < 1e-4
+    assert maxerr(ret['acc_map'], golden['train_acc_map']) < 1e-4
+    assert maxerr(ret['reg_distortion_loss'], golden['train_reg_distortion_loss']) < 1e-5
+    if mode == 'graph':
+        offset = torch.norm(ret['resd'], dim=2).mean()
+    else:
+        offset = ret['offset_loss']                                  # reduced on the device; resd itself is read back lazily
+        assert abs(float(offset) - float(np.linalg.norm(golden['train_resd'], axis=2).mean())) < 1e-7
+        from invr.trainer import reg_raw_crit
+        assert abs(float(ret['pair_loss']) - float(reg_raw_crit(torch.from_numpy(golden['train_oresd'])))) < 2e-5
+    loss = ((ret['rgb_map'] - tb['rgb']) ** 2).mean() + 0.1 * ret['reg_distortion_loss'].mean() + 0.1 * offset   # make_golden.py's loss
+    assert abs(float(loss.detach()) - float(golden['train_loss'])) < 1e-5
+    loss.backward()
+    # the reference's dynamic-shape outputs (lazy in the fused modes)
+    assert ret['resd'].shape == golden['train_resd'].shape and maxerr(ret['resd'], golden['train_resd']) < 5e-6
+    assert ret['tocc'].shape == golden['train_tocc'].shape and maxerr(ret['tocc'], golden['train_tocc']) < 1e-3
+    assert ret['oresd'].shape == golden['train_oresd'].shape and maxerr(ret['oresd'], golden['train_oresd']) < 5e-6
+    if mode == 'fused_arena':
+        assert all(pn.embedder.hash.grad is None for pn in net.tpose_human.part_networks)     # tables: row scalars only
+        opt.arena.expand_tables()
+    _check_golden_grads(dict(net.named_parameters()), golden)
+
+
+def test_train_pair_and_offset_term_gradients_fused_vs_graph(gpu_setup, golden):
+    """The regulariser terms the goldens' loss does not contain (pair regulariser: neighbour deformer evaluations and
+    crit.reg_raw_crit) — gradients of the fused node against torch autograd of the reference formulas on the op-by-op graph."""
+    import copy
+    cfg0, sd, batch, gb, net0 = gpu_setup
+    tb = _train_batch(gb, golden)
+    grads = {}
+    for mode in ('graph', 'fused'):
+        net = copy.deepcopy(net0).train()
+        net.cfg = copy.deepcopy(cfg0)
+        net.cfg.train_fused = mode == 'fused'
+        from invr.trainer import NetworkWrapper
+        wrap = NetworkWrapper(net)
+        r = wrap.renderer
+        r._jitter = lambda shape, device: cu(golden['train_jitter'][0])
+        r._pair_noise = lambda like: cu(golden['train_pair_u'])
+        if mode == 'fused':
+            dense = _dense_pair_noise(net, tb, golden, net.cfg)
+            r._pair_noise_dense = lambda rows, device: dense[:rows]
+        tbb = dict(tb)
+        tbb['iter_step'] = 2
+        ret, loss, stats, _ = wrap(tbb, split='train')
+        loss.backward()
+        grads[mode] = ({k: v.grad.clone() for k, v in net.named_parameters() if v.grad is not None}, float(loss), float(stats['pair_loss']))
+    (ga, la, pa), (gf, lf, pf) = grads['graph'], grads['fused']
+    assert abs(la - lf) < 2e-5 and abs(pa - pf) < 2e-5 and pa > 1e-3
+    assert set(ga) == set(gf)
+    for k in ga:
+        scale = max(float(ga[k].abs().max()), 1e-6)
+        assert float((ga[k] - gf[k]).abs().max()) <= 2e-4 * scale + 2e-7, (k, float((ga[k] - gf[k]).abs().max()), scale)
 
 
 def test_network_wrapper_optimisation_steps(gpu_setup, golden):
@@ -417,10 +497,12 @@ def test_network_wrapper_lpips_patch_branch(gpu_setup, golden):
     pl = PerceptualLoss(allow_random=True).to(DEV)
     wrap = NetworkWrapper(net, perceptual_loss=pl)
     seen = {}
-    def spy(x, t):
-        seen['x'], seen['t'] = x, t
-        return pl(x, t)
-    wrap.perceptual_loss = spy
+
+    class Spy(torch.nn.Module):
+        def forward(self, x, t):
+            seen['x'], seen['t'] = x, t
+            return pl(x, t)
+    wrap.perceptual_loss = Spy()
     tb = dict(gb)                                    # the whole 64x64 frame as the "patch": mask_at_box has holes
     tb['iter_step'] = 2
     ret, loss, stats, _ = wrap(tb, split='train')

@@ -113,8 +113,16 @@ def test_knn_pairs_vs_brute_force_whole_frame(fr):
         dd = ((pp[sl][None, :, None, :] - b['part_pts'][0][:, None, :, :]) ** 2).sum(-1)
         dd = dd.masked_fill(torch.arange(M)[None, None, :] >= b['lengths2'][0][:, None, None], float('inf'))
         d2k, idx = dd.topk(4, dim=-1, largest=False)                             # (P,n,4)
+        # neighbour SETS (knn_points order is unspecified).  The CPU sum may associate (dx2+dy2)+dz2 differently, so a 4th/5th
+        # neighbour at (near-)equal distance may swap: the kernel's four rows must have the oracle's four smallest distances
         ref_sets = idx.permute(1, 0, 2).sort(-1)[0]
-        assert torch.equal(got_nn[sl].long().sort(-1)[0], ref_sets), k           # neighbour SETS (knn_points order is unspecified)
+        same = (got_nn[sl].long().sort(-1)[0] == ref_sets).all(-1)               # (n,P)
+        assert float(same.float().mean()) > 0.999
+        got_d = torch.gather(dd.permute(1, 0, 2), 2, got_nn[sl].long()).sort(-1)[0]
+        ref_d = d2k.permute(1, 0, 2).sort(-1)[0]
+        fin = torch.isfinite(ref_d)
+        assert bool((fin == torch.isfinite(got_d)).all())
+        assert bool(((got_d - ref_d).abs()[fin] <= 1e-6 * ref_d[fin] + 1e-12).all()), k
         _, ref_dist = O.knn_blend(pp[sl], b['part_pts'][0], b['part_pbw'][0], b['lengths2'][0])
         assert float((got_dist[sl] - ref_dist).abs().max()) < 2e-6
         margin = (ref_dist - thresh).abs() < 1e-6
@@ -136,19 +144,24 @@ def test_warp_pairs_and_slice_deformer_vs_dense_whole_frame(fr):
         if cnt == 0:
             continue
         slots = v['l_slot'][p][:cnt].long()
-        x = v['l_x'][p][:, :cnt].t()
+        r = v['l_r'][p][:, :cnt].t().contiguous()
+        xb = (v['l_x'][p][:, :cnt].t() - r).contiguous()                           # init_bigpose (l_x = init_bigpose + resd)
         d = v['l_d'][p][:, :cnt].t()
-        r = v['l_r'][p][:, :cnt].t()
-        ex = (x - tp[slots, p]).abs().max(1)[0]
+        ex = (xb - (tp[slots, p] - rs[slots, p])).abs().max(1)[0]
         ed = (d - td[slots, p]).abs().max(1)[0]
-        er = (r - rs[slots, p]).abs().max(1)[0]
+        # residual: 0.05 tanh(MLP(grid(uv(x)))) is steep in x (nearest-vertex UV volume: d uv / d x ~ 40 / m), so it is
+        # compared on the SAME canonical point: MFMA + per-frame t-slices (k_deform_pairs_slice) vs the thread-per-point
+        # deformer with 3-D lookups (invr_deform_fwd, pinned to the reference goldens by test_warp_deform)
+        r_pts = f['net'].resd(xb[None], ctx)[0]
+        er = (r - r_pts).abs().max(1)[0]
         worst[p] = (float(ex.max()), float(ed.max()), float(er.max()))
         # canonical point / view direction: the pre-blended per-vertex matrices change the summation order of the
         # 24-joint blend (sum_k w_k (sum_j pbw_kj A_j) vs (sum_k w_k pbw_kj) A_j): fp32 rounding of O(1) quantities
         assert float(ex.max()) < 1e-5 and float(ed.max()) < 1e-5, (k, p, worst[p])
-        # residual: 0.05 tanh(MLP(grid(uv(x)))), MFMA + per-frame t-slices vs thread-per-point 3-D lookups
-        assert float(er.max()) < 5e-6, (k, p, worst[p])
+        assert float(er.max()) < 2e-6, (k, p, worst[p])
         assert float(r.abs().max()) <= 0.05 + 1e-7
+        # and the dense path's residual of ITS canonical point agrees within the deformer's sensitivity to that fp32 noise
+        assert float((r - rs[slots, p]).abs().max()) < 3e-4, (k, p)
     assert len(worst) >= 4
     # the far-constant pair: zero weights -> canonical origin, zero direction (k_knn.hip header)
     for p in range(5):
