@@ -45,6 +45,12 @@ class Embedder(nn.Module):
             nn.init.kaiming_normal_(self.hash)
         self.offsets = nn.Parameter(torch.from_numpy(params.CORNER_OFFSETS.copy()), **ng)
 
+    def __getstate__(self):
+        d = self.__dict__.copy()
+        for k in ('_rs', '_rs_key', '_row_grad', 'row_grad_dirty'):
+            d.pop(k, None)
+        return d
+
     def maybe_adopt_batch_bounds(self, batch):
         # part_base_embedder.py:107-109: bounds are re-created from the batch at iter_step == 1
         if self.use_batch_bounds and 'iter_step' in batch and batch['iter_step'] == 1:
@@ -205,6 +211,19 @@ class Network(nn.Module):
         self.cfg = cfg or global_cfg
         self.tpose_deformer = Deformer(self.cfg)
         self.tpose_human = TPoseHuman(self.cfg)
+        self._ws = None
+
+    _TRANSIENT = ('_model_key', '_model_base', '_model_keep', '_ws', '_grad_arena')
+
+    def __getstate__(self):
+        # derived ctypes views / scratch buffers are not part of the module's state (copy.deepcopy, pickling)
+        d = self.__dict__.copy()
+        for k in self._TRANSIENT:
+            d.pop(k, None)
+        return d
+
+    def __setstate__(self, d):
+        self.__dict__.update(d)
         self._ws = None
 
     # -- C-ABI glue ---------------------------------------------------------------------------
