@@ -387,8 +387,15 @@ int invr_train_fwd(const InvrScene* scene, const InvrModel* model,
 int invr_train_bwd(const InvrScene* scene, const InvrModel* model, int64_t n_rays, int32_t n_samples,
                    const float* raw, const float* weights, const float* z_vals,
                    const float* g_rgb_map, const float* g_acc_map, const float* g_dist_loss, const float* g_raw,
-                   const float* g_offset_sum, const float* g_pair_sum, const InvrTrainGrads* grads,
+                   const float* g_offset_sum, const float* g_pair_sum, const InvrTrainGrads* grads, int32_t stages,
                    void* workspace, size_t workspace_bytes, int64_t max_active, void* stream);
+/* `stages` of invr_train_bwd (0 = all): a data-parallel trainer calls HEAD, then the parts one by one — starting the
+ * all-reduce of a part's gradients as soon as its kernels are enqueued, beside the remaining backward — then DEFORMER
+ * (which needs every part's canonical-point gradient).  HEAD must come first, DEFORMER last. */
+#define INVR_BWD_HEAD 1
+#define INVR_BWD_PART(p) (2 << (p))
+#define INVR_BWD_DEFORMER 64
+#define INVR_BWD_ALL 127
 /* row-scalar table gradient (invr_grid_row_sums order) -> dense gradients g_dense (dense_rows,F) / g_hash (n_hash,T,F) of the
  * grid's tables (every feature of a row takes the row's scalar); overwrites.  g_dense may be NULL for a non-separate table. */
 int invr_expand_row_grad(const InvrGrid* grid, const float* row_grad, float* g_dense, float* g_hash, void* stream);

@@ -90,6 +90,7 @@ EXPORTS = ['invr_last_error', 'invr_version', 'invr_sizeof', 'invr_workspace_byt
            'invr_rigid_transformation', 'invr_pack_parts', 'invr_grid_row_sums_len', 'invr_grid_row_sums', 'invr_adam_chunk_elems', 'invr_adam_step', 'invr_part_mlp_fwd', 'invr_part_mlp_bwd',
            'invr_knn_neighbors', 'invr_pose_points', 'invr_adam_advance', 'invr_train_workspace_bytes', 'invr_train_fwd',
            'invr_train_bwd', 'invr_expand_row_grad']
+BWD_HEAD, BWD_DEFORMER, BWD_ALL = 1, 64, 127
 NUM_STAGES = 14
 STAGE_NAMES = ['cull', 'knn', 'warp'] + ['encode_%d' % p for p in range(5)] + ['mlp_%d' % p for p in range(5)] + ['composite']
 
@@ -129,7 +130,7 @@ def lib():
                                      vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, C.c_int64, vp]
         L.invr_train_fwd.restype = C.c_int
         L.invr_train_bwd.argtypes = [C.POINTER(InvrScene), C.POINTER(InvrModel), C.c_int64, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, vp,
-                                     C.POINTER(InvrTrainGrads), vp, C.c_size_t, C.c_int64, vp]
+                                     C.POINTER(InvrTrainGrads), C.c_int32, vp, C.c_size_t, C.c_int64, vp]
         L.invr_train_bwd.restype = C.c_int
         L.invr_expand_row_grad.argtypes = [C.POINTER(InvrGrid), vp, vp, vp, vp]
         L.invr_expand_row_grad.restype = C.c_int

@@ -475,11 +475,26 @@ class TrainRenderFn(torch.autograd.Function):
         if g_terms is not None:
             g_off, g_pair = g_terms[TERM_OFFSET_SUM:TERM_OFFSET_SUM + 1], g_terms[TERM_PAIR_SUM:TERM_PAIR_SUM + 1]
         own = arena if arena is not None else GradArena(net)       # no arena: a throw-away one, handed to autograd below
-        _abi.check(L.invr_train_bwd(C.byref(rctx.scene), C.byref(rctx.model), n, S, _abi.ptr(raw), _abi.ptr(weights), _abi.ptr(z),
-                                    _abi.ptr(g_rgb), _abi.ptr(c(g_acc)), _abi.ptr(c(g_dist)), _abi.ptr(c(g_raw)),
-                                    C.c_void_p(g_off.data_ptr()) if g_off is not None else None,
-                                    C.c_void_p(g_pair.data_ptr()) if g_pair is not None else None,
-                                    C.byref(own.struct), C.c_void_p(ctx.ws.data_ptr()), nbytes, max_active, _abi.stream_ptr()))
+        g_acc, g_dist, g_raw = c(g_acc), c(g_dist), c(g_raw)
+
+        def run(stages):
+            _abi.check(L.invr_train_bwd(C.byref(rctx.scene), C.byref(rctx.model), n, S, _abi.ptr(raw), _abi.ptr(weights), _abi.ptr(z),
+                                        _abi.ptr(g_rgb), _abi.ptr(g_acc), _abi.ptr(g_dist), _abi.ptr(g_raw),
+                                        C.c_void_p(g_off.data_ptr()) if g_off is not None else None,
+                                        C.c_void_p(g_pair.data_ptr()) if g_pair is not None else None,
+                                        C.byref(own.struct), stages, C.c_void_p(ctx.ws.data_ptr()), nbytes, max_active, _abi.stream_ptr()))
+        reducer = getattr(arena, 'reducer', None) if arena is not None else None
+        if reducer is None:
+            run(_abi.BWD_ALL)
+        else:
+            # data parallel: the largest gradient blocks first, each part's all-reduce starts as soon as its kernels are enqueued
+            # and runs on the collective's own stream beside the rest of the backward (dist_train.GradReducer)
+            run(_abi.BWD_HEAD)
+            for p in reducer.part_order:
+                run(2 << p)
+                reducer.reduce_part(p)
+            run(_abi.BWD_DEFORMER)
+            reducer.reduce_small()
         head = (None,) * 11
         if arena is not None:
             arena.publish()

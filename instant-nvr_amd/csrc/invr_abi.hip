@@ -698,10 +698,11 @@ __global__ void k_add_inplace(float* __restrict__ dst, const float* __restrict__
 extern "C" int invr_train_bwd(const InvrScene* scene, const InvrModel* model, int64_t n_rays, int32_t n_samples,
                               const float* raw, const float* weights, const float* z_vals,
                               const float* g_rgb_map, const float* g_acc_map, const float* g_dist_loss, const float* g_raw,
-                              const float* g_offset_sum, const float* g_pair_sum, const InvrTrainGrads* grads,
+                              const float* g_offset_sum, const float* g_pair_sum, const InvrTrainGrads* grads, int32_t stages,
                               void* workspace, size_t workspace_bytes, int64_t max_active, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     INVR_CHECK(scene && model && grads, "invr_train_bwd: null scene / model / grads");
+    if (stages == 0) stages = INVR_BWD_ALL;
     if (n_rays == 0) return 0;
     INVR_CHECK(raw && weights && z_vals && g_rgb_map, "invr_train_bwd: raw, weights, z_vals and g_rgb_map are required");
     const int64_t N = n_rays * (int64_t)n_samples;
@@ -714,6 +715,7 @@ extern "C" int invr_train_bwd(const InvrScene* scene, const InvrModel* model, in
     carve_train(t, workspace, inner, N, cap + 1);
     const int64_t lcap = w.lcap;
     // distortion^T -> compositing^T (-> + direct gradient of raw) -> merge^T
+    if (stages & INVR_BWD_HEAD) {
     if (g_dist_loss && launch_distortion_bwd(weights, z_vals, g_dist_loss, n_rays, n_samples, t.g_w, st)) return 1;
     if (launch_composite_bwd(raw, g_rgb_map, g_acc_map, g_dist_loss ? t.g_w : nullptr, n_rays, n_samples, reinterpret_cast<float*>(t.g_rawfull), st)) return 1;
     if (g_raw) {
@@ -721,8 +723,10 @@ extern "C" int invr_train_bwd(const InvrScene* scene, const InvrModel* model, in
         INVR_LAUNCH_CHECK();
     }
     if (launch_merge_bwd(w, t.g_rawfull, t.g_raws, st)) return 1;
-    // per part: MLPs^T -> weight gradients -> encoder^T (largest part first)
+    }
+    // per part: MLPs^T -> weight gradients -> encoder^T
     for (int p = 0; p < INVR_NUM_PARTS; ++p) {
+        if (!(stages & INVR_BWD_PART(p))) continue;
         const InvrPartGrads& G = grads->part[p];
         PartMlpDev pm = make_part_mlp(model, p, scene->latent_index);
         const int n_rgb = pm.rgb.n_linear;
@@ -740,7 +744,8 @@ extern "C" int invr_train_bwd(const InvrScene* scene, const InvrModel* model, in
         GridDev g = make_grid_dev(&model->part[p].grid);
         if (launch_part_encode_bwd_lists(g, w.l_x[p], t.g_emb, t.g_x[p], lcap, lcap, count, G.row_grad, st)) return 1;
     }
-    // deformer^T over the listed pairs and the pair-regulariser neighbours
+    // deformer^T over the listed pairs and the pair-regulariser neighbours (needs the g_x of every part)
+    if (!(stages & INVR_BWD_DEFORMER)) return 0;
     if (check_grid(&model->deform_grid, "deformer grid") || check_mlp_deform(&model->deform_mlp)) return 1;
     INVR_CHECK(grads->deform_hash && (!model->deform_grid.separate_dense || grads->deform_dense) && grads->deform_w[0] && grads->deform_w[1] &&
                grads->deform_w[2] && grads->deform_b[0] && grads->deform_b[1] && grads->deform_b[2], "invr_train_bwd: null deformer gradient pointer");

@@ -335,6 +335,8 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_part_encode(GridDev g, const floa
 // sends ~1e5 pairs through 8..1000-row coarse levels and would serialise on global atomics.
 #define BWD_SMALL_ROWS 1100
 #define BWD_SMALL_FLOATS 6144
+#define BWD_CACHE 4096
+#define BWD_CACHE_RES 128
 
 // Layout-generic: element (point i, component c) of xyz / gout / g_xyz sits at i*ps + c*cs (AoS (n,3)/(n,19): ps = 3/19,
 // cs = 1; the SoA pair lists of the training pipeline: ps = 1, cs = list stride); the point count is `n_host` or, when
@@ -347,16 +349,25 @@ struct EncBwdIO {
     float* g_xyz; int64_t gx_ps, gx_cs;
     int64_t n_host; const int32_t* count;
     float* g_dense; float* g_hash; float* rowgrad;
+    int dbg_tp, dbg_noatom;
 };
 
 __global__ __launch_bounds__(ENC_BLOCK) void k_part_encode_bwd(GridDev g, EncBwdIO io) {
     __shared__ float sgo[ENC_WAVES][64][20];          // g_out tile of the wave
     __shared__ float sgx[ENC_WAVES][64][3];           // per point: gradient w.r.t. the normalised coordinate
     __shared__ float ssmall[BWD_SMALL_FLOATS];        // per-workgroup accumulators of the small dense levels
+    // write-combining cache of the medium dense levels (res <= BWD_CACHE_RES, too large for ssmall): a training patch sends
+    // all its ~5e4 pairs through a few dozen rows of the coarse levels (cells of 3..12 cm against a 10 cm patch); their
+    // same-line global atomics from ~3000 waves serialised the kernel (0.8 of 1.1 ms per iteration).  Persistent workgroups
+    // accumulate those rows in LDS (direct-mapped {level<<24 | row, sum}; a slot conflict falls back to the global atomic) and
+    // flush each touched row once.
+    __shared__ unsigned ckey[BWD_CACHE];
+    __shared__ float cval[BWD_CACHE];
     const int64_t n = io.count ? (int64_t)*io.count : io.n_host;
     if (n <= 0) return;
     int tp = 64;                                      // points per wave tile: enough waves to fill the GPU, long enough runs to combine
     while (tp > 16 && n / tp < 4096) tp >>= 1;
+    if (io.dbg_tp) tp = io.dbg_tp;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int level = lane >> 2, q = lane & 3;
     LaneLevel L;
@@ -387,6 +398,8 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_part_encode_bwd(GridDev g, EncBwd
         if (small) small_total += (int)rows;
     }
     for (int j = threadIdx.x; j < small_total; j += ENC_BLOCK) ssmall[j] = 0.0f;
+    for (int j = threadIdx.x; j < BWD_CACHE; j += ENC_BLOCK) { ckey[j] = 0xFFFFFFFFu; cval[j] = 0.0f; }
+    const bool cached = small_off < 0 && !L.hashed && g.separate_dense && L.res <= BWD_CACHE_RES && !io.dbg_noatom;
     __syncthreads();
     const float b0x = g.bounds[0], b0y = g.bounds[1], b0z = g.bounds[2];
     const float ex = g.bounds[3] - b0x, ey = g.bounds[4] - b0y, ez = g.bounds[5] - b0z;
@@ -414,8 +427,15 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_part_encode_bwd(GridDev g, EncBwd
 #pragma unroll
         for (int k = 0; k < 8; ++k) { prow[k] = 0xFFFFFFFFu; pval[k] = 0.0f; }
         auto flush = [&](unsigned r, float vsum) {
-            if (small_off >= 0) atomicAdd(&ssmall[small_off + r], vsum);
-            else unsafeAtomicAdd(gtb + (size_t)r * gstride, vsum);          // column 0 = row scalar
+            if (io.dbg_noatom) return;
+            if (small_off >= 0) { atomicAdd(&ssmall[small_off + r], vsum); return; }
+            if (cached) {
+                const unsigned key = ((unsigned)level << 24) | r;
+                const unsigned slot = ((r * 2654435761u) >> 18 ^ (unsigned)level * 977u) & (BWD_CACHE - 1);
+                const unsigned old = atomicCAS(&ckey[slot], 0xFFFFFFFFu, key);
+                if (old == 0xFFFFFFFFu || old == key) { atomicAdd(&cval[slot], vsum); return; }
+            }
+            unsafeAtomicAdd(gtb + (size_t)r * gstride, vsum);               // column 0 = row scalar
         };
         for (int j = 0; j < m; ++j) {
             const float x = rdlane(xi, j), y = rdlane(yi, j), z = rdlane(zi, j);
@@ -484,6 +504,15 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_part_encode_bwd(GridDev g, EncBwd
         }
     }
     __syncthreads();
+    // flush the write-combining cache: one global atomic per touched (level, row)
+    for (int j = threadIdx.x; j < BWD_CACHE; j += ENC_BLOCK) {
+        const unsigned key = ckey[j];
+        if (key == 0xFFFFFFFFu) continue;
+        const int l = (int)(key >> 24);
+        const unsigned r = key & 0xFFFFFFu;
+        float* base = io.rowgrad ? io.rowgrad + g.dense_off[l] : io.g_dense + g.dense_off[l] * 16;
+        unsafeAtomicAdd(base + (size_t)r * gstride, cval[j]);
+    }
     // flush the small-level accumulators (dense levels are contiguous in g_dense from dense_off[l])
     int off = 0;
     for (int l = 0; l < 16; ++l) {
@@ -499,12 +528,16 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_part_encode_bwd(GridDev g, EncBwd
     }
 }
 
-static int launch_part_encode_bwd_io(const GridDev& g, const EncBwdIO& io, hipStream_t st) {
+static int launch_part_encode_bwd_io(const GridDev& g, const EncBwdIO& io_in, hipStream_t st) {
+    EncBwdIO io = io_in;
+    static const int dbg_tp = getenv("INVR_ENCB_TP") ? atoi(getenv("INVR_ENCB_TP")) : 0, dbg_na = getenv("INVR_ENCB_NOATOM") ? 1 : 0;
+    io.dbg_tp = dbg_tp; io.dbg_noatom = dbg_na;
     const int64_t n = io.n_host;                             // the count or its upper bound (device count given)
     int tp = 64;
     while (tp > 16 && n / tp < 4096) tp >>= 1;
     int64_t tiles = cdiv(n, (int64_t)tp * ENC_WAVES);
-    unsigned grid = (unsigned)(tiles < 2048 ? (tiles > 0 ? tiles : 1) : 2048);
+    static const int gmax = getenv("INVR_ENCB_GRID") ? atoi(getenv("INVR_ENCB_GRID")) : 512;      // persistent: 2 workgroups per CU (79 KB of LDS each)
+    unsigned grid = (unsigned)(tiles < gmax ? (tiles > 0 ? tiles : 1) : gmax);
     hipLaunchKernelGGL(k_part_encode_bwd, dim3(grid), dim3(ENC_BLOCK), 0, st, g, io);
     INVR_LAUNCH_CHECK();
     return 0;
@@ -512,7 +545,7 @@ static int launch_part_encode_bwd_io(const GridDev& g, const EncBwdIO& io, hipSt
 
 int launch_part_encode_bwd(const GridDev& g, const float* xyz, const float* gout, int64_t n, float* g_dense, float* g_hash,
                            float* g_xyz, hipStream_t st) {
-    EncBwdIO io{xyz, 3, 1, gout, 19, 1, g_xyz, 3, 1, n, nullptr, g_dense, g_hash, nullptr};
+    EncBwdIO io{xyz, 3, 1, gout, 19, 1, g_xyz, 3, 1, n, nullptr, g_dense, g_hash, nullptr, 0, 0};
     return launch_part_encode_bwd_io(g, io, st);
 }
 
@@ -523,7 +556,7 @@ int launch_part_encode_bwd_lists(const GridDev& g, const float* x_soa, const flo
         invr_set_error("part encoder backward supports n_levels=16, n_features_per_level=16, sum, sum_over_features, include_input");
         return 1;
     }
-    EncBwdIO io{x_soa, 1, stride, gout_soa, 1, stride, gx_soa, 1, stride, n_max, count, nullptr, nullptr, rowgrad};
+    EncBwdIO io{x_soa, 1, stride, gout_soa, 1, stride, gx_soa, 1, stride, n_max, count, nullptr, nullptr, rowgrad, 0, 0};
     return launch_part_encode_bwd_io(g, io, st);
 }
 

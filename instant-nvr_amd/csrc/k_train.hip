@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void k_merge_bwd(Workspace w, const float4* __
 // gradient) over its slab of rows and adds it to the gradient tensors with atomics.  Input column j of
 // `a` may be a k-slot of the part MLPs' rgb layer 1 (slot_order: rgb1_col maps it to the weight column, < 0 = padding).
 typedef float wg4 __attribute__((ext_vector_type(4)));
-#define WG_SLAB 512
+#define WG_SLAB 256
 struct WgradJob {
     const float* gz; const float* a;
     float* dW; float* db;
@@ -246,10 +246,10 @@ __global__ __launch_bounds__(64) void k_wgrad(WgradJobs jobs, const int32_t* __r
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 5; ++nt) acc[mt][nt] = (wg4){0.f, 0.f, 0.f, 0.f};
-    for (int64_t r = r0; r < r1; r += 4) {
+    // operands of one k-step (4 rows): loaded one step ahead of the MFMAs that consume them
+    auto load = [&](int64_t r, float* av, float* bv) {
         const int64_t row = r + g;
         const bool live = row < r1;
-        float av[4], bv[5];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             const int o = 16 * mt + i;
@@ -260,6 +260,11 @@ __global__ __launch_bounds__(64) void k_wgrad(WgradJobs jobs, const int32_t* __r
             const int c = 16 * nt + i;
             bv[nt] = (live && nt < NT) ? (c < J.I ? J.a[row * J.lda + c] : (c == J.I ? 1.0f : 0.0f)) : 0.0f;
         }
+    };
+    float av[4], bv[5], an[4], bn[5];
+    load(r0, av, bv);
+    for (int64_t r = r0; r < r1; r += 4) {
+        load(r + 4, an, bn);                               // rows >= r1 load as zeros
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             if (mt >= MT) continue;
@@ -269,6 +274,10 @@ __global__ __launch_bounds__(64) void k_wgrad(WgradJobs jobs, const int32_t* __r
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
             }
         }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) av[mt] = an[mt];
+#pragma unroll
+        for (int nt = 0; nt < 5; ++nt) bv[nt] = bn[nt];
     }
     // D[row = 4g + r][col = i] of tile (mt, nt) = dW[16 mt + 4g + r][16 nt + i]
 #pragma unroll

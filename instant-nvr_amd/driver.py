@@ -94,3 +94,60 @@ def load_network(net, model_dir, epoch=-1, strict=True):
     ck = torch.load(path, map_location='cpu')
     net.load_state_dict(ck['net'], strict=strict)
     return ck['epoch'] + 1
+
+
+class ExponentialLR(torch.optim.lr_scheduler._LRScheduler):
+    """lib/utils/optimizer/lr_scheduler.py:66-75 (cfg.train.scheduler type "exponential"): lr = base_lr * gamma ** (epoch /
+    decay_epochs), stepped once per epoch (train_net.py:138)."""
+
+    def __init__(self, optimizer, decay_epochs, gamma=0.1, last_epoch=-1):
+        self.decay_epochs, self.gamma = decay_epochs, gamma
+        super().__init__(optimizer, last_epoch)
+
+    def get_lr(self):
+        return [base_lr * self.gamma ** (self.last_epoch / self.decay_epochs) for base_lr in self.base_lrs]
+
+
+def change_training_stages(cfg, epoch, stages):
+    """train_net.py:64-75: the last stage whose `_start` <= epoch writes its keys into cfg."""
+    for stage in (stages or [])[::-1]:
+        if epoch >= stage['_start']:
+            for k, v in stage.items():
+                if k != '_start':
+                    cfg[k] = v
+            break
+
+
+def train(wrapper, optimizer, batch_fn, epochs, ep_iter, scheduler=None, stages=None, budget_s=None, on_step=None):
+    """The reference's training schedule (train_net.py:131-158 around Trainer.train, trainer.py:64-185) on the drop-in classes:
+    per epoch change_training_stages, `ep_iter` iterations with iter_step = index + 1 (so the part grids adopt the batch's
+    bounds at the first iteration of every epoch, part_base_embedder.py:107-109), scheduler.step() after the epoch.
+    `batch_fn(epoch, index)` -> collated batch dict on the device.  Stops when `budget_s` seconds of wall clock are spent
+    (BASELINE configs[3]: "5-min budget").  Nothing in the loop reads a device value back: the loss history is a list of
+    device scalars, one synchronisation at the end.  Returns dict(iterations, seconds, ray_samples, losses)."""
+    import time
+    cfg = wrapper.cfg
+    losses, n_samples, it = [], 0, 0
+    torch.cuda.synchronize() if torch.cuda.is_available() else None
+    t0 = time.perf_counter()
+    done = False
+    for epoch in range(epochs):
+        change_training_stages(cfg, epoch, stages)
+        for index in range(ep_iter):
+            batch = batch_fn(epoch, index)
+            loss, stats = train_step(wrapper, optimizer, batch, index + 1, epoch)
+            losses.append(loss)
+            n_samples += int(batch['ray_o'].shape[1]) * int(cfg.N_samples)
+            it += 1
+            if on_step is not None:
+                on_step(epoch, index, loss, stats)
+            if budget_s is not None and (it & 15) == 0 and time.perf_counter() - t0 > budget_s:
+                done = True
+                break
+        if scheduler is not None:
+            scheduler.step()
+        if done:
+            break
+    torch.cuda.synchronize() if torch.cuda.is_available() else None
+    dt = time.perf_counter() - t0
+    return {'iterations': it, 'seconds': dt, 'ray_samples': n_samples, 'losses': [float(l) for l in losses]}

@@ -67,3 +67,50 @@ def test_gather_world2_ragged():
 
 def test_gather_world2_fewer_tiles_than_ranks():
     _run(2, 30, 64)            # one tile only: rank 1 renders nothing
+
+
+# ---- data-parallel training: the gradient reducer (invr/dist_train.py) on CPU stand-ins ---------------------------------
+class _FakeEmbedder:
+    def __init__(self, n, seed):
+        self._rg = torch.randn(n, generator=torch.Generator().manual_seed(seed))
+
+    def row_grad(self):
+        return self._rg
+
+
+class _FakeArena:
+    def __init__(self, rank):
+        self.embedders = [_FakeEmbedder(n, 100 * rank + k) for k, n in enumerate((1000, 50, 7000, 3, 3))]
+        self.flat = torch.randn(123, generator=torch.Generator().manual_seed(7 + rank))
+
+
+def _reduce_worker(rank, world, port, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from invr import dist_train
+        arenas = [_FakeArena(r) for r in range(world)]          # every rank can compute the expected mean locally
+        mine = arenas[rank]
+        red = dist_train.GradReducer(mine)
+        assert red.part_order == [2, 0, 1, 3, 4]                # largest block first
+        for p in red.part_order:
+            red.reduce_part(p)
+        red.reduce_small()
+        red.wait()
+        ok = True
+        for k in range(5):
+            want = torch.stack([_FakeArena(r).embedders[k].row_grad() for r in range(world)]).mean(0)
+            ok = ok and torch.allclose(mine.embedders[k].row_grad(), want, atol=1e-7)
+        want = torch.stack([_FakeArena(r).flat for r in range(world)]).mean(0)
+        ok = ok and torch.allclose(mine.flat, want, atol=1e-7)
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_reducer_world2_averages_every_block():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_reduce_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    assert all(ret[r] for r in range(2)), dict(ret)

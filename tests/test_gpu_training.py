@@ -1,0 +1,170 @@
+"""GPU: the training half at BASELINE configs[3] / configs[4].
+
+  * configs[4] shape — 1024 rays x 128 samples, full-size inb_377 model (1.09 GB tables): forward values and EVERY parameter
+    gradient of one iteration (fused node, gradient arena, row-scalar table gradients) against CPU torch autograd of the oracle.
+  * configs[3] — inb_lan.yaml training (smpl_thresh 0.1, pair_loss_weight 1e-4, lr 1e-3, ExponentialLR, bounds adoption at
+    iter_step == 1, the reference's epoch / iteration schedule) through driver.train + FusedAdam: the loss trajectory over
+    >= 12 optimisation steps against the same loop run on the oracle with torch.optim.Adam.
+  * data-parallel training (configs[4], two ranks): see tests/test_gpu_dist_train.py.
+"""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from invr import scene, params, driver                 # noqa: E402
+from invr.config import make_cfg                        # noqa: E402
+from invr.network import Network                        # noqa: E402
+from invr.trainer import NetworkWrapper                 # noqa: E402
+from invr.optim import FusedAdam                        # noqa: E402
+from tests import oracle_train as OT                    # noqa: E402
+
+DEV = 'cuda:0'
+
+
+def patch_batch(side, seed=0, frame=3, cam_dist=1.8, res=512, centre=(256, 256), pose_scale=0.5):
+    y0, x0 = centre[0] - side // 2, centre[1] - side // 2
+    bnp, _ = scene.make_scene(res, res, seed=seed, frame=frame, cam_dist=cam_dist, pose_scale=pose_scale, crop=(y0, x0, side, side))
+    return scene.to_torch(bnp)
+
+
+def test_configs4_full_size_iteration_vs_oracle_autograd(full_net):
+    cfg0, net0 = full_net
+    cfg = copy.deepcopy(cfg0)                                     # N_samples 128, inb_377 defaults
+    net = net0                                                    # shared 286 M parameter model: restored below
+    old_cfg, was_training = net.cfg, net.training
+    net.cfg = cfg
+    net.train()
+    try:
+        bc = patch_batch(32)
+        assert bc['ray_o'].shape[1] == 1024
+        gb = {k: v.to(DEV) for k, v in bc.items()}
+        n, S = 1024, cfg.N_samples
+        g = torch.Generator().manual_seed(5)
+        jitter = torch.rand(n, S, generator=g)
+        noise = torch.rand(n * S * 5, 3, generator=g)
+        opt = FusedAdam([{'params': [p]} for p in net.parameters() if p.requires_grad], 5e-4, eps=1e-15).attach(net)
+        opt.zero_grad()
+        wrap = NetworkWrapper(net)
+        wrap.renderer._jitter = lambda shape, device: jitter.to(device)
+        wrap.renderer._pair_noise_dense = lambda rows, device: noise.to(device)[:rows]
+        tb = dict(gb)
+        tb['iter_step'] = 2
+        ret, loss, stats, _ = wrap(tb, split='train')
+        loss.backward()
+        arena = opt.arena
+        # ---- oracle: same objective, CPU autograd
+        sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+        leaves = {k: v.requires_grad_() for k, v in sd.items() if v.is_floating_point() and dict(net.named_parameters())[k].requires_grad}
+        ref_loss, ref_stats = OT.train_loss(sd, cfg, bc, jitter, noise)
+        ref_loss.backward()
+        assert abs(float(loss) - float(ref_loss)) < 2e-5 * max(1.0, abs(float(ref_loss))), (float(loss), float(ref_loss))
+        for k in ('img_loss', 'reg_dist', 'offset_loss', 'pair_loss'):
+            assert abs(float(stats[k]) - float(ref_stats[k])) < 2e-5 * max(1.0, abs(float(ref_stats[k]))), k
+        assert float(ref_stats['pair_loss']) > 0
+        # ---- gradients: small tensors dense, part tables as row scalars (every row of the 68 M compared)
+        named = dict(net.named_parameters())
+        table_ids = {id(t) for t in arena.tables}
+        checked = 0
+        for k, ref_leaf in leaves.items():
+            p = named[k]
+            rg = ref_leaf.grad
+            if id(p) in table_ids:
+                continue
+            assert rg is not None, k
+            got = arena.grad_of(p).cpu()
+            scale = max(float(rg.abs().max()), 1e-6)
+            tol = 2e-3 if k.startswith('tpose_deformer') else 2e-4           # pair term: see test_gpu_parity
+            assert float((got - rg).abs().max()) <= tol * scale + 2e-7, (k, float((got - rg).abs().max()), scale)
+            checked += 1
+        for i, pn in enumerate(net.tpose_human.part_networks):
+            e = pn.embedder
+            q = 'tpose_human.part_networks.%d.embedder.' % i
+            rows = torch.cat([leaves[q + 'dense'].grad.reshape(-1, 16), leaves[q + 'hash'].grad.reshape(-1, 16)], 0)
+            assert float((rows - rows[:, :1]).abs().max()) == 0.0           # the dense gradient IS a row scalar broadcast
+            ref_rows = rows[:, 0].to(DEV)
+            got = e.row_grad()
+            scale = max(float(ref_rows.abs().max()), 1e-6)
+            err = (got - ref_rows).abs()
+            assert float(err.max()) <= 2e-4 * scale + 2e-7, (i, float(err.max()), scale)
+            touched = ref_rows != 0
+            assert bool((got[~touched] == 0).all())                          # untouched rows: exact zeros
+            checked += 1
+        assert checked >= 60
+    finally:
+        net.cfg = old_cfg
+        net.train(was_training)
+        if hasattr(net, '_grad_arena'):
+            del net._grad_arena
+        for p in net.parameters():
+            p.grad = None
+
+
+def test_lan_config_training_loop_vs_oracle():
+    """BASELINE configs[3] (configs/inb/inb_lan.yaml over inb_377.yaml) at reduced table size: smpl_thresh 0.1,
+    pair_loss_weight 1e-4, lr 1e-3 eps 1e-15, ExponentialLR per epoch, iter_step == 1 bounds adoption at the start of each
+    epoch.  2 epochs x 7 iterations over varying frames / patches; the HIP path (driver.train, FusedAdam with gradient arena)
+    against the oracle loop with torch.optim.Adam on the CPU."""
+    cfg = make_cfg(table_log2=12, N_samples=48, smpl_thresh=0.1, pair_loss_weight=1e-4)
+    LR, GAMMA, DECAY_EPOCHS, EPOCHS, EP_ITER = 1e-3, 0.1, 2, 2, 7          # decay_epochs 1000 in the yaml; 2 here so that the step shows
+    sd0 = params.init_state_dict(cfg, seed=17)
+    frames = [dict(seed=4, frame=10 + 7 * k, centre=(250 + 9 * k, 262 - 11 * k), pose_scale=0.5 + 0.05 * k) for k in range(5)]
+    batches = [patch_batch(24, **kw) for kw in frames]
+    g = torch.Generator().manual_seed(23)
+    n_it = EPOCHS * EP_ITER
+    jit = [torch.rand(b['ray_o'].shape[1], cfg.N_samples, generator=g) for b in batches]
+    noi = [torch.rand(b['ray_o'].shape[1] * cfg.N_samples * 5, 3, generator=g) for b in batches]
+    pick = lambda epoch, index: (epoch * EP_ITER + index) % len(batches)
+
+    # ---- HIP path
+    net = Network(cfg=copy.deepcopy(cfg))
+    net.load_state_dict(sd0, strict=True)
+    net = net.to(DEV).train()
+    wrap = NetworkWrapper(net)
+    opt = driver.make_optimizer(net, lr=LR, eps=1e-15)
+    assert isinstance(opt, FusedAdam) and opt.arena is not None
+    sched = driver.ExponentialLR(opt, decay_epochs=DECAY_EPOCHS, gamma=GAMMA)
+    gbs = [{k: v.to(DEV) for k, v in b.items()} for b in batches]
+    cur = {}
+
+    def batch_fn(epoch, index):
+        k = pick(epoch, index)
+        cur['k'] = k
+        return dict(gbs[k])
+    wrap.renderer._jitter = lambda shape, device: jit[cur['k']].to(device)
+    wrap.renderer._pair_noise_dense = lambda rows, device: noi[cur['k']].to(device)[:rows]
+    out = driver.train(wrap, opt, batch_fn, EPOCHS, EP_ITER, scheduler=sched, stages=[{'_start': 0, 'ratio': 1.0}])
+    assert out['iterations'] == n_it and net.cfg.ratio == 1.0
+    mine = np.array(out['losses'])
+
+    # ---- oracle loop (CPU)
+    sd = {k: v.clone() for k, v in sd0.items()}
+    train_keys = [k for k, p in Network(cfg=copy.deepcopy(cfg)).named_parameters() if p.requires_grad]
+    for k in train_keys:
+        sd[k].requires_grad_()
+    ref_opt = torch.optim.Adam([{'params': [sd[k]], 'lr': LR} for k in train_keys], LR, eps=1e-15)
+    ref_sched = driver.ExponentialLR(ref_opt, decay_epochs=DECAY_EPOCHS, gamma=GAMMA)
+    ref = []
+    for epoch in range(EPOCHS):
+        for index in range(EP_ITER):
+            k = pick(epoch, index)
+            if index + 1 == 1:
+                OT.adopt_batch_bounds(sd, cfg, batches[k])
+            loss, _ = OT.train_loss(sd, cfg, batches[k], jit[k], noi[k])
+            ref_opt.zero_grad(set_to_none=True)
+            loss.backward()
+            ref_opt.step()
+            ref.append(float(loss))
+        ref_sched.step()
+    ref = np.array(ref)
+    assert abs(opt.param_groups[0]['lr'] - ref_opt.param_groups[0]['lr']) < 1e-12 and opt.param_groups[0]['lr'] < LR * 0.4
+    assert np.isfinite(mine).all() and mine[-1] < mine[0]
+    rel = np.abs(mine - ref) / np.abs(ref)
+    assert rel[0] < 2e-5, rel[0]                                       # identical parameters: fp32 agreement of the objective
+    assert rel.max() < 5e-3, (rel, mine, ref)                         # 14 Adam steps later (eps 1e-15: sign-like updates of noise-level gradients)
+    # the adopted bounds are part of the checkpoint
+    b0 = net.state_dict()['tpose_human.part_networks.0.embedder.bounds'].cpu()
+    assert torch.equal(b0, sd['tpose_human.part_networks.0.embedder.bounds'])
