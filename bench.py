@@ -128,8 +128,140 @@ def train_probe(net, dev, S, iters):
             'parameters_updated': int(sum(p.numel() for p in net.parameters() if p.requires_grad)), 'final_loss': float(loss)}
 
 
+def main_train(args):
+    """--train: the training iteration of the path as the bench step (BASELINE configs[4]: 1024 rays x 128 samples per rank,
+    inb_377 defaults, forward + backward fused HIP + dense Adam over all 286 M parameters; --train-config lan = configs[3]:
+    inb_lan.yaml (smpl_thresh 0.1, lr 1e-3, pair_loss_weight 1e-4), 64x64 patches x 64 samples, the reference's epoch /
+    iteration schedule, optional wall-clock --budget).  N ranks = data parallel (invr.dist_train): every rank trains on its own
+    patches (per-rank work fixed -> "scaling": "weak"), gradients are averaged with one all-reduce per gradient block,
+    overlapped with the backward."""
+    from invr import driver, dist_train
+    from invr.trainer import NetworkWrapper
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)' % (args.gpus, world)
+    dev_index = int(os.environ.get('INVR_FORCE_DEVICE', local_rank))
+    backend = os.environ.get('INVR_DIST_BACKEND', 'nccl')
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
+    if world > 1:
+        dist.init_process_group(backend, **({'device_id': dev} if backend == 'nccl' else {}))
+    lan = args.train_config == 'lan'
+    S = 64 if lan else args.samples
+    side = 64 if lan else 32
+    kw = dict(N_samples=S)
+    if args.table_log2:
+        kw['table_log2'] = args.table_log2
+    if lan:
+        kw.update(smpl_thresh=0.1, pair_loss_weight=1e-4)
+    cfg = make_cfg(**kw)
+    net = build_model(cfg, dev).train()
+    if world > 1:
+        dist_train.broadcast_parameters(net)
+    n_params = sum(p.numel() for p in net.parameters() if p.requires_grad)
+    wrap = NetworkWrapper(net)
+    opt = driver.make_optimizer(net, lr=1e-3 if lan else 5e-4, eps=1e-15)
+    sched = driver.ExponentialLR(opt, decay_epochs=1000, gamma=0.1)
+    red = dist_train.attach(opt) if world > 1 else None
+    # a small pool of patches per rank, resident in HBM (the reference's loader prefetches 8 batches deep, trainer.py:83-88)
+    pool = []
+    for k in range(8):
+        c = (200 + 23 * ((k + 3 * rank) % 5), 216 + 19 * ((2 * k + rank) % 5))
+        bnp, _ = scene_mod.make_scene(512, 512, seed=0, frame=(7 * k + 13 * rank) % 100, cam_dist=1.8, crop=(c[0], c[1], side, side))
+        pool.append({kk: v.to(dev) for kk, v in scene_mod.to_torch(bnp).items()})
+    rays = sum(int(b['ray_o'].shape[1]) for b in pool) / len(pool)         # mean rays per iteration (patches near the AABB edge lose a few)
+    it = [0]
+
+    def step():
+        b = dict(pool[it[0] % len(pool)])
+        it[0] += 1
+        return driver.train_step(wrap, opt, b, 2 + (it[0] % 400))[0]
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+    for _ in range(max(args.warmup, 2)):
+        loss = step()
+    fence()
+    region = []
+    t_start = time.perf_counter()
+    while True:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step()
+        fence()
+        region.append(time.perf_counter() - t0)
+        total = time.perf_counter() - t_start
+        enough = (total >= args.budget) if args.budget else (sum(region) >= args.min_time or len(region) >= 1000)
+        if world > 1:
+            flag = torch.tensor([1 if enough else 0], device=dev)
+            dist.broadcast(flag, 0)
+            enough = bool(int(flag.item()))
+        if enough:
+            break
+    dt = sum(region) / len(region)
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    # the dominant kernel of the iteration: the dense Adam step (HBM-bound), timed with events on the launch stream
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    adam_ms = []
+    for _ in range(5):
+        b = dict(pool[0]); b['iter_step'] = 5
+        ret, l2, _, _ = wrap(b, 0, split='train')
+        opt.zero_grad(set_to_none=True)
+        l2.mean().backward()
+        if red is not None:
+            red.wait()
+        e0.record(); opt.step(); e1.record()
+        torch.cuda.synchronize()
+        adam_ms.append(e0.elapsed_time(e1))
+    adam_ms = sorted(adam_ms)[len(adam_ms) // 2]
+    stats = wrap.renderer.last_stats.cpu().numpy().astype('int64')
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        total_rs = rays * S * world
+        table_params = sum(t.numel() for t in opt.arena.tables)
+        adam_bytes = 24 * n_params + 4 * (n_params - table_params) + table_params // 4     # p, m, v read+write; g: dense 4 B, row-scalar tables 0.25 B
+        line = {
+            'metric': 'ray-samples/sec (training iteration: forward + backward + Adam)', 'value': total_rs * args.steps / dt, 'unit': 'ray-samples/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms, 'repeats': len(region), 'timed_region_s': sum(region),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {
+                'workload': ('configs[3]: inb_lan.yaml training (smpl_thresh 0.1, lr 1e-3), 64x64 patch x 64 samples per iteration' if lan else
+                             'configs[4]: inb_377 training, %d rays x %d samples per rank per iteration' % (round(rays), S)) +
+                            ', full-size model, forward + backward fused HIP + dense Adam',
+                'rays_per_rank': float(rays), 'samples_per_ray': S, 'ray_samples_per_step': int(total_rs), 'parameters_updated': int(n_params),
+                'active_samples_rank0': int(stats[0]), 'pairs_per_part_rank0': [int(v) for v in stats[1:6]],
+                'optimizer': type(opt).__name__, 'iterations_timed': args.steps * len(region),
+                'parallelism': 'dp%d: full replicas, row-scalar table gradients (%.0f MB) + %.1f MB small tensors averaged per iteration, '
+                               'all-reduce overlapped with the backward' % (world, 4e-6 * sum(e.row_grad().numel() for e in opt.arena.embedders),
+                                                                           4e-6 * opt.arena.flat.numel()),
+                'final_loss': float(loss),
+            },
+            'roofline': {'kernel': 'k_adam (dense Adam over every parameter, 1 launch/step)', 'bound': 'hbm',
+                         'achieved': adam_bytes / (adam_ms * 1e-3) / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
+                         'frac': adam_bytes / (adam_ms * 1e-3) / HBM_PEAK, 'traffic': None,
+                         'algorithmic_bytes_per_launch': int(adam_bytes), 'kernel_ms_per_launch': adam_ms,
+                         'note': '24 B per parameter (param, exp_avg, exp_avg_sq read + write) + gradient: 4 B dense, 0.25 B for the '
+                                 'row-scalar table gradients; torch events on the launch stream around the step'},
+            'cpu_baseline': None,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument('--train', action='store_true', help='bench the training iteration instead of the eval frame (see main_train)')
+    ap.add_argument('--train-config', choices=['377', 'lan'], default='377', help='--train: configs[4] (377) or configs[3] (lan)')
+    ap.add_argument('--budget', type=float, default=0.0, help='--train: keep training for this many seconds of wall clock (configs[3]: 300)')
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
@@ -147,6 +279,8 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='launch the ~25 kernels of a frame eagerly instead of replaying one captured hipGraph')
     ap.add_argument('--shard-of', type=int, default=0, help='debug (1 GPU): render only rank 0\'s ray shard of a W-way split')
     args = ap.parse_args()
+    if args.train:
+        return main_train(args)
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))

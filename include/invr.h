@@ -309,6 +309,9 @@ typedef struct InvrAdamTensor {
     float* exp_avg_sq;          /* dev, updated in place */
     int64_t numel;
     float lr, weight_decay, bc1, bc2_sqrt;
+    const float* active;        /* dev float[1] or NULL: when it reads 0 the tensor is SKIPPED this step (no update, no step count) — the
+                                   reference's Adam skips tensors without a gradient (a body part with no flagged pair in the batch);
+                                   the fused backward reports that per part in InvrTrainGrads.part_active */
     int32_t grad_shift;         /* 0: grad has numel elements.  s > 0: grad is a ROW-SCALAR gradient of numel >> s floats, element i
                                    takes grad[i >> s] (sum-over-features hash tables: invr_train_bwd's compact table gradients) */
     int32_t step;               /* step count kept on the device by invr_adam_advance */
@@ -376,6 +379,8 @@ typedef struct InvrTrainGrads {
     float* deform_hash;
     float* deform_w[INVR_MAX_LINEAR];
     float* deform_b[INVR_MAX_LINEAR];
+    float* part_active;                     /* dev float[INVR_NUM_PARTS] or NULL: += 1 for every part that had a flagged (near or far)
+                                               pair in this backward — 0 = the reference would not have touched the part's parameters */
 } InvrTrainGrads;
 size_t invr_train_workspace_bytes(int64_t n_rays, int32_t n_samples, int64_t max_active);
 int invr_train_fwd(const InvrScene* scene, const InvrModel* model,

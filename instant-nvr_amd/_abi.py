@@ -36,7 +36,7 @@ class InvrMlpBwdOut(C.Structure):
 class InvrAdamTensor(C.Structure):
     _fields_ = [('param', C.c_void_p), ('grad', C.c_void_p), ('exp_avg', C.c_void_p), ('exp_avg_sq', C.c_void_p),
                 ('numel', C.c_int64), ('lr', C.c_float), ('weight_decay', C.c_float), ('bc1', C.c_float), ('bc2_sqrt', C.c_float),
-                ('grad_shift', C.c_int32), ('step', C.c_int32)]
+                ('active', C.c_void_p), ('grad_shift', C.c_int32), ('step', C.c_int32)]
 
 
 class InvrPartGrads(C.Structure):
@@ -46,7 +46,7 @@ class InvrPartGrads(C.Structure):
 
 class InvrTrainGrads(C.Structure):
     _fields_ = [('part', InvrPartGrads * NUM_PARTS), ('deform_dense', C.c_void_p), ('deform_hash', C.c_void_p),
-                ('deform_w', C.c_void_p * 4), ('deform_b', C.c_void_p * 4)]
+                ('deform_w', C.c_void_p * 4), ('deform_b', C.c_void_p * 4), ('part_active', C.c_void_p)]
 
 
 class InvrMlp(C.Structure):

@@ -690,6 +690,11 @@ extern "C" int invr_train_fwd(const InvrScene* scene, const InvrModel* model,
     return 0;
 }
 
+__global__ void k_part_active(const int32_t* __restrict__ counters, float* __restrict__ act) {
+    const int p = threadIdx.x;
+    if (p < INVR_NUM_PARTS && (counters[CNT_PAIRS + p] > 1 || counters[CNT_FAR + p] > 0)) act[p] += 1.0f;    // (the list always ends with the far constant)
+}
+
 __global__ void k_add_inplace(float* __restrict__ dst, const float* __restrict__ src, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] += src[i];
@@ -723,6 +728,10 @@ extern "C" int invr_train_bwd(const InvrScene* scene, const InvrModel* model, in
         INVR_LAUNCH_CHECK();
     }
     if (launch_merge_bwd(w, t.g_rawfull, t.g_raws, st)) return 1;
+    if (grads->part_active) {
+        hipLaunchKernelGGL(k_part_active, dim3(1), dim3(64), 0, st, w.counters, grads->part_active);
+        INVR_LAUNCH_CHECK();
+    }
     }
     // per part: MLPs^T -> weight gradients -> encoder^T
     for (int p = 0; p < INVR_NUM_PARTS; ++p) {

@@ -8,6 +8,7 @@
 //   g += wd * p ; m = lerp(m, g, 1-b1) ; v = b2*v + (1-b2) g*g ; p -= (lr / bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
 #include "common.h"
 
+static_assert(sizeof(float*) == 8, "64-bit");
 #define ADAM_BLOCK 256
 #define ADAM_CHUNK 16384            // elements per workgroup
 
@@ -15,6 +16,7 @@ struct AdamTensor {                 // device-resident table, one entry per tens
     float* p; const float* g; float* m; float* v;
     int64_t n;
     float lr, wd, bc1, bc2_sqrt;    // bias corrections 1-b1^step and sqrt(1-b2^step) of THIS tensor's step count
+    const float* active;            // optional device flag: 0 -> the tensor is skipped this step (torch skips tensors without gradient)
     int32_t grad_shift;             // > 0: g is a ROW-SCALAR gradient — element i takes g[i >> grad_shift] (the gradient of a
                                     // sum-over-features table is one scalar per row of 2^shift features, k_encode.hip)
     int32_t step;                   // device-side step count (invr_adam_advance): host tables need no per-step upload
@@ -25,6 +27,7 @@ struct AdamTensor {                 // device-resident table, one entry per tens
 __global__ void k_adam_advance(AdamTensor* tensors, int n, double b1, double b2) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
+    if (tensors[t].active && tensors[t].active[0] == 0.0f) return;
     const int s = tensors[t].step + 1;
     tensors[t].step = s;
     tensors[t].bc1 = (float)(1.0 - pow(b1, (double)s));
@@ -34,6 +37,7 @@ __global__ void k_adam_advance(AdamTensor* tensors, int n, double b1, double b2)
 __global__ __launch_bounds__(ADAM_BLOCK) void k_adam(const AdamTensor* __restrict__ tensors, const int32_t* __restrict__ chunk_tensor,
                                                      const int32_t* __restrict__ chunk_index, float b1, float b2, float eps) {
     const AdamTensor t = tensors[chunk_tensor[blockIdx.x]];
+    if (t.active && t.active[0] == 0.0f) return;
     const int64_t base = (int64_t)chunk_index[blockIdx.x] * ADAM_CHUNK;
     const int64_t end = min(base + ADAM_CHUNK, t.n);
     const float w1 = 1.0f - b1, w2 = 1.0f - b2, step_size = t.lr / t.bc1;
@@ -73,6 +77,8 @@ __global__ __launch_bounds__(ADAM_BLOCK) void k_adam(const AdamTensor* __restric
         for (int64_t i = base + threadIdx.x; i < end; i += ADAM_BLOCK) upd(t.p[i], t.g[i], t.m[i], t.v[i]);
     }
 }
+
+static_assert(sizeof(AdamTensor) == sizeof(InvrAdamTensor), "AdamTensor mirrors InvrAdamTensor");
 
 int launch_adam_advance(void* tensors, int n, float b1, float b2, hipStream_t st) {
     if (n == 0) return 0;

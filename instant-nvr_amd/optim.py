@@ -50,9 +50,12 @@ class FusedAdam(torch.optim.Optimizer):
             self.arena.zero()
 
     def _flush_steps(self):
+        """Write the device-side step counts back into the host `step` tensors (state_dict layout of torch.optim.Adam).  The
+        device is authoritative: a tensor skipped through its activity flag did not count the step."""
         if self._pending:
-            for p in self._plan_params:
-                self.state[p]['step'] += self._pending
+            tab = (_abi.InvrAdamTensor * len(self._plan_params)).from_buffer_copy(bytes(self._table.cpu().numpy()))
+            for p, e in zip(self._plan_params, tab):
+                self.state[p]['step'] = torch.tensor(float(e.step))
             self._pending = 0
 
     def state_dict(self):
@@ -114,6 +117,8 @@ class FusedAdam(torch.optim.Optimizer):
                 e.param, e.grad, e.exp_avg, e.exp_avg_sq = p.data_ptr(), g.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr()
                 e.numel, e.lr, e.weight_decay = p.numel(), group['lr'], group['weight_decay']
                 e.grad_shift, e.step = sh, int(st['step'])
+                act = self.arena.active_flag_of(p) if self.arena is not None else None
+                e.active = act.data_ptr() if act is not None else None
                 n = (p.numel() + E - 1) // E
                 ct.append(np.full(n, t, np.int32))
                 ci.append(np.arange(n, dtype=np.int32))

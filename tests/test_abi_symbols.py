@@ -52,8 +52,8 @@ def test_struct_sizes_match_header():
     assert C.sizeof(_abi.InvrMlp) == 8 * 8 + 5 * 4 + 4
     assert C.sizeof(_abi.InvrPart) == C.sizeof(_abi.InvrGrid) + 2 * C.sizeof(_abi.InvrMlp) + 8 + 8
     L = _abi.lib()
-    assert C.sizeof(_abi.InvrAdamTensor) == 4 * 8 + 8 + 4 * 4 + 2 * 4
-    assert C.sizeof(_abi.InvrTrainGrads) == 5 * (8 + 4 * 4 * 8 + 8) + 2 * 8 + 2 * 4 * 8
+    assert C.sizeof(_abi.InvrAdamTensor) == 4 * 8 + 8 + 4 * 4 + 8 + 2 * 4
+    assert C.sizeof(_abi.InvrTrainGrads) == 5 * (8 + 4 * 4 * 8 + 8) + 2 * 8 + 2 * 4 * 8 + 8
     for i, t in enumerate((_abi.InvrGrid, _abi.InvrMlp, _abi.InvrPart, _abi.InvrModel, _abi.InvrScene, _abi.InvrWsLayout, _abi.InvrMlpBwdOut,
                            _abi.InvrAdamTensor, _abi.InvrTrainGrads)):
         assert L.invr_sizeof(i) == C.sizeof(t), t

