@@ -167,7 +167,8 @@ def main_train(args):
     # a small pool of patches per rank, resident in HBM (the reference's loader prefetches 8 batches deep, trainer.py:83-88)
     pool = []
     for k in range(8):
-        c = (200 + 23 * ((k + 3 * rank) % 5), 216 + 19 * ((2 * k + rank) % 5))
+        # patch corners spread over the figure (head .. legs, torso .. arms), as random crops of the reference's sampler do
+        c = (90 + 70 * ((k + 3 * rank) % 5), 190 + 32 * ((2 * k + rank) % 4))
         bnp, _ = scene_mod.make_scene(512, 512, seed=0, frame=(7 * k + 13 * rank) % 100, cam_dist=1.8, crop=(c[0], c[1], side, side))
         pool.append({kk: v.to(dev) for kk, v in scene_mod.to_torch(bnp).items()})
     rays = sum(int(b['ray_o'].shape[1]) for b in pool) / len(pool)         # mean rays per iteration (patches near the AABB edge lose a few)
@@ -225,8 +226,18 @@ def main_train(args):
     if rank == 0:
         ms = dt / args.steps * 1e3
         total_rs = rays * S * world
-        table_params = sum(t.numel() for t in opt.arena.tables)
-        adam_bytes = 24 * n_params + 4 * (n_params - table_params) + table_params // 4     # p, m, v read+write; g: dense 4 B, row-scalar tables 0.25 B
+        # bytes the timed Adam launch moved: p, m, v read+write (24 B) + gradient (dense 4 B, row-scalar tables 0.25 B) for every
+        # tensor that was updated (a part without a flagged pair in the batch is skipped, as torch skips tensors without gradient)
+        act = opt.arena.part_active.cpu().numpy()
+        table_ids = {id(t) for t in opt.arena.tables}
+        adam_bytes = 0
+        for p_ in net.parameters():
+            if not p_.requires_grad:
+                continue
+            flag = opt.arena.active_flag_of(p_)
+            if flag is not None and float(flag) == 0.0:
+                continue
+            adam_bytes += p_.numel() * 24 + (p_.numel() // 4 if id(p_) in table_ids else p_.numel() * 4)
         line = {
             'metric': 'ray-samples/sec (training iteration: forward + backward + Adam)', 'value': total_rs * args.steps / dt, 'unit': 'ray-samples/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms, 'repeats': len(region), 'timed_region_s': sum(region),
@@ -236,7 +247,7 @@ def main_train(args):
                              'configs[4]: inb_377 training, %d rays x %d samples per rank per iteration' % (round(rays), S)) +
                             ', full-size model, forward + backward fused HIP + dense Adam',
                 'rays_per_rank': float(rays), 'samples_per_ray': S, 'ray_samples_per_step': int(total_rs), 'parameters_updated': int(n_params),
-                'active_samples_rank0': int(stats[0]), 'pairs_per_part_rank0': [int(v) for v in stats[1:6]],
+                'active_samples_rank0': int(stats[0]), 'pairs_per_part_rank0': [int(v) for v in stats[1:6]], 'parts_updated_last_step': [bool(a) for a in act],
                 'optimizer': type(opt).__name__, 'iterations_timed': args.steps * len(region),
                 'parallelism': 'dp%d: full replicas, row-scalar table gradients (%.0f MB) + %.1f MB small tensors averaged per iteration, '
                                'all-reduce overlapped with the backward' % (world, 4e-6 * sum(e.row_grad().numel() for e in opt.arena.embedders),

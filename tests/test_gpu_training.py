@@ -95,7 +95,8 @@ def test_configs4_full_size_iteration_vs_oracle_autograd(full_net):
                 assert float(e.row_grad().abs().max()) == 0.0
                 continue
             rows = torch.cat([leaves[q + 'dense'].grad.reshape(-1, 16), leaves[q + 'hash'].grad.reshape(-1, 16)], 0)
-            assert float((rows - rows[:, :1]).abs().max()) == 0.0           # the dense gradient IS a row scalar broadcast
+            # the dense gradient IS a row scalar broadcast (the CPU sums each feature column separately: equal up to rounding)
+            assert float((rows - rows[:, :1]).abs().max()) <= 1e-5 * float(rows.abs().max()) + 1e-12
             ref_rows = rows[:, 0].to(DEV)
             got = e.row_grad()
             scale = max(float(ref_rows.abs().max()), 1e-6)
