@@ -19,6 +19,92 @@
 
 #include "mlp_common.h"
 
+// One 16-pair column block of a wave: inputs, activations and outputs stay in registers from the embedding to [rgb, occ].
+struct MlpCol {
+    float eb[EMB_STEPS];        // k-slots 4s+g of the (padded) 20-wide embedding of pair `col`
+    float dv[3];                // canonical view direction
+    f32x4 h[4];                 // hidden activations (log2 domain), feature 16 mt + 4 g + r
+    f32x4 feat;                 // occ features 1..16 (true scale)
+    float occ;
+    float k5[13];               // rgb layer-1 k-slots 5..17: sin/cos (6), [d | latent] (3), feat (4)
+};
+
+// The stages of the two MLPs for ONE column block.  mlp_part runs two column blocks per wave SKEWED by one stage, so that in
+// every scheduling region the matrix-core instructions of one block sit beside the vector instructions (activation, view-
+// direction encoding, heads) of the other: a SIMD issues VALU in the shadow of a 32-cycle fp32 MFMA only if independent VALU
+// work is available at that point of the (in-order) wave.
+__device__ __forceinline__ void st_occ1(const float* lds, int lane, int g, MlpCol& c) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) c.h[mt] = bias4(lds + O_B_OCC1, mt, g);
+#pragma unroll
+    for (int s = 0; s < EMB_STEPS; ++s)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) c.h[mt] = mfma4(lds[O_W_OCC1 + (s * 4 + mt) * 64 + lane], c.eb[s], c.h[mt]);
+}
+__device__ __forceinline__ void st_act(MlpCol& c) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) c.h[mt] = softplus4_log2(c.h[mt]);
+}
+__device__ __forceinline__ void st_occ2(const float* lds, int lane, int g, MlpCol& c) {       // features 1..16 on MFMA, logit 0 on VALU
+    c.feat = bias4(lds + O_B_OCC2, 0, g);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) c.feat = mfma4(lds[O_W_OCC2 + s * 64 + lane], c.h[s >> 2][s & 3], c.feat);
+    const float lg = head_dot_s(c.h, lds + O_V_OCC, g) + lds[O_V_OCC + 64];
+    c.occ = one_minus_exp_neg(softplus_f(lg));                    // 1 - exp(-softplus(h0))  (:52)
+}
+__device__ __forceinline__ void st_rgb_in(MlpCol& c, int g, float fmul, float misc0_lat, float misc1, float misc2) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float sn, cs;
+        sincos_hw(c.dv[k] * fmul, &sn, &cs);
+        c.k5[2 * k] = sn;
+        c.k5[2 * k + 1] = cs;
+    }
+    c.k5[6] = g == 0 ? c.dv[0] : (g == 1 ? c.dv[1] : (g == 2 ? c.dv[2] : misc0_lat));
+    c.k5[7] = misc1;
+    c.k5[8] = misc2;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c.k5[9 + r] = c.feat[r];
+}
+__device__ __forceinline__ void st_rgb1(const float* lds, int lane, int g, MlpCol& c) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) c.h[mt] = bias4(lds + O_B_RGB1, mt, g);
+#pragma unroll
+    for (int s = 0; s < RGB1_STEPS; ++s)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+            c.h[mt] = mfma4(lds[O_W_RGB1 + (s * 4 + mt) * 64 + lane], s < EMB_STEPS ? c.eb[s < EMB_STEPS ? s : 0] : c.k5[s >= EMB_STEPS ? s - EMB_STEPS : 0], c.h[mt]);
+}
+__device__ __forceinline__ void st_rgb2(const float* lds, int lane, int g, MlpCol& c) {
+    f32x4 h2[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) h2[mt] = bias4(lds + O_B_RGB2, mt, g);
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) h2[mt] = mfma4(lds[O_W_RGB2 + (s * 4 + mt) * 64 + lane], c.h[s >> 2][s & 3], h2[mt]);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) c.h[mt] = h2[mt];
+}
+__device__ __forceinline__ float4 st_head(const float* lds, int g, const MlpCol& c) {          // rgb head 64 -> 3, sigmoid
+    float o[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) o[k] = sigmoid_f(head_dot_s(c.h, lds + O_V_OUT + k * 64, g) + lds[O_V_OUT + 3 * 64 + k]);
+    return make_float4(o[0], o[1], o[2], c.occ);
+}
+#define MLP_FENCE() __builtin_amdgcn_sched_barrier(0)
+// Interleave directive for one scheduling region (between two MLP_FENCEs): N_MFMA groups of {1 matrix instruction, V vector
+// instructions} — the vector work of the other column block is issued in the shadows of this block's MFMAs (<= 5 single-issue
+// VALU fit beside a 32-cycle fp32 MFMA; MI355X_MICROARCH.md).  LDS reads of the weights float freely.
+template <int N_MFMA, int V>
+__device__ __forceinline__ void mlp_interleave() {
+#pragma unroll
+    for (int i = 0; i < N_MFMA; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, V, 0);      // VALU
+    }
+}
+
 template <int NRGB>
 __device__ __forceinline__ void mlp_part(float* lds, const PartMlpDev& pm, const float* __restrict__ emb,
                                          const float* __restrict__ ds, int64_t stride, const int32_t* __restrict__ l_slot,
@@ -26,7 +112,7 @@ __device__ __forceinline__ void mlp_part(float* lds, const PartMlpDev& pm, const
                                          float4* __restrict__ raw_direct) {
     if ((int64_t)blockIdx.x * (MLP_BLOCK / 64) * MLP_CB * 16 >= cnt) return;
     __syncthreads();                                   // previous part's weights no longer in use
-    stage_weights<NRGB>(pm, lds);
+    stage_weights<NRGB, true>(pm, lds);
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, col = lane & 15;
     // per-lane constant k-slots of the [d, latent, pad] block of the rgb input
@@ -36,123 +122,70 @@ __device__ __forceinline__ void mlp_part(float* lds, const PartMlpDev& pm, const
     const float misc2 = g < 3 ? lat[5 + g] : 0.0f;               // e = 8+g ; e = 11 is padding
     const float fmul = (float)(1 << g);                          // frequency 2^g of this lane group
 
-    const int64_t per_block = (MLP_BLOCK / 64) * MLP_CB * 16;
-    for (int64_t t0 = (int64_t)blockIdx.x * per_block; t0 < cnt; t0 += (int64_t)gridDim.x * per_block) {
-        const int64_t wbase = t0 + (int64_t)wv * MLP_CB * 16;
-        if (wbase >= cnt) continue;
-        int64_t pair[MLP_CB];
-        float eb[MLP_CB][EMB_STEPS];
-        float dv[MLP_CB][3];
+    const int64_t per_block = (MLP_BLOCK / 64) * MLP_CB * 16, step = (int64_t)gridDim.x * per_block;
+    auto load_in = [&](int64_t wbase, MlpCol& A, MlpCol& B) {
+        const int64_t pa = min(wbase + col, (int64_t)cnt - 1), pb = min(wbase + 16 + col, (int64_t)cnt - 1);
 #pragma unroll
-        for (int cb = 0; cb < MLP_CB; ++cb) {
-            pair[cb] = min(wbase + cb * 16 + col, (int64_t)cnt - 1);
+        for (int s = 0; s < EMB_STEPS; ++s) { A.eb[s] = emb[(int64_t)(4 * s + g) * cap + pa]; B.eb[s] = emb[(int64_t)(4 * s + g) * cap + pb]; }
 #pragma unroll
-            for (int s = 0; s < EMB_STEPS; ++s) eb[cb][s] = emb[(int64_t)(4 * s + g) * cap + pair[cb]];
+        for (int c = 0; c < 3; ++c) { A.dv[c] = ds[(int64_t)c * stride + pa]; B.dv[c] = ds[(int64_t)c * stride + pb]; }
+    };
+    int64_t wbase = (int64_t)blockIdx.x * per_block + (int64_t)wv * MLP_CB * 16;
+    if (wbase >= cnt) return;
+    MlpCol A, B;
+    float nA_eb[EMB_STEPS], nB_eb[EMB_STEPS], nA_dv[3], nB_dv[3];      // inputs of the NEXT tile: loaded a whole tile ahead
+    load_in(wbase, A, B);
+    for (; wbase < cnt; wbase += step) {
+        {
+            MlpCol tA, tB;
+            load_in(min(wbase + step, (int64_t)cnt - 1), tA, tB);         // (clamped: the values are unused past the last tile)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) dv[cb][c] = ds[(int64_t)c * stride + pair[cb]];
+            for (int s = 0; s < EMB_STEPS; ++s) { nA_eb[s] = tA.eb[s]; nB_eb[s] = tB.eb[s]; }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { nA_dv[c] = tA.dv[c]; nB_dv[c] = tB.dv[c]; }
         }
-        // ---- occ layer 1: 20 -> 64
-        f32x4 h[MLP_CB][4];
-#pragma unroll
-        for (int cb = 0; cb < MLP_CB; ++cb)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) h[cb][mt] = bias4(lds + O_B_OCC1, mt, g);
-#pragma unroll
-        for (int s = 0; s < EMB_STEPS; ++s)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const float a = lds[O_W_OCC1 + (s * 4 + mt) * 64 + lane];
-#pragma unroll
-                for (int cb = 0; cb < MLP_CB; ++cb) h[cb][mt] = mfma4(a, eb[cb][s], h[cb][mt]);
-            }
-#pragma unroll
-        for (int cb = 0; cb < MLP_CB; ++cb)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) h[cb][mt] = softplus4(h[cb][mt]);
-        // ---- occ layer 2: features 1..16 on MFMA, logit 0 on VALU
-        f32x4 feat[MLP_CB];
-        float occ[MLP_CB];
-#pragma unroll
-        for (int cb = 0; cb < MLP_CB; ++cb) {
-            feat[cb] = bias4(lds + O_B_OCC2, 0, g);
-            float lg = head_dot(h[cb], lds + O_V_OCC, g) + lds[O_V_OCC + 64];
-            occ[cb] = one_minus_exp_neg(softplus_f(lg));          // 1 - exp(-softplus(h0))  (:52)
-        }
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const float a = lds[O_W_OCC2 + s * 64 + lane];
-#pragma unroll
-            for (int cb = 0; cb < MLP_CB; ++cb) feat[cb] = mfma4(a, h[cb][s >> 2][s & 3], feat[cb]);
-        }
-        // ---- rgb layer 1: 72 -> 64
-#pragma unroll
-        for (int cb = 0; cb < MLP_CB; ++cb)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) h[cb][mt] = bias4(lds + O_B_RGB1, mt, g);
-        float kb[MLP_CB][RGB1_STEPS];
-#pragma unroll
-        for (int cb = 0; cb < MLP_CB; ++cb) {
-#pragma unroll
-            for (int s = 0; s < EMB_STEPS; ++s) kb[cb][s] = eb[cb][s];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                float sn, cs;
-                sincos_hw(dv[cb][c] * fmul, &sn, &cs);
-                kb[cb][5 + 2 * c] = sn;
-                kb[cb][6 + 2 * c] = cs;
-            }
-            kb[cb][11] = g == 0 ? dv[cb][0] : (g == 1 ? dv[cb][1] : (g == 2 ? dv[cb][2] : misc0_lat));
-            kb[cb][12] = misc1;
-            kb[cb][13] = misc2;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) kb[cb][14 + r] = feat[cb][r];
-        }
-#pragma unroll
-        for (int s = 0; s < RGB1_STEPS; ++s)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const float a = lds[O_W_RGB1 + (s * 4 + mt) * 64 + lane];
-#pragma unroll
-                for (int cb = 0; cb < MLP_CB; ++cb) h[cb][mt] = mfma4(a, kb[cb][s], h[cb][mt]);
-            }
-#pragma unroll
-        for (int cb = 0; cb < MLP_CB; ++cb)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) h[cb][mt] = softplus4(h[cb][mt]);
-        // ---- rgb layer 2: 64 -> 64 (body, head)
+        st_occ1(lds, lane, g, A);
+        MLP_FENCE();
+        st_occ1(lds, lane, g, B); st_act(A);
+        mlp_interleave<20, 4>();
+        MLP_FENCE();
+        st_occ2(lds, lane, g, A); st_act(B);
+        mlp_interleave<16, 5>();
+        MLP_FENCE();
+        st_occ2(lds, lane, g, B); st_rgb_in(A, g, fmul, misc0_lat, misc1, misc2);
+        mlp_interleave<16, 4>();
+        MLP_FENCE();
+        st_rgb1(lds, lane, g, A); st_rgb_in(B, g, fmul, misc0_lat, misc1, misc2);
+        mlp_interleave<30, 1>();
+        MLP_FENCE();
+        st_rgb1(lds, lane, g, B); st_act(A);
+        mlp_interleave<72, 1>();
+        MLP_FENCE();
+        float4 rA, rB;
         if (NRGB == 3) {
-            f32x4 h2[MLP_CB][4];
-#pragma unroll
-            for (int cb = 0; cb < MLP_CB; ++cb)
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) h2[cb][mt] = bias4(lds + O_B_RGB2, mt, g);
-#pragma unroll
-            for (int s = 0; s < 16; ++s)
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
-                    const float a = lds[O_W_RGB2 + (s * 4 + mt) * 64 + lane];
-#pragma unroll
-                    for (int cb = 0; cb < MLP_CB; ++cb) h2[cb][mt] = mfma4(a, h[cb][s >> 2][s & 3], h2[cb][mt]);
-                }
-#pragma unroll
-            for (int cb = 0; cb < MLP_CB; ++cb)
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) h[cb][mt] = softplus4(h2[cb][mt]);
+            st_rgb2(lds, lane, g, A); st_act(B);
+            mlp_interleave<64, 1>();
+            MLP_FENCE();
+            st_rgb2(lds, lane, g, B); st_act(A);
+            mlp_interleave<64, 1>();
+            MLP_FENCE();
+            rA = st_head(lds, g, A); st_act(B);
+            MLP_FENCE();
+            rB = st_head(lds, g, B);
+        } else {
+            rA = st_head(lds, g, A); st_act(B);
+            MLP_FENCE();
+            rB = st_head(lds, g, B);
         }
-        // ---- rgb head 64 -> 3, sigmoid; store [rgb, occ]
-#pragma unroll
-        for (int cb = 0; cb < MLP_CB; ++cb) {
-            float o[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-                o[c] = sigmoid_f(head_dot(h[cb], lds + O_V_OUT + c * 64, g) + lds[O_V_OUT + 3 * 64 + c]);
-            const int64_t pi = wbase + cb * 16 + col;
-            if (g == 0 && pi < cnt) {
-                float4 r = make_float4(o[0], o[1], o[2], occ[cb]);
-                if (raw_direct) raw_direct[pi] = r;
-                else raws[(int64_t)l_slot[pi] * INVR_NUM_PARTS + part] = r;
-            }
+        const int64_t pa = wbase + col, pb = wbase + 16 + col;
+        if (g == 0) {
+            if (pa < cnt) { if (raw_direct) raw_direct[pa] = rA; else raws[(int64_t)l_slot[pa] * INVR_NUM_PARTS + part] = rA; }
+            if (pb < cnt) { if (raw_direct) raw_direct[pb] = rB; else raws[(int64_t)l_slot[pb] * INVR_NUM_PARTS + part] = rB; }
         }
+#pragma unroll
+        for (int s = 0; s < EMB_STEPS; ++s) { A.eb[s] = nA_eb[s]; B.eb[s] = nB_eb[s]; }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { A.dv[c] = nA_dv[c]; B.dv[c] = nB_dv[c]; }
     }
 }
 

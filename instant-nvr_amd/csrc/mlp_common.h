@@ -36,23 +36,29 @@ __device__ __forceinline__ int rgb1_col(int s, int g) {
 // hidden unit held by lane group g for k-step s of a 64-wide hidden layer
 __device__ __forceinline__ int hid_col(int s, int g) { return 16 * (s >> 2) + 4 * g + (s & 3); }
 
-template <int NRGB>   // number of rgb linears: 2 (70-64-3) or 3 (70-64-64-3)
+// LOG2DOM (forward-only kernels): the hidden activations are kept in the log2 domain, u = log2(1 + exp2(z log2e)) = softplus(z) /
+// ln2, and the two scale factors are folded into the staged weights — a layer that feeds a Softplus is scaled by log2e (weights
+// and bias), a layer that consumes Softplus outputs by ln2; for a hidden-to-hidden layer the two cancel exactly (only its bias is
+// scaled).  The activation then costs {min, exp2, add, log2} = 4 single-issue VALU per value instead of 4.5 issue slots with packed
+// multiplies, which are expensive beside MFMAs (MI355X_MICROARCH.md "price of one filler beside MFMAs").
+template <int NRGB, bool LOG2DOM = false>   // number of rgb linears: 2 (70-64-3) or 3 (70-64-64-3)
 __device__ void stage_weights(const PartMlpDev& pm, float* lds) {
+    const float s_in = LOG2DOM ? INVR_LOG2E : 1.0f, s_out = LOG2DOM ? INVR_LN2 : 1.0f;
     const float* W0 = pm.occ.w[0]; const float* W1 = pm.occ.w[1];
     const float* R0 = pm.rgb.w[0]; const float* R1 = pm.rgb.w[1]; const float* R2 = pm.rgb.w[NRGB - 1];
     for (int t = threadIdx.x; t < EMB_STEPS * 4 * 64; t += MLP_BLOCK) {
         int ln = t & 63, mt = (t >> 6) & 3, s = t >> 8, g = ln >> 4, i = ln & 15;
         int col = 4 * s + g;
-        lds[O_W_OCC1 + t] = col < 19 ? W0[(16 * mt + i) * 19 + col] : 0.0f;
+        lds[O_W_OCC1 + t] = col < 19 ? W0[(16 * mt + i) * 19 + col] * s_in : 0.0f;
     }
     for (int t = threadIdx.x; t < 16 * 64; t += MLP_BLOCK) {
         int ln = t & 63, s = t >> 6, g = ln >> 4, i = ln & 15;
-        lds[O_W_OCC2 + t] = W1[(1 + i) * HID + hid_col(s, g)];
+        lds[O_W_OCC2 + t] = W1[(1 + i) * HID + hid_col(s, g)] * s_out;
     }
     for (int t = threadIdx.x; t < RGB1_STEPS * 4 * 64; t += MLP_BLOCK) {
         int ln = t & 63, mt = (t >> 6) & 3, s = t >> 8, g = ln >> 4, i = ln & 15;
         int col = rgb1_col(s, g);
-        lds[O_W_RGB1 + t] = col >= 0 ? R0[(16 * mt + i) * 70 + col] : 0.0f;
+        lds[O_W_RGB1 + t] = col >= 0 ? R0[(16 * mt + i) * 70 + col] * s_in : 0.0f;
     }
     if (NRGB == 3)
         for (int t = threadIdx.x; t < 16 * 4 * 64; t += MLP_BLOCK) {
@@ -60,14 +66,14 @@ __device__ void stage_weights(const PartMlpDev& pm, float* lds) {
             lds[O_W_RGB2 + t] = R1[(16 * mt + i) * HID + hid_col(s, g)];
         }
     for (int t = threadIdx.x; t < 64; t += MLP_BLOCK) {
-        lds[O_B_OCC1 + t] = pm.occ.b[0][t];
-        lds[O_B_RGB1 + t] = pm.rgb.b[0][t];
-        if (NRGB == 3) lds[O_B_RGB2 + t] = pm.rgb.b[1][t];
+        lds[O_B_OCC1 + t] = pm.occ.b[0][t] * s_in;
+        lds[O_B_RGB1 + t] = pm.rgb.b[0][t] * s_in;
+        if (NRGB == 3) lds[O_B_RGB2 + t] = pm.rgb.b[1][t] * s_in;      // (rgb2 weights: ln2 * log2e = 1, unscaled)
         int g = t >> 4, u = t & 15;                              // slot order: [g][mt*4+r]
         int hc = 16 * (u >> 2) + 4 * g + (u & 3);
-        lds[O_V_OCC + t] = W1[hc];                               // occ logit row 0
+        lds[O_V_OCC + t] = W1[hc] * s_out;                       // occ logit row 0
 #pragma unroll
-        for (int c = 0; c < 3; ++c) lds[O_V_OUT + c * 64 + t] = R2[c * HID + hc];
+        for (int c = 0; c < 3; ++c) lds[O_V_OUT + c * 64 + t] = R2[c * HID + hc] * s_out;
     }
     if (threadIdx.x < 16) lds[O_B_OCC2 + threadIdx.x] = pm.occ.b[1][1 + threadIdx.x];
     if (threadIdx.x == 0) {
@@ -101,9 +107,31 @@ __device__ __forceinline__ f32x4 softplus4(f32x4 v) {
     r[0] = la.x; r[1] = la.y; r[2] = lb.x; r[3] = lb.y;
     return r;
 }
+// log2-domain Softplus of an MFMA tile whose pre-activation already carries the log2e factor (stage_weights<.., true>):
+// u = log2(1 + exp2(a)); softplus = ln2 * u is folded into the consumer's weights.  a is clamped at 126 (exp2 overflow).
+__device__ __forceinline__ f32x4 softplus4_log2(f32x4 v) {
+    f32x4 r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = log2_raw(1.0f + exp2_raw(fminf(v[k], 126.0f)));
+    return r;
+}
 __device__ __forceinline__ f32x4 bias4(const float* b, int mt, int g) {
     const float* p = b + 16 * mt + 4 * g;
     f32x4 r; r[0] = p[0]; r[1] = p[1]; r[2] = p[2]; r[3] = p[3];
+    return r;
+}
+// scalar-FMA form of head_dot (forward kernels: packed fp32 ops beside MFMAs cost more than their slot)
+__device__ __forceinline__ float head_dot_s(const f32x4* h, const float* wv, int g) {
+    const float* w = wv + g * 16;
+    float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        a0 = fmaf(w[mt * 4], h[mt][0], a0); a1 = fmaf(w[mt * 4 + 1], h[mt][1], a1);
+        a0 = fmaf(w[mt * 4 + 2], h[mt][2], a0); a1 = fmaf(w[mt * 4 + 3], h[mt][3], a1);
+    }
+    float r = a0 + a1;
+    r += __shfl_xor(r, 16);
+    r += __shfl_xor(r, 32);
     return r;
 }
 // dot of the 16 hidden values this lane holds with slot-ordered head weights, summed over the 4 lane groups
