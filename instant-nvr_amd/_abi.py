@@ -13,7 +13,7 @@ from . import params
 from .config import NUM_PARTS, PART_NAMES
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libinvr.so')
+LIB_PATH = os.environ.get('INVR_LIB_PATH') or os.path.join(HERE, 'libinvr.so')      # (INVR_LIB_PATH: experiment builds)
 
 MAX_LEVELS, MAX_LINEAR, STATS_LEN = 16, 4, 16
 _f32p, _i32p, _i64p, _u8p = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_uint8)

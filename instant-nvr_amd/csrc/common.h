@@ -49,6 +49,8 @@ struct GridDev {
     // T = 2^mod_k + mod_c with a small mod_c (nextprime(2^k)): 32-bit reduction is valid (host-checked)
     int32_t mod_k, mod32;
     uint32_t mod_c;
+    int32_t mod24;              // mod32 and every multiplicand of its folding rounds < 2^24: v_mul_u32_u24 (full rate) instead of
+                                // v_mul_lo_u32 (quarter rate)
     int32_t res[INVR_MAX_LEVELS];
     float cell[INVR_MAX_LEVELS];
     int64_t dense_off[INVR_MAX_LEVELS];
@@ -230,6 +232,19 @@ __device__ __forceinline__ void level_corners(float x, float cell, int res, int&
 
 __device__ __forceinline__ uint32_t grid_hash_mod(uint64_t x, const GridDev& g) {
     return g.mod32 ? hash_mod32(x, g.mod_k, g.mod_c, (uint32_t)g.T) : hash_mod64(x, g.T, g.inv_T);
+}
+// hash_mod32 with 24-bit multiplies (host-checked: c, h0, h1, h2 < 2^24): the same integer arithmetic, exact
+__device__ __forceinline__ uint32_t hash_mod24(uint64_t x, int k, uint32_t c, uint32_t T) {
+    const uint32_t mask = (1u << k) - 1u, lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    const uint32_t a0 = lo & mask, h0 = (hi << (32 - k)) | (lo >> k);
+    const uint32_t y1 = __umul24(c, h0), a1 = y1 & mask, h1 = y1 >> k;
+    const uint32_t y2 = __umul24(c, h1), a2 = y2 & mask, h2 = y2 >> k;
+    const uint32_t y3 = __umul24(c, h2);
+    int32_t v = (int32_t)(a0 + a2) - (int32_t)(a1 + y3);
+    v += (v < 0) ? (int32_t)T : 0;
+    v += (v < 0) ? (int32_t)T : 0;
+    v -= (v >= (int32_t)T) ? (int32_t)T : 0;
+    return (uint32_t)v;
 }
 
 // ---- kernel launchers (defined in the .hip files) ---------------------------------------------

@@ -54,6 +54,8 @@ GridDev make_grid_dev(const InvrGrid* g) {
             if (y1 < (1ull << 32) && y2 < (1ull << 32) && y3 < (uint64_t)d.T && (y3 >> k) == 0 &&
                 (uint64_t)d.T < (1ull << 30))
                 d.mod32 = 1;
+            // 24-bit multiplies: c and the multiplicands h0 <= 2^41 >> k, h1 <= y1 >> k, h2 <= y2 >> k below 2^24
+            d.mod24 = d.mod32 && c < (1u << 24) && ((1ull << 41) >> k) < (1ull << 24) && (y1 >> k) < (1ull << 24) && (y2 >> k) < (1ull << 24);
         }
     }
     for (int l = 0; l < INVR_MAX_LEVELS; ++l) { d.res[l] = g->res[l]; d.cell[l] = g->cell[l]; d.dense_off[l] = g->dense_off[l]; }
@@ -189,6 +191,7 @@ static size_t carve(Workspace& w, void* base, int64_t N, int64_t cap) {
     w.knn.voxcls = c.take<uint8_t>((size_t)VOXMASK_MAX_CELLS * INVR_NUM_PARTS);
     w.knn.voxmask = c.take<unsigned long long>((size_t)VOXMASK_MAX_CELLS * INVR_NUM_PARTS);
     w.knn.voxu2 = c.take<float>((size_t)VOXMASK_MAX_CELLS * INVR_NUM_PARTS);
+    w.knn.live_cells = c.take<int32_t>((size_t)VOXMASK_MAX_CELLS);
     w.mask = c.take<unsigned long long>(nb * 16);
     w.block_cnt = c.take<int32_t>(nb);
     w.block_off = c.take<int32_t>(nb);
@@ -306,6 +309,10 @@ static int render_impl(const InvrScene* scene, const InvrModel* model,
     }
     hipStream_t side = ss.side;
     hipEvent_t ev_fork = ss.fork, ev_join = ss.join;
+    // cell mask of the distance volume + list of the cells that can hold a survivor (a few us): feeds both the cull (this
+    // stream) and the KNN's lattice classification (side stream)
+    INVR_HIP(hipMemsetAsync(w.counters, 0, CNT_LEN * sizeof(int32_t), st));
+    const bool have_cells = launch_cull_cells(a, w, st) != 0;
     INVR_HIP(hipEventRecord(ev_fork, st));
     INVR_HIP(hipStreamWaitEvent(side, ev_fork, 0));
     if (launch_knn_prepare(a, w, side)) return 1;
@@ -314,13 +321,12 @@ static int render_impl(const InvrScene* scene, const InvrModel* model,
     static const bool no_voxmask = getenv("INVR_NO_VOXMASK") != nullptr, no_voxcls = getenv("INVR_NO_VOXCLS") != nullptr,
                       no_merge = getenv("INVR_NO_MERGE") != nullptr;
     if (no_voxmask) w.knn.voxmask = nullptr;
-    if ((int64_t)a.scene.pbw.dx * a.scene.pbw.dy * a.scene.pbw.dz > VOXMASK_MAX_CELLS || no_voxcls) { w.knn.voxcls = nullptr; w.knn.voxmask = nullptr; }
+    if (!have_cells || no_voxcls) { w.knn.voxcls = nullptr; w.knn.voxmask = nullptr; }
     else if (launch_knn_voxel_class(a, w, side)) return 1;
     INVR_HIP(hipEventRecord(ev_join, side));
     {
         ProfStage ps(INVR_STAGE_CULL, st);
-        INVR_HIP(hipMemsetAsync(w.counters, 0, CNT_LEN * sizeof(int32_t), st));
-        if (launch_cull(a, w, max_active, st)) return 1;
+        if (launch_cull(a, w, max_active, have_cells, st)) return 1;
     }
     INVR_HIP(hipStreamWaitEvent(st, ev_join, 0));        // join
     {

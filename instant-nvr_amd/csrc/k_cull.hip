@@ -18,9 +18,13 @@
 // corners of its cell (weights in [0,1], sum 1 within 4e-7), so a cell whose corners are all >= thresh*(1+1e-5)
 // cannot hold a survivor — 93 % of the samples of the bench frame then skip the 8 taps.  Cell (x0,y0,z0) pairs
 // with corner x1 = min(x0+1, dx-1) exactly as the border-clamped sampler does, so there are dx*dy*dz cells.
-__global__ void k_cull_cells(VolDev v, float thresh_hi, uint8_t* __restrict__ mask) {
+// The live cells are also appended to a list (wave-aggregated: one atomic per wave), which the KNN's per-cell classification
+// (k_knn_voxel_class, side stream) walks instead of the whole lattice.
+__global__ void k_cull_cells(VolDev v, float thresh_hi, uint8_t* __restrict__ mask, int32_t* __restrict__ live, int32_t* __restrict__ n_live) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= v.dx * v.dy * v.dz) return;
+    const bool in = i < v.dx * v.dy * v.dz;
+    bool keep = false;
+    if (in) {
     const int z0 = i % v.dz, y0 = (i / v.dz) % v.dy, x0 = i / (v.dz * v.dy);
     const int x1 = min(x0 + 1, v.dx - 1), y1 = min(y0 + 1, v.dy - 1), z1 = min(z0 + 1, v.dz - 1);
     float m = __builtin_inff();
@@ -32,7 +36,19 @@ __global__ void k_cull_cells(VolDev v, float thresh_hi, uint8_t* __restrict__ ma
         nan = nan || d != d;
         m = fminf(m, d);
     }
-    mask[i] = (m < thresh_hi || nan) ? 1 : 0;
+    keep = m < thresh_hi || nan;
+    mask[i] = keep ? 1 : 0;
+    }
+    if (live) {
+        const unsigned long long b = __ballot(keep);
+        if (b) {
+            const int lane = threadIdx.x & 63;
+            int base = 0;
+            if (lane == __ffsll((long long)b) - 1) base = atomicAdd(n_live, __popcll(b));
+            base = __shfl(base, __ffsll((long long)b) - 1);
+            if (keep) live[base + __popcll(b & ((1ull << lane) - 1ull))] = i;
+        }
+    }
 }
 
 // distance channel of the pose-space volume at (px,py,pz): sample_volume_dev<1> (same arithmetic, bit for bit)
@@ -187,16 +203,25 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_compact(RenderArgs a, Workspace 
     }
 }
 
-int launch_cull(const RenderArgs& a, const Workspace& w, int64_t max_active, hipStream_t st) {
-    int64_t nb = cdiv(a.N, CULL_TILE);
+// cell mask of the cull + list of the live cells (for the KNN's lattice classification); 1 = built
+int launch_cull_cells(const RenderArgs& a, const Workspace& w, hipStream_t st) {
     const VolDev& v = a.scene.pbw;
     const int64_t cells = (int64_t)v.dx * v.dy * v.dz;
     static const bool no_mask = getenv("INVR_NO_CULLMASK") != nullptr;
+    if (cells > CULL_MASK_MAX || cells > VOXMASK_MAX_CELLS || no_mask) return 0;
+    hipLaunchKernelGGL(k_cull_cells, dim3((unsigned)cdiv(cells, 256)), dim3(256), 0, st, v, a.scene.thresh * (1.0f + 1e-5f), w.cullmask,
+                       w.knn.live_cells, w.counters + CNT_LIVE);
+    if (hipGetLastError() != hipSuccess) return 0;
+    return 1;
+}
+
+int launch_cull(const RenderArgs& a, const Workspace& w, int64_t max_active, bool have_cells, hipStream_t st) {
+    int64_t nb = cdiv(a.N, CULL_TILE);
+    const VolDev& v = a.scene.pbw;
+    const int64_t cells = (int64_t)v.dx * v.dy * v.dz;
     const double inv_S = 1.0 / (double)a.S;
     const float lin_step = 1.0f / (float)(a.S - 1);                // linspace01's step, the same IEEE division
-    if (cells <= CULL_MASK_MAX && a.N >= 4 * cells && !no_mask) {        // the mask pays for itself on full frames only
-        hipLaunchKernelGGL(k_cull_cells, dim3((unsigned)cdiv(cells, 256)), dim3(256), 0, st, v, a.scene.thresh * (1.0f + 1e-5f), w.cullmask);
-        INVR_LAUNCH_CHECK();
+    if (have_cells && a.N >= 4 * cells) {        // the mask pays for itself on full frames only
         const bool fast = !a.wpts && !a.jitter && a.N < (1ll << 31) && cells * v.c < (1ll << 31) && a.S >= 2;
         if (fast) hipLaunchKernelGGL((k_cull_flag<true, true>), dim3((unsigned)nb), dim3(CULL_BLOCK), 0, st, a, w, inv_S, lin_step);
         else hipLaunchKernelGGL((k_cull_flag<true, false>), dim3((unsigned)nb), dim3(CULL_BLOCK), 0, st, a, w, inv_S, lin_step);

@@ -581,17 +581,53 @@ __device__ __forceinline__ float level_rowsum(const GridDev& g, const float* __r
     const float* tab;
     if (l >= g.start_hash) {
         tab = rs + g.dense_rows + (int64_t)(l - hstart) * g.T;
+        // (cx * 1) ^ (cy * P1) ^ (cz * P2) in 64 bits (:132-136).  The second corner of an axis is the first + d, d in {0, 1, 2}
+        // (0: both clipped to the same cell; 2: f within half an ulp below an integer, where f + 1.0f rounds up and
+        // trunc(f + 1) = trunc(f) + 2 — the reference's float arithmetic, :116): its product is the first's + d * prime — one
+        // 64-bit multiply per axis instead of two (v_mul_lo/hi_u32 are quarter-rate instructions)
+        const uint64_t hy0 = (uint64_t)(uint32_t)c0y * HASH_P1, hz0 = (uint64_t)(uint32_t)c0z * HASH_P2;
+        const int dy = c1y - c0y, dz = c1z - c0z;
         const uint64_t hx[2] = {(uint64_t)(uint32_t)c0x, (uint64_t)(uint32_t)c1x};
-        const uint64_t hy[2] = {(uint64_t)(uint32_t)c0y * HASH_P1, (uint64_t)(uint32_t)c1y * HASH_P1};
-        const uint64_t hz[2] = {(uint64_t)(uint32_t)c0z * HASH_P2, (uint64_t)(uint32_t)c1z * HASH_P2};
+        const uint64_t hy[2] = {hy0, hy0 + (dy > 0 ? HASH_P1 : 0ull) + (dy > 1 ? HASH_P1 : 0ull)};
+        const uint64_t hz[2] = {hz0, hz0 + (dz > 0 ? HASH_P2 : 0ull) + (dz > 1 ? HASH_P2 : 0ull)};
+        if (g.mod24) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) row[k] = grid_hash_mod(hx[k >> 2] ^ hy[(k >> 1) & 1] ^ hz[k & 1], g);
+            for (int k = 0; k < 8; ++k) row[k] = hash_mod24(hx[k >> 2] ^ hy[(k >> 1) & 1] ^ hz[k & 1], g.mod_k, g.mod_c, (uint32_t)g.T);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) row[k] = grid_hash_mod(hx[k >> 2] ^ hy[(k >> 1) & 1] ^ hz[k & 1], g);
+        }
     } else {
         tab = g.separate_dense ? rs + g.dense_off[l] : rs + (int64_t)l * g.T;
+        // cx*res^2 + cy*res + cz (:124-129) with 24-bit multiplies: a dense level has res^3 <= T < 2^31, so res < 1291 and
+        // cx*res + cy < res^2 < 2^21
         const unsigned ures = (unsigned)res;
+        const unsigned bx0 = __umul24((unsigned)c0x, ures), bx1 = __umul24((unsigned)c1x, ures);
+        const unsigned b00 = __umul24(bx0 + (unsigned)c0y, ures), b01 = __umul24(bx0 + (unsigned)c1y, ures);
+        const unsigned b10 = __umul24(bx1 + (unsigned)c0y, ures), b11 = __umul24(bx1 + (unsigned)c1y, ures);
+        // The two z corners of an (x, y) corner are ADJACENT floats of the row-sum table (row = .. + cz): one 8-byte load of
+        // [z0, z0+1], z0 = min(c0z, res-2), instead of two 4-byte loads — the kernel is bound by the number of vector-memory
+        // requests (L1 line lookups), not by bytes.  c0z is z0 or z0+1; c1z is c0z or c0z+1 (both res-1 when clipped) — or, when f
+        // lies within half an ulp below an integer, c0z+2 (f + 1.0f rounds up, :116): that rare lane reloads its second corner.
+        const unsigned z0 = (unsigned)min(c0z, res - 2);
+        const bool s0 = (unsigned)c0z != z0, s1 = (unsigned)c1z != z0;       // take the second float of the pair
+        const bool far1 = (unsigned)c1z > z0 + 1u;
+        const unsigned bb[4] = {b00, b01, b10, b11};
+        float vv[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
-            row[k] = ((unsigned)((k & 4) ? c1x : c0x) * ures + (unsigned)((k & 2) ? c1y : c0y)) * ures + (unsigned)((k & 1) ? c1z : c0z);
+        for (int j = 0; j < 4; ++j) {
+            float2 pr;
+            __builtin_memcpy(&pr, tab + bb[j] + z0, sizeof(pr));             // 4-byte aligned 8-byte load (global_load_dwordx2)
+            vv[2 * j] = s0 ? pr.y : pr.x;
+            vv[2 * j + 1] = s1 ? pr.y : pr.x;
+            if (far1) vv[2 * j + 1] = tab[bb[j] + (unsigned)c1z];
+        }
+        const float ux = 1.0f - tx, uy = 1.0f - ty, uz = 1.0f - tz;
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)     // weight_k = prod_axis ((1-o) + (2o-1) t)  (:157-158)
+            acc = fmaf(((k & 4) ? tx : ux) * ((k & 2) ? ty : uy) * ((k & 1) ? tz : uz), vv[k], acc);
+        return acc;
     }
     float v[8];
 #pragma unroll

@@ -164,7 +164,9 @@ __device__ __forceinline__ unsigned spread6(unsigned v) {       // 6 bits -> eve
 }
 
 __global__ __launch_bounds__(PREP_T) void k_part_prepare(SceneDev s, KnnIndex ix) {
-    __shared__ unsigned keys[PREP_MAX];
+    extern __shared__ unsigned prep_lds[];                // [keys PREP_MAX | counting-sort output PREP_MAX | 4096 buckets] = 80 KB
+    unsigned* keys = prep_lds;
+    unsigned* sorted = prep_lds + PREP_MAX;
     __shared__ float red[6][PREP_T / 64];
     const int p = blockIdx.x;
     const int len = min((int)s.lengths2[p], PREP_MAX);
@@ -189,9 +191,7 @@ __global__ __launch_bounds__(PREP_T) void k_part_prepare(SceneDev s, KnnIndex ix
 #pragma unroll
         for (int a = 0; a < 3; ++a) { ix.part_aabb[p * 6 + a] = lo[a]; ix.part_aabb[p * 6 + 3 + a] = hi[a]; }
     // 2. Morton keys (6 bits / axis) | original index (13 bits)
-    int n2 = 64;
-    while (n2 < len) n2 <<= 1;
-    for (int j = threadIdx.x; j < n2; j += PREP_T) {
+    for (int j = threadIdx.x; j < len; j += PREP_T) {
         unsigned key = 0xFFFFFFFFu;
         if (j < len) {
             unsigned q[3];
@@ -207,19 +207,53 @@ __global__ __launch_bounds__(PREP_T) void k_part_prepare(SceneDev s, KnnIndex ix
         keys[j] = key;
     }
     __syncthreads();
-    // 3. bitonic sort
-    for (int k = 2; k <= n2; k <<= 1)
-        for (int jj = k >> 1; jj > 0; jj >>= 1) {
-            for (int i = threadIdx.x; i < n2; i += PREP_T) {
-                int l = i ^ jj;
-                if (l > i) {
-                    unsigned a = keys[i], b = keys[l];
-                    bool up = (i & k) == 0;
-                    if ((a > b) == up) { keys[i] = b; keys[l] = a; }
-                }
-            }
-            __syncthreads();
+    // 3. sort by key: counting sort on the 12 leading Morton bits (4096 buckets for <= 8192 vertices: ~1 vertex per bucket),
+    //    then every bucket is put in key order by one thread.  (A 1024-thread bitonic sort of 4096 keys needs 78
+    //    barrier-separated passes: 40 of this kernel's 70 us, and the kernel is the head of the frame's critical path for
+    //    small frames / ray shards.)  The result is the same total order: keys are unique (they end in the vertex index).
+    {
+        unsigned* hist = sorted + PREP_MAX;              // [4096] bucket counts -> start offsets
+        __shared__ int wsum[PREP_T / 64];
+        for (int j = threadIdx.x; j < 4096; j += PREP_T) hist[j] = 0;
+        __syncthreads();
+        for (int j = threadIdx.x; j < len; j += PREP_T) atomicAdd(&hist[keys[j] >> 19], 1u);     // key = morton18 << 13 | index
+        __syncthreads();
+        // exclusive scan of the 4096 counts: 4 per thread, wave scan, block scan
+        unsigned c4[4], tot = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { c4[k] = hist[threadIdx.x * 4 + k]; tot += c4[k]; }
+        unsigned x = tot;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { unsigned y = __shfl_up(x, d); if (lane >= d) x += y; }
+        if (lane == 63) wsum[wv] = (int)x;
+        __syncthreads();
+        unsigned woff = 0;
+        for (int k = 0; k < wv; ++k) woff += (unsigned)wsum[k];
+        unsigned run = woff + x - tot;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { hist[threadIdx.x * 4 + k] = run; run += c4[k]; }
+        __syncthreads();
+        // scatter through per-bucket cursors (the cursor of bucket b ends at the start of bucket b+1)
+        for (int j = threadIdx.x; j < len; j += PREP_T) {
+            const unsigned key = keys[j];
+            sorted[atomicAdd(&hist[key >> 19], 1u)] = key;
         }
+        __syncthreads();
+        // order inside the buckets: thread b owns bucket b = [end(b-1), end(b))
+        for (int b = threadIdx.x; b < 4096; b += PREP_T) {
+            const int lo_b = b ? (int)hist[b - 1] : 0, hi_b = (int)hist[b];
+            for (int i = lo_b + 1; i < hi_b; ++i) {
+                const unsigned key = sorted[i];
+                int q = i - 1;
+                while (q >= lo_b && sorted[q] > key) { sorted[q + 1] = sorted[q]; --q; }
+                sorted[q + 1] = key;
+            }
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < len; j += PREP_T) keys[j] = sorted[j];
+        __syncthreads();
+    }
     // 4. sorted vertices, pair-interleaved {x0,x1,y0,y1} {z0,z1,row0,row1} (packed-fp32 distance math reads
     //    two vertices per register pair), clusters of 64 and their four 16-vertex sub-clusters
     const int64_t voff = (int64_t)p * ix.mpad;
@@ -542,7 +576,7 @@ __global__ void k_append_const_pairs(Workspace w) {
 // (lower bound >= near_hi and some vertex within band_lo) — the same two tests k_knn_pairs applies per point, so a
 // definite cell class is exactly what the per-point classification would conclude; undecided cells (class 0) and
 // points outside the lattice run the per-point cluster loop.  17x fewer cells than survivors on the bench frame.
-__global__ void k_knn_voxel_class(SceneDev s, KnnIndex ix) {
+__global__ __launch_bounds__(128) void k_knn_voxel_class(SceneDev s, KnnIndex ix, const int32_t* __restrict__ n_live_dev) {
     const VolDev& v = s.pbw;
     // cluster {lo, hi, rep} and sub-cluster {lo, hi} records of this block's part, staged once (wave-uniform reads below)
     __shared__ float4 s_cl[(PREP_MAX / 64) * 3];
@@ -553,22 +587,12 @@ __global__ void k_knn_voxel_class(SceneDev s, KnnIndex ix) {
         for (int j = threadIdx.x; j < ncl_p * 8; j += blockDim.x) s_sub[j] = ix.sub[(int64_t)pp * ix.cpad * 8 + j];
     }
     __syncthreads();
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= v.dx * v.dy * v.dz) return;
+    // one thread per (live cell, part): the live cells — a corner below the cull threshold, 7 % of the lattice on the bench
+    // frame; all other cells are never looked up — were listed by k_cull_cells
+    const int n_live = n_live_dev[0];
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_live; e += gridDim.x * blockDim.x) {
+    const int idx = ix.live_cells[e];
     const int z0 = idx % v.dz, y0 = (idx / v.dz) % v.dy, x0 = idx / (v.dz * v.dy);
-    {   // survivors of the cull only exist in cells with a corner below the threshold (the trilinear value is a convex
-        // combination of the corners, k_cull.hip): all other cells are never looked up — 93 % of the lattice on the bench frame
-        const int x1 = min(x0 + 1, v.dx - 1), y1 = min(y0 + 1, v.dy - 1), z1 = min(z0 + 1, v.dz - 1);
-        float m = __builtin_inff();
-        bool nan = false;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float d = v.data[((((int64_t)((k & 4) ? x1 : x0)) * v.dy + ((k & 2) ? y1 : y0)) * v.dz + ((k & 1) ? z1 : z0)) * v.c + (v.c - 1)];
-            nan = nan || d != d;
-            m = fminf(m, d);
-        }
-        if (!(m < s.thresh * (1.0f + 1e-5f) || nan)) return;
-    }
     const int c0[3] = {x0, y0, z0}, dims[3] = {v.dx, v.dy, v.dz};
     float lo[3], hi[3], ce[3], h2 = 0.0f;
 #pragma unroll
@@ -631,14 +655,21 @@ __global__ void k_knn_voxel_class(SceneDev s, KnnIndex ix) {
                     }
                 {   // tighten: the 4th-smallest exact distance among the (up to 48) vertices of those three sub-clusters is still an
                     // upper bound of the 4th-nearest distance from the centre, usually the exact one
-                    const float* svf = reinterpret_cast<const float*>(ix.sverts + (int64_t)p * ix.mpad);
                     float e0 = __builtin_inff(), e1 = e0, e2 = e0, e3 = e0;
                     const int ids[3] = {i0, i1, i2};
                     for (int t3 = 0; t3 < 3; ++t3) {
                         if (ids[t3] < 0) continue;
-                        for (int j = ids[t3] * 16; j < ids[t3] * 16 + 16; ++j) {
-                            const float* q = svf + (j >> 1) * 8 + (j & 1);
-                            const float dx = ce[0] - q[0], dy = ce[1] - q[2], dz = ce[2] - q[4];
+                        // the 16 vertices of the sub-cluster = 8 pair records {x0,x1,y0,y1}{z0,z1,..}: all 16 loads are issued
+                        // before the first use (one L2 round trip per sub-cluster instead of one per vertex)
+                        const float4* rec = ix.sverts + (int64_t)p * ix.mpad + ids[t3] * 16;
+                        float4 ra[8], rb[8];
+#pragma unroll
+                        for (int m = 0; m < 8; ++m) { ra[m] = rec[2 * m]; rb[m] = rec[2 * m + 1]; }
+#pragma unroll
+                        for (int jj = 0; jj < 16; ++jj) {
+                            const float4 A = ra[jj >> 1], B = rb[jj >> 1];
+                            const float vx = (jj & 1) ? A.y : A.x, vy = (jj & 1) ? A.w : A.z, vz = (jj & 1) ? B.y : B.x;
+                            const float dx = ce[0] - vx, dy = ce[1] - vy, dz = ce[2] - vz;
                             const float d = dx * dx + dy * dy + dz * dz;
                             if (d < e3) {
                                 e3 = d;
@@ -666,12 +697,14 @@ __global__ void k_knn_voxel_class(SceneDev s, KnnIndex ix) {
             ix.voxu2[(int64_t)idx * INVR_NUM_PARTS + p] = u2_out;
         }
     }
+    }
 }
 
 int launch_knn_voxel_class(const RenderArgs& a, const Workspace& w, hipStream_t st) {
     const VolDev& v = a.scene.pbw;
     const int64_t cells = (int64_t)v.dx * v.dy * v.dz;
-    hipLaunchKernelGGL(k_knn_voxel_class, dim3((unsigned)cdiv(cells, 256), INVR_NUM_PARTS), dim3(256), 0, st, a.scene, w.knn);
+    hipLaunchKernelGGL(k_knn_voxel_class, dim3((unsigned)(cells / 128 < 1024 ? cdiv(cells, 128) : 1024), INVR_NUM_PARTS), dim3(128), 0, st, a.scene, w.knn,
+                       w.counters + CNT_LIVE);
     INVR_LAUNCH_CHECK();
     return 0;
 }
@@ -679,7 +712,13 @@ int launch_knn_voxel_class(const RenderArgs& a, const Workspace& w, hipStream_t 
 // The per-frame KNN index only depends on the posed vertices, not on the rays: it is built on a side stream
 // beside the cull kernels (fork / join with events — also a valid pattern under hipGraph capture).
 int launch_knn_prepare(const RenderArgs& a, const Workspace& w, hipStream_t st) {
-    hipLaunchKernelGGL(k_part_prepare, dim3(INVR_NUM_PARTS), dim3(PREP_T), 0, st, a.scene, w.knn);
+    const size_t lds_bytes = (size_t)(2 * PREP_MAX + 4096) * sizeof(unsigned);
+    static bool attr_set = false;
+    if (!attr_set) {
+        INVR_HIP(hipFuncSetAttribute((const void*)k_part_prepare, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_part_prepare, dim3(INVR_NUM_PARTS), dim3(PREP_T), lds_bytes, st, a.scene, w.knn);
     INVR_LAUNCH_CHECK();
     return 0;
 }

@@ -19,6 +19,17 @@
 
 #include "mlp_common.h"
 
+// compile-time ablations for profiling experiments (tools/mlp_ablate.sh): 1 no activations, 2 no MFMA, 3 no LDS weight reads
+#ifndef MLP_DBG
+#define MLP_DBG 0
+#endif
+#if MLP_DBG == 2
+#define mfma4(a, b, c) ((c) + (f32x4){(a) * (b), 0.f, 0.f, 0.f})
+#endif
+#if MLP_DBG == 1
+#define softplus4_log2(v) (v)
+#endif
+
 // One 16-pair column block of a wave: inputs, activations and outputs stay in registers from the embedding to [rgb, occ].
 struct MlpCol {
     float eb[EMB_STEPS];        // k-slots 4s+g of the (padded) 20-wide embedding of pair `col`
@@ -37,9 +48,11 @@ __device__ __forceinline__ void st_occ1(const float* lds, int lane, int g, MlpCo
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) c.h[mt] = bias4(lds + O_B_OCC1, mt, g);
 #pragma unroll
-    for (int s = 0; s < EMB_STEPS; ++s)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) c.h[mt] = mfma4(lds[O_W_OCC1 + (s * 4 + mt) * 64 + lane], c.eb[s], c.h[mt]);
+    for (int s = 0; s < EMB_STEPS; ++s) {
+        const float4 a = *reinterpret_cast<const float4*>(lds + O_W_OCC1 + (s * 64 + lane) * 4);
+        c.h[0] = mfma4(a.x, c.eb[s], c.h[0]); c.h[1] = mfma4(a.y, c.eb[s], c.h[1]);
+        c.h[2] = mfma4(a.z, c.eb[s], c.h[2]); c.h[3] = mfma4(a.w, c.eb[s], c.h[3]);
+    }
 }
 __device__ __forceinline__ void st_act(MlpCol& c) {
 #pragma unroll
@@ -48,7 +61,11 @@ __device__ __forceinline__ void st_act(MlpCol& c) {
 __device__ __forceinline__ void st_occ2(const float* lds, int lane, int g, MlpCol& c) {       // features 1..16 on MFMA, logit 0 on VALU
     c.feat = bias4(lds + O_B_OCC2, 0, g);
 #pragma unroll
-    for (int s = 0; s < 16; ++s) c.feat = mfma4(lds[O_W_OCC2 + s * 64 + lane], c.h[s >> 2][s & 3], c.feat);
+    for (int q = 0; q < 4; ++q) {
+        const float4 a = *reinterpret_cast<const float4*>(lds + O_W_OCC2 + (q * 64 + lane) * 4);
+        c.feat = mfma4(a.x, c.h[q][0], c.feat); c.feat = mfma4(a.y, c.h[q][1], c.feat);
+        c.feat = mfma4(a.z, c.h[q][2], c.feat); c.feat = mfma4(a.w, c.h[q][3], c.feat);
+    }
     const float lg = head_dot_s(c.h, lds + O_V_OCC, g) + lds[O_V_OCC + 64];
     c.occ = one_minus_exp_neg(softplus_f(lg));                    // 1 - exp(-softplus(h0))  (:52)
 }
@@ -70,19 +87,24 @@ __device__ __forceinline__ void st_rgb1(const float* lds, int lane, int g, MlpCo
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) c.h[mt] = bias4(lds + O_B_RGB1, mt, g);
 #pragma unroll
-    for (int s = 0; s < RGB1_STEPS; ++s)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-            c.h[mt] = mfma4(lds[O_W_RGB1 + (s * 4 + mt) * 64 + lane], s < EMB_STEPS ? c.eb[s < EMB_STEPS ? s : 0] : c.k5[s >= EMB_STEPS ? s - EMB_STEPS : 0], c.h[mt]);
+    for (int s = 0; s < RGB1_STEPS; ++s) {
+        const float4 a = *reinterpret_cast<const float4*>(lds + O_W_RGB1 + (s * 64 + lane) * 4);
+        const float b = s < EMB_STEPS ? c.eb[s < EMB_STEPS ? s : 0] : c.k5[s >= EMB_STEPS ? s - EMB_STEPS : 0];
+        c.h[0] = mfma4(a.x, b, c.h[0]); c.h[1] = mfma4(a.y, b, c.h[1]);
+        c.h[2] = mfma4(a.z, b, c.h[2]); c.h[3] = mfma4(a.w, b, c.h[3]);
+    }
 }
 __device__ __forceinline__ void st_rgb2(const float* lds, int lane, int g, MlpCol& c) {
     f32x4 h2[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) h2[mt] = bias4(lds + O_B_RGB2, mt, g);
 #pragma unroll
-    for (int s = 0; s < 16; ++s)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) h2[mt] = mfma4(lds[O_W_RGB2 + (s * 4 + mt) * 64 + lane], c.h[s >> 2][s & 3], h2[mt]);
+    for (int s = 0; s < 16; ++s) {
+        const float4 a = *reinterpret_cast<const float4*>(lds + O_W_RGB2 + (s * 64 + lane) * 4);
+        const float b = c.h[s >> 2][s & 3];
+        h2[0] = mfma4(a.x, b, h2[0]); h2[1] = mfma4(a.y, b, h2[1]);
+        h2[2] = mfma4(a.z, b, h2[2]); h2[3] = mfma4(a.w, b, h2[3]);
+    }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) c.h[mt] = h2[mt];
 }
@@ -196,14 +218,14 @@ __global__ __launch_bounds__(MLP_BLOCK, 3) void k_part_mlp(PartMlpDev pm, const 
                                                         const int32_t* __restrict__ l_slot,
                                                         const int32_t* __restrict__ count, int64_t cap,
                                                         float4* __restrict__ raws, int part, float4* __restrict__ raw_direct) {
-    __shared__ float lds[LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     mlp_part<NRGB>(lds, pm, emb, ds, stride, l_slot, *count, cap, raws, part, raw_direct);
 }
 
 // all five parts in one persistent launch (see k_part_encode_rs_all): the weights of the next part are staged
 // into the same LDS image when a workgroup has finished its share of the previous one
 __global__ __launch_bounds__(MLP_BLOCK, 3) void k_part_mlp_all(MlpAllArgs a) {
-    __shared__ float lds[LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     for (int p = 0; p < INVR_NUM_PARTS; ++p) {
         if (a.pm[p].rgb.n_linear == 3)
             mlp_part<3>(lds, a.pm[p], a.emb[p], a.ds[p], a.stride, a.l_slot[p], a.counts[p], a.cap, a.raws, p, nullptr);

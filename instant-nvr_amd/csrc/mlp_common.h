@@ -36,7 +36,9 @@ __device__ __forceinline__ int rgb1_col(int s, int g) {
 // hidden unit held by lane group g for k-step s of a 64-wide hidden layer
 __device__ __forceinline__ int hid_col(int s, int g) { return 16 * (s >> 2) + 4 * g + (s & 3); }
 
-// LOG2DOM (forward-only kernels): the hidden activations are kept in the log2 domain, u = log2(1 + exp2(z log2e)) = softplus(z) /
+// LOG2DOM (forward-only kernels): the four m-tile weights of a k-step sit next to each other per lane ([k-step][lane][m-tile];
+// occ layer 2, one m-tile: four k-steps), so ONE ds_read_b128 feeds four MFMAs — LDS instructions take issue slots like VALU
+// does, and the SIMD's issue is what bounds these kernels.  The hidden activations are kept in the log2 domain, u = log2(1 + exp2(z log2e)) = softplus(z) /
 // ln2, and the two scale factors are folded into the staged weights — a layer that feeds a Softplus is scaled by log2e (weights
 // and bias), a layer that consumes Softplus outputs by ln2; for a hidden-to-hidden layer the two cancel exactly (only its bias is
 // scaled).  The activation then costs {min, exp2, add, log2} = 4 single-issue VALU per value instead of 4.5 issue slots with packed
@@ -49,21 +51,21 @@ __device__ void stage_weights(const PartMlpDev& pm, float* lds) {
     for (int t = threadIdx.x; t < EMB_STEPS * 4 * 64; t += MLP_BLOCK) {
         int ln = t & 63, mt = (t >> 6) & 3, s = t >> 8, g = ln >> 4, i = ln & 15;
         int col = 4 * s + g;
-        lds[O_W_OCC1 + t] = col < 19 ? W0[(16 * mt + i) * 19 + col] * s_in : 0.0f;
+        lds[O_W_OCC1 + (LOG2DOM ? (s * 64 + ln) * 4 + mt : t)] = col < 19 ? W0[(16 * mt + i) * 19 + col] * s_in : 0.0f;
     }
     for (int t = threadIdx.x; t < 16 * 64; t += MLP_BLOCK) {
         int ln = t & 63, s = t >> 6, g = ln >> 4, i = ln & 15;
-        lds[O_W_OCC2 + t] = W1[(1 + i) * HID + hid_col(s, g)] * s_out;
+        lds[O_W_OCC2 + (LOG2DOM ? ((s >> 2) * 64 + ln) * 4 + (s & 3) : t)] = W1[(1 + i) * HID + hid_col(s, g)] * s_out;
     }
     for (int t = threadIdx.x; t < RGB1_STEPS * 4 * 64; t += MLP_BLOCK) {
         int ln = t & 63, mt = (t >> 6) & 3, s = t >> 8, g = ln >> 4, i = ln & 15;
         int col = rgb1_col(s, g);
-        lds[O_W_RGB1 + t] = col >= 0 ? R0[(16 * mt + i) * 70 + col] * s_in : 0.0f;
+        lds[O_W_RGB1 + (LOG2DOM ? (s * 64 + ln) * 4 + mt : t)] = col >= 0 ? R0[(16 * mt + i) * 70 + col] * s_in : 0.0f;
     }
     if (NRGB == 3)
         for (int t = threadIdx.x; t < 16 * 4 * 64; t += MLP_BLOCK) {
             int ln = t & 63, mt = (t >> 6) & 3, s = t >> 8, g = ln >> 4, i = ln & 15;
-            lds[O_W_RGB2 + t] = R1[(16 * mt + i) * HID + hid_col(s, g)];
+            lds[O_W_RGB2 + (LOG2DOM ? (s * 64 + ln) * 4 + mt : t)] = R1[(16 * mt + i) * HID + hid_col(s, g)];
         }
     for (int t = threadIdx.x; t < 64; t += MLP_BLOCK) {
         lds[O_B_OCC1 + t] = pm.occ.b[0][t] * s_in;

@@ -3,7 +3,8 @@
 #include "common.h"
 
 enum { CNT_ACTIVE = 0, CNT_PAIRS = 1 /* ..5 */, CNT_OVERFLOW = 6, CNT_FAR = 7 /* ..11 */, CNT_TICKET = 12,
-       CNT_NB = 13 /* selected pair-regulariser rows */, CNT_DTOT = 14 /* entries of the deformer backward list */, CNT_LEN = 16 };
+       CNT_NB = 13 /* selected pair-regulariser rows */, CNT_DTOT = 14 /* entries of the deformer backward list */,
+       CNT_LIVE = 15 /* lattice cells that can hold a survivor */, CNT_LEN = 16 };
 
 #define CULL_MASK_MAX (4 << 20)   // cells of the per-frame cull mask (bytes); larger distance volumes run unmasked
 #define VOXMASK_MAX_CELLS (1 << 20)  // lattice cells with per-part candidate-cluster masks (40 B each)
@@ -36,6 +37,7 @@ struct KnnIndex {
                          //            point of the cell (undecided cells of parts with <= 64 clusters; all ones otherwise); NULL = off
     float* voxu2;        // per (lattice cell, part): squared upper bound of the 4th-nearest distance of any point of the cell
     uint8_t* voxcls;     // per (lattice cell, part): 0 undecided, 1 far, 2 unflagged; NULL = off
+    int32_t* live_cells; // lattice cells with a corner below the cull threshold (k_cull_cells; count in counters[CNT_LIVE])
     float4* vmat;        // P*mpad*6 : per vertex, rows 0..2 of sum_j pbw[v][j] A_j and of sum_j pbw[v][j] big_A_j
     int32_t mpad, cpad;
 };
@@ -113,7 +115,8 @@ __device__ __forceinline__ void sample_pose_point(const RenderArgs& a, int64_t i
 }
 
 // ---- pipeline stage launchers ------------------------------------------------------------------
-int launch_cull(const RenderArgs& a, const Workspace& w, int64_t max_active, hipStream_t st);
+int launch_cull_cells(const RenderArgs& a, const Workspace& w, hipStream_t st);      // -> 1 if the cell mask / live list were built
+int launch_cull(const RenderArgs& a, const Workspace& w, int64_t max_active, bool have_cells, hipStream_t st);
 int launch_pose_points(const RenderArgs& a, const int32_t* idx, int64_t n, float* pts, float* dirs, hipStream_t st);
 int launch_knn_prepare(const RenderArgs& a, const Workspace& w, hipStream_t st);
 int launch_vertex_mats(const RenderArgs& a, const Workspace& w, hipStream_t st);

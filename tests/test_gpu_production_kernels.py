@@ -187,6 +187,25 @@ def test_row_sum_xcd_encoder_vs_oracle_real_tables(fr):
     model = O.Model(sd, f['cfg'])
     total, inside_total = 0, 0
     g = torch.Generator().manual_seed(7 + k)
+    # (1) EVERY listed pair of the frame against the generic thread-per-point encoder on the 64-byte rows (invr_grid_encode_fwd,
+    #     pinned to the reference goldens by test_grid_encoder_variants): catches rare index-arithmetic cases a sample misses
+    for p in range(5):
+        cnt = int(st[1 + p])
+        e = net.tpose_human.part_networks[p].embedder
+        x_all = v['l_x'][p][:, :cnt].t().contiguous()
+        ref_all = e(x_all)                                                  # (cnt, 19)
+        got_all = v['emb'][p][:19, :cnt].t()
+        xn = ref_all[:, :3]
+        oob = torch.clamp(torch.maximum(-xn, xn - 1.0), min=0.0)            # encoder_tolerance on the device
+        res_t = torch.tensor(model.pspec[p]['res'], device=DEV, dtype=torch.float32)
+        tol_all = 1.2e-5 * torch.prod(1.0 + 2.0 * oob[:, None, :] * (res_t[None, :, None] - 1), dim=-1)
+        bad = ((got_all[:, 3:] - ref_all[:, 3:]).abs() > tol_all)
+        if bool(bad.any()):
+            i, l = [int(t[0]) for t in bad.nonzero(as_tuple=True)]
+            raise AssertionError('pose %d part %d: %d mismatching (pair, level) entries of %d pairs; first: pair %d level %d x_norm %s got %r ref %r'
+                                 % (k, p, int(bad.sum()), cnt, i, l, xn[i].tolist(), float(got_all[i, 3 + l]), float(ref_all[i, 3 + l])))
+        assert float((got_all[:, :3] - xn).abs().max()) < 1e-6
+    # (2) a sample against the oracle on the CPU
     for p in range(5):
         cnt = int(st[1 + p])                                  # incl. the far-constant pair (canonical origin, far outside most boxes)
         take = min(cnt, 25000)
