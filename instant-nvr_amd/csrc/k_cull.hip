@@ -20,7 +20,8 @@
 // with corner x1 = min(x0+1, dx-1) exactly as the border-clamped sampler does, so there are dx*dy*dz cells.
 // The live cells are also appended to a list (wave-aggregated: one atomic per wave), which the KNN's per-cell classification
 // (k_knn_voxel_class, side stream) walks instead of the whole lattice.
-__global__ void k_cull_cells(VolDev v, float thresh_hi, uint8_t* __restrict__ mask, int32_t* __restrict__ live, int32_t* __restrict__ n_live) {
+__global__ void k_cull_cells(VolDev v, float thresh_hi, uint8_t* __restrict__ mask, int32_t* __restrict__ live, int32_t* __restrict__ n_live,
+                             uint8_t* __restrict__ voxcls) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool in = i < v.dx * v.dy * v.dz;
     bool keep = false;
@@ -47,6 +48,12 @@ __global__ void k_cull_cells(VolDev v, float thresh_hi, uint8_t* __restrict__ ma
             if (lane == __ffsll((long long)b) - 1) base = atomicAdd(n_live, __popcll(b));
             base = __shfl(base, __ffsll((long long)b) - 1);
             if (keep) live[base + __popcll(b & ((1ull << lane) - 1ull))] = i;
+        }
+        // class "undecided" for every cell: k_knn_pairs maps a point to its cell with slightly different arithmetic than the
+        // sampler, so a survivor on a cell face may look up a neighbour that is not live — and is never classified
+        if (in && voxcls) {
+#pragma unroll
+            for (int p = 0; p < INVR_NUM_PARTS; ++p) voxcls[(int64_t)i * INVR_NUM_PARTS + p] = 0;
         }
     }
 }
@@ -210,7 +217,7 @@ int launch_cull_cells(const RenderArgs& a, const Workspace& w, hipStream_t st) {
     static const bool no_mask = getenv("INVR_NO_CULLMASK") != nullptr;
     if (cells > CULL_MASK_MAX || cells > VOXMASK_MAX_CELLS || no_mask) return 0;
     hipLaunchKernelGGL(k_cull_cells, dim3((unsigned)cdiv(cells, 256)), dim3(256), 0, st, v, a.scene.thresh * (1.0f + 1e-5f), w.cullmask,
-                       w.knn.live_cells, w.counters + CNT_LIVE);
+                       w.knn.live_cells, w.counters + CNT_LIVE, w.knn.voxcls);
     if (hipGetLastError() != hipSuccess) return 0;
     return 1;
 }

@@ -368,8 +368,8 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w, 
             L.voff[p] = off;
             off += (L.len[p] + 63) / 64 * 64;
         }
-        if (off > KNN_LDS_MAX_V) {                       // does not fit the LDS-resident design
-            if (threadIdx.x == 0 && blockIdx.x == 0) w.counters[CNT_OVERFLOW] = 2;
+        if (off > KNN_LDS_MAX_V) {                       // does not fit the LDS-resident design: k_knn_pairs_bf takes the frame
+            if (threadIdx.x == 0 && blockIdx.x == 0) w.counters[CNT_TICKET] = -1;
             return;
         }
         for (int p = 0; p < INVR_NUM_PARTS; ++p) { L.coff[p] = off; off += (L.len[p] + 63) / 64 * 3; }
@@ -557,6 +557,70 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w, 
     }
 }
 
+// Fallback when the posed vertex sets of the five parts do not fit the LDS-resident index together (> 8192 vertex slots, e.g.
+// SMPL-X): brute force per (survivor, part) over LDS tiles of the part's vertices — the arithmetic of k_knn_dense, the outputs of
+// k_knn_pairs (far pairs by the exact nearest distance > 0.68 m, flagged pairs listed).  Runs only when k_knn_pairs left the
+// "does not fit" mark in the ticket counter; otherwise every workgroup exits at once.
+__global__ __launch_bounds__(KNN_BLOCK) void k_knn_pairs_bf(RenderArgs a, Workspace w) {
+    if (w.counters[CNT_TICKET] != -1) return;
+    __shared__ float4 sv[KNN_TILE];
+    const int na = w.counters[CNT_ACTIVE];
+    const int lane = threadIdx.x & 63;
+    for (int64_t tile = blockIdx.x; tile * KNN_BLOCK < na; tile += gridDim.x) {
+        const int64_t slot = tile * KNN_BLOCK + threadIdx.x;
+        const bool live = slot < na;
+        float px = 0, py = 0, pz = 0;
+        if (live) sample_pose_point(a, w.active_idx[slot], px, py, pz, nullptr, nullptr);
+        unsigned flags = 0, farflags = 0;
+        for (int p = 0; p < INVR_NUM_PARTS; ++p) {
+            const int len = (int)a.scene.lengths2[p];
+            if (len < KNN_K) continue;
+            const float* verts = a.scene.part_pts + (int64_t)p * a.scene.M * 3;
+            Top4 t;
+            t.init();
+            for (int base = 0; base < len; base += KNN_TILE) {
+                const int m = min(KNN_TILE, len - base);
+                __syncthreads();
+                for (int j = threadIdx.x; j < m; j += KNN_BLOCK) {
+                    const float* v = verts + (int64_t)(base + j) * 3;
+                    sv[j] = make_float4(v[0], v[1], v[2], 0.0f);
+                }
+                __syncthreads();
+#pragma unroll 4
+                for (int j = 0; j < m; ++j) {
+                    const float4 v = sv[j];
+                    const float dx = px - v.x, dy = py - v.y, dz = pz - v.z;
+                    t.push(dx * dx + dy * dy + dz * dz, base + j);
+                }
+            }
+            t.finish();
+            float wt[KNN_K];
+            const float ds = knn_weights(t, wt);
+            const bool far = live && t.d[0] > KNN_DFAR2;
+            const bool hit = live && !far && ds < a.scene.thresh;
+            if (far) farflags |= 1u << p;
+            const unsigned long long hb = __ballot(hit), fb = __ballot(far);
+            int base_pos = 0;
+            if (lane == 0) {
+                if (hb) base_pos = atomicAdd(&w.counters[CNT_PAIRS + p], __popcll(hb));
+                if (fb) atomicAdd(&w.counters[CNT_FAR + p], __popcll(fb));
+            }
+            base_pos = __shfl(base_pos, 0);
+            if (hit) {
+                flags |= 1u << p;
+                const int64_t pos = base_pos + __popcll(hb & ((1ull << lane) - 1ull));
+                w.l_slot[p][pos] = (int32_t)slot;
+                reinterpret_cast<int4*>(w.l_nn[p])[pos] = make_int4(t.i[0], t.i[1], t.i[2], t.i[3]);
+                reinterpret_cast<float4*>(w.l_w[p])[pos] = make_float4(wt[0], wt[1], wt[2], wt[3]);
+            }
+        }
+        if (live) {
+            w.pflags[slot] = (uint8_t)flags;
+            w.farflags[slot] = (uint8_t)farflags;
+        }
+    }
+}
+
 // one zero-weight pair per part, appended behind the real pairs: its field value is the constant
 // every far pair of that part takes (see the header comment).  It lives in the extra slot `cap`.
 __global__ void k_append_const_pairs(Workspace w) {
@@ -735,6 +799,11 @@ int launch_knn_pairs(const RenderArgs& a, const Workspace& w, hipStream_t st) {
     static int dbg = getenv("INVR_KNN_DBG") ? atoi(getenv("INVR_KNN_DBG")) : 0;
     hipLaunchKernelGGL(k_knn_pairs, dim3(grid), dim3(KNN_T), lds_bytes, st, a, w, dbg);
     INVR_LAUNCH_CHECK();
+    if (a.scene.M * (int64_t)INVR_NUM_PARTS > KNN_LDS_MAX_V) {      // the five parts may not fit the LDS index together: fallback armed
+        int64_t bt = cdiv(w.cap, KNN_BLOCK);
+        hipLaunchKernelGGL(k_knn_pairs_bf, dim3((unsigned)(bt < 2048 ? (bt > 0 ? bt : 1) : 2048)), dim3(KNN_BLOCK), 0, st, a, w);
+        INVR_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(k_append_const_pairs, dim3(1), dim3(64), 0, st, w);
     INVR_LAUNCH_CHECK();
     return 0;

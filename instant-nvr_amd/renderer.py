@@ -65,8 +65,7 @@ class Renderer:
             else:
                 st = None                                   # asynchronous caller: check last_stats[6] yourself
             if st is not None and int(st[6]) != 0:
-                raise RuntimeError('invr_render_fwd reported stats[6] = %d: %s' % (int(st[6]), 'the posed vertex set does not fit the '
-                                   'LDS-resident KNN index (8192 vertex slots)' if int(st[6]) == 2 else 'workspace overflow'))
+                raise RuntimeError('invr_render_fwd reported stats[6] = %d: workspace overflow' % int(st[6]))
             outs.append(out)
         cat = (lambda k: outs[0][k]) if len(outs) == 1 else (lambda k: torch.cat([o[k] for o in outs], 0))
         ret = {'rgb_map': cat('rgb_map')[None], 'acc_map': cat('acc_map')[None]}

@@ -586,6 +586,49 @@ def test_render_config_variants_vs_oracle(small_setup, over):
     assert float(err_gpu.median()) < 5e-6
 
 
+def test_knn_fallback_when_vertex_sets_exceed_lds_index(small_setup):
+    """More posed vertices than the LDS-resident KNN index holds (8192 slots over the five parts; SMPL has 6890, SMPL-X 10475):
+    the render falls back to the brute-force pair kernel (k_knn_pairs_bf) on the device, without a host decision.  The per-part
+    reference sets are doubled with slightly displaced copies (13780 vertices, largest part 7378) and the render is checked against
+    the oracle like every other scene."""
+    from invr.config import make_cfg
+    _, _, batch, _ = small_setup
+    cfg = make_cfg(table_log2=12, N_samples=24)
+    sd = params.init_state_dict(cfg, seed=13)
+    b = dict(batch)
+    pp, pw, l2 = batch['part_pts'][0], batch['part_pbw'][0], batch['lengths2'][0]
+    M = int(l2.max())
+    g = torch.Generator().manual_seed(2)
+    npp, npw = torch.zeros(5, 2 * M, 3), torch.zeros(5, 2 * M, 24)
+    for p in range(5):
+        n = int(l2[p])
+        npp[p, :n], npw[p, :n] = pp[p, :n], pw[p, :n]
+        npp[p, n:2 * n] = pp[p, :n] + (torch.rand(n, 3, generator=g) - 0.5) * 2e-3
+        npw[p, n:2 * n] = pw[p, :n]
+    b['part_pts'], b['part_pbw'], b['lengths2'] = npp[None], npw[None], (2 * l2)[None]
+    assert int(b['lengths2'].sum()) > 8192 and 2 * M <= 8192
+    sel = torch.arange(0, batch['ray_o'].shape[1], 9)
+    for k in ('ray_o', 'ray_d', 'near', 'far'):
+        b[k] = batch[k][:, sel]
+    net = Network(cfg=cfg)
+    net.load_state_dict(sd, strict=True)
+    net = net.to(DEV).eval()
+    r = Renderer(net)
+    ret = r.render({k: v.to(DEV) for k, v in b.items()})
+    assert int(r.last_stats[6]) == 0
+    with torch.no_grad():
+        ref = O.render(O.Model(sd, cfg), b)
+        sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+        b64 = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in b.items()}
+        exact = O.render(O.Model(sd64, cfg), b64)['rgb_map'][0]
+    assert ((ret['raw'][0, :, 3] != 0) == (ref['raw'][0, :, 3] != 0)).all()
+    assert int((ref['raw'][0, :, 3] != 0).sum()) > 100
+    err_gpu = (ret['rgb_map'][0].double() - exact).abs().max(1)[0]
+    err_ref = (ref['rgb_map'][0].double() - exact).abs().max(1)[0]
+    assert bool((err_gpu <= 1e-4 + 4 * err_ref).all()), (float(err_gpu.max()), float(err_ref.max()))
+    assert float(err_gpu.median()) < 5e-6
+
+
 def test_tpose_viewdir_false_is_rejected(gpu_setup):
     """cfg.tpose_viewdir=False cannot run in the reference either (TPoseHuman.forward indexes the (Na,3)
     view-dir tensor per part, inb_part_network_multiassign.py:216); the library reports it instead of
