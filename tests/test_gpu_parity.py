@@ -685,6 +685,13 @@ def test_scene_prep_on_device(small_setup):
     assert torch.equal(l2.cpu(), batch['lengths2'][0])
     assert torch.equal(pp.cpu(), batch['part_pts'][0]) and torch.equal(pb.cpu(), batch['part_pbw'][0])
     assert torch.equal(bd.cpu(), batch['bounds'][0])
+    # and against the reference's own inline code (tpose_dataset.py:569-591, executed by tests/golden/make_golden_parts.py)
+    from tests.test_oracle_golden import parts_inputs, check_parts_against_golden
+    gp = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'parts_small.npz'))
+    for tag, seed in (('a', 0), ('b', 7)):
+        ppts, weights, parts, tpose = parts_inputs(seed)
+        pp, pb, l2, bd = prep.pack_parts(cu(ppts), cu(weights), cu(parts), cu(tpose), float(gp[tag + '_overlap']))
+        check_parts_against_golden(tag, pp.cpu().numpy(), pb.cpu().numpy(), l2.cpu().numpy(), bd.cpu().numpy(), gp)
 
 
 def test_pair_deformer_matches_point_deformer(gpu_setup):

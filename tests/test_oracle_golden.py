@@ -149,3 +149,56 @@ def test_train_mode_forward(golden, small_setup):
     close(r['resd'].reshape(1, -1, 3), golden['train_resd'])
     close(r['tocc'].reshape(1, -1, 1), golden['train_tocc'], 5e-6)
     close(O.distortion_loss(r['weights'], r['z'])[None], golden['train_reg_distortion_loss'], 5e-6)
+
+
+def parts_inputs(seed):
+    """Inputs of tests/golden/make_golden_parts.py, regenerated from the seed."""
+    from invr import scene
+    tverts, weights, parts, _ = scene.make_body(seed)
+    rng = np.random.RandomState(seed + 5)
+    poses = rng.uniform(-1, 1, (24, 3)) * 0.4
+    poses[0] = 0
+    A = scene.rigid_transformation(poses, scene._J, scene.PARENTS)
+    big = np.zeros(72); big[5] = np.deg2rad(30); big[8] = np.deg2rad(-30)
+    ppts = scene.lbs(tverts, weights, A)
+    tpose = scene.lbs(tverts, weights, scene.rigid_transformation(big.reshape(24, 3), scene._J, scene.PARENTS))
+    return ppts, weights, parts.astype(np.int64), tpose
+
+
+def digest(v):
+    v = np.asarray(v, np.float64)
+    return np.array([v.sum(), np.abs(v).sum(), (v * (np.arange(v.size).reshape(v.shape) % 97)).sum()])
+
+
+def check_parts_against_golden(tag, part_pts, part_pbw, lengths2, bounds, g):
+    """Per-part packing results against the reference's own lines (tpose_dataset.py:569-591; parts_small.npz stores digests of
+    the large arrays + 50 sampled rows + the small arrays in full)."""
+    assert np.array_equal(np.asarray(lengths2), g[tag + '_lengths2'])
+    assert np.array_equal(np.asarray(bounds), g[tag + '_bounds'])
+    for name, arr in (('part_pts', part_pts), ('part_pbw', part_pbw)):
+        arr = np.asarray(arr)
+        assert tuple(arr.shape) == tuple(g[tag + '_' + name + '_shape'])
+        assert np.array_equal(digest(arr), g[tag + '_' + name]), name
+        flat = arr.reshape(-1, arr.shape[-1])
+        assert np.array_equal(flat[:: max(1, flat.shape[0] // 50)][:50], g[tag + '_' + name + '_rows'])
+
+
+def test_part_packing_restatement_vs_reference_lines():
+    """invr.scene's per-part KNN reference sets (what every synthetic batch is built with) against the reference's inline code."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'parts_small.npz'))
+    for tag, seed in (('a', 0), ('b', 7)):
+        ppts, weights, parts, tpose = parts_inputs(seed)
+        overlap = float(g[tag + '_overlap'])
+        P, N = 5, ppts.shape[0]
+        part_pts = np.zeros((P, N, 3), np.float32); part_pbw = np.zeros((P, N, 24), np.float32)
+        lengths2 = np.zeros(P, np.int64); bounds = np.zeros((P, 2, 3), np.float32)
+        for pid in range(P):
+            f = parts == pid
+            lengths2[pid] = f.sum()
+            part_pts[pid, :lengths2[pid]] = ppts[f]
+            part_pbw[pid, :lengths2[pid]] = weights[f]
+            bounds[pid, 0] = tpose[f].min(0) - np.float32(overlap)
+            bounds[pid, 1] = tpose[f].max(0) + np.float32(overlap)
+        M = int(lengths2.max())
+        check_parts_against_golden(tag, part_pts[:, :M], part_pbw[:, :M], lengths2, bounds, g)
