@@ -180,7 +180,9 @@ static size_t carve(Workspace& w, void* base, int64_t N, int64_t cap) {
     w.cap = cap;
     const int64_t lc = cap + 1;          // list / slot capacity incl. the far-constant entry
     w.lcap = lc;
-    w.counters = c.take<int32_t>(CNT_LEN);
+    w.n_groups = cdiv(lc, PAIR_GROUP);
+    w.counters = c.take<int32_t>(CNT_ALLOC + (size_t)w.n_groups * INVR_NUM_PARTS);
+    w.gcount = w.counters ? w.counters + CNT_ALLOC : nullptr;
     w.knn.part_aabb = c.take<float>(INVR_NUM_PARTS * 6);
     w.knn.mpad = KNN_MAX_PART;
     w.knn.cpad = KNN_MAX_PART / 64;
@@ -295,7 +297,7 @@ static int render_impl(const InvrScene* scene, const InvrModel* model,
     a.R = n_rays; a.S = n_samples; a.N = N;
 
     // fork: KNN index build (k_part_prepare, 5 workgroups, ~60 us) on a side stream beside the cull kernels
-    struct SideStream { hipStream_t side = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+    struct SideStream { hipStream_t side = nullptr; hipEvent_t fork = nullptr, join = nullptr, join2 = nullptr; };
     static thread_local std::vector<SideStream> side_of_device;   // one per device this thread renders on (CPX mode: up to 64)
     int dev_id = 0;
     INVR_HIP(hipGetDevice(&dev_id));
@@ -306,24 +308,28 @@ static int render_impl(const InvrScene* scene, const InvrModel* model,
         INVR_HIP(hipStreamCreateWithFlags(&ss.side, hipStreamNonBlocking));
         INVR_HIP(hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming));
         INVR_HIP(hipEventCreateWithFlags(&ss.join, hipEventDisableTiming));
+        INVR_HIP(hipEventCreateWithFlags(&ss.join2, hipEventDisableTiming));
     }
     hipStream_t side = ss.side;
-    hipEvent_t ev_fork = ss.fork, ev_join = ss.join;
+    hipEvent_t ev_fork = ss.fork, ev_join = ss.join, ev_join2 = ss.join2;
     // cell mask of the distance volume + list of the cells that can hold a survivor (a few us): feeds both the cull (this
     // stream) and the KNN's lattice classification (side stream)
-    INVR_HIP(hipMemsetAsync(w.counters, 0, CNT_LEN * sizeof(int32_t), st));
+    INVR_HIP(hipMemsetAsync(w.counters, 0, (CNT_ALLOC + (size_t)w.n_groups * INVR_NUM_PARTS) * sizeof(int32_t), st));
     const bool have_cells = launch_cull_cells(a, w, st) != 0;
     INVR_HIP(hipEventRecord(ev_fork, st));
     INVR_HIP(hipStreamWaitEvent(side, ev_fork, 0));
     if (launch_knn_prepare(a, w, side)) return 1;
-    if (launch_vertex_mats(a, w, side)) return 1;
     // ablation switches: the environment is read once per process, not per frame
     static const bool no_voxmask = getenv("INVR_NO_VOXMASK") != nullptr, no_voxcls = getenv("INVR_NO_VOXCLS") != nullptr,
                       no_merge = getenv("INVR_NO_MERGE") != nullptr;
     if (no_voxmask) w.knn.voxmask = nullptr;
     if (!have_cells || no_voxcls) { w.knn.voxcls = nullptr; w.knn.voxmask = nullptr; }
     else if (launch_knn_voxel_class(a, w, side)) return 1;
-    INVR_HIP(hipEventRecord(ev_join, side));
+    INVR_HIP(hipEventRecord(ev_join, side));             // the KNN waits for the index and the lattice classes only;
+    GridDev dgrid = make_grid_dev(&model->deform_grid);
+    if (launch_vertex_mats(a, w, side)) return 1;        // the warp needs these two, they run beside the KNN
+    if (launch_deform_slice(a, w, dgrid, side)) return 1;
+    INVR_HIP(hipEventRecord(ev_join2, side));
     {
         ProfStage ps(INVR_STAGE_CULL, st);
         if (launch_cull(a, w, max_active, have_cells, st)) return 1;
@@ -331,13 +337,13 @@ static int render_impl(const InvrScene* scene, const InvrModel* model,
     INVR_HIP(hipStreamWaitEvent(st, ev_join, 0));        // join
     {
         ProfStage ps(INVR_STAGE_KNN, st);
-        if (launch_knn_pairs(a, w, st)) return 1;
+        if (launch_knn_pairs(a, w, stats, st)) return 1;
     }
+    INVR_HIP(hipStreamWaitEvent(st, ev_join2, 0));
     {
         ProfStage ps(INVR_STAGE_WARP, st);
-        GridDev dg = make_grid_dev(&model->deform_grid);
         MlpDev dm = make_mlp_dev(&model->deform_mlp);
-        if (launch_warp_pairs(a, w, dg, dm, st)) return 1;
+        if (launch_warp_pairs(a, w, dgrid, dm, st)) return 1;
     }
     bool merged = !geometry_only && !no_merge;
     for (int p = 0; p < INVR_NUM_PARTS; ++p) merged = merged && model->part[p].grid.row_sums != nullptr;
@@ -375,11 +381,7 @@ static int render_impl(const InvrScene* scene, const InvrModel* model,
         if (launch_merge_composite(a, w, rgb_map, acc_map, raw, occ, weights, st)) return 1;
     }
     if (g_prof_on) ++g_prof_renders;
-    if (stats) {
-        hipLaunchKernelGGL(k_export_stats, dim3(1), dim3(64), 0, st, w.counters, stats);
-        INVR_LAUNCH_CHECK();
-    }
-    return 0;
+    return 0;                   // (stats were exported by the KNN stage: the counters are final once the pair lists are)
 }
 
 extern "C" int invr_render_fwd(const InvrScene* scene, const InvrModel* model,

@@ -674,19 +674,23 @@ __global__ __launch_bounds__(RS_BLOCK) void k_part_encode_rs_all(EncodeAllArgs a
 // eighth of the row-sum tables (8.5 MB of 68 MB) instead of all of them.
 __global__ __launch_bounds__(RS_BLOCK) void k_part_encode_rs_xcd(EncodeAllArgs a) {
     const int xcd = blockIdx.x & 7;
-    const int64_t tile0 = blockIdx.x >> 3, tstride = gridDim.x >> 3;
+    const int tstride = gridDim.x >> 3;
+    int off = 0;                   // tiles of part p are dealt round-robin from where part p-1 stopped (see k_part_mlp_all)
     for (int p = 0; p < INVR_NUM_PARTS; ++p) {
         const GridDev& g = a.g[p];
         const float* __restrict__ rs = g.row_sums;
         const float* __restrict__ xs = a.xs[p];
         float* __restrict__ emb = a.emb[p];
         const int cnt = a.counts[p];
+        int64_t tile0 = (int)(blockIdx.x >> 3) - off;
+        if (tile0 < 0) tile0 += tstride;
+        off = (int)((off + (cnt + RS_BLOCK - 1) / RS_BLOCK) % tstride);
         const int lg = (xcd + 3 * p) & 7;
         const int la = lg, lb = 15 - lg;
         const float b0x = g.bounds[0], b0y = g.bounds[1], b0z = g.bounds[2];
         const float ex = g.bounds[3] - b0x, ey = g.bounds[4] - b0y, ez = g.bounds[5] - b0z;
         const int hstart = g.separate_dense ? g.start_hash : 0;
-        for (int64_t i = tile0 * RS_BLOCK + threadIdx.x; i < cnt; i += tstride * RS_BLOCK) {
+        for (int64_t i = tile0 * RS_BLOCK + threadIdx.x; i < cnt; i += (int64_t)tstride * RS_BLOCK) {
             const float x = (xs[i] - b0x) / ex, y = (xs[a.stride + i] - b0y) / ey, z = (xs[2 * a.stride + i] - b0z) / ez;   // :112
             if (lg < 3) emb[(int64_t)lg * a.cap + i] = lg == 0 ? x : (lg == 1 ? y : z);
             else if (lg == 3) emb[(int64_t)(EMB_K - 1) * a.cap + i] = 0.0f;          // pad column

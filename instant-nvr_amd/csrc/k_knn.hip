@@ -345,20 +345,98 @@ __device__ __forceinline__ void scan_sub16(const float4* sv, v2f px, v2f py, v2f
 #define KNN_T 1024
 #define KNN_LDS_MAX_V 8192          // float4 vertex slots (131 KB) + 11 record float4 per cluster must fit 160 KB
 
-#define KNN_LDS_HDR 64              // float4: per-wave pair / far counts + list bases
-#define KNN_LDS_FLOAT4 (KNN_LDS_HDR + KNN_LDS_MAX_V + (KNN_LDS_MAX_V / 64 + INVR_NUM_PARTS) * 11)
+#define KNN_LDS_FLOAT4 (KNN_LDS_MAX_V + (KNN_LDS_MAX_V / 64 + INVR_NUM_PARTS) * 11)
+
+// Fallback when the posed vertex sets of the five parts do not fit the LDS-resident index together (> 8192 vertex slots, e.g.
+// SMPL-X): brute force per (survivor, part) over LDS tiles of the part's vertices — the arithmetic of k_knn_dense, the outputs of
+// k_knn_pairs (far pairs by the exact nearest distance > 0.68 m; neighbours / weights of flagged pairs stored at the survivor's
+// slot).  Called by k_knn_pairs (same launch) when its LDS carve does not fit; sv = KNN_TILE float4 of LDS.
+template <int BLOCK>
+__device__ void knn_pairs_bf(const RenderArgs& a, const Workspace& w, float4* sv) {
+    const int na = w.counters[CNT_ACTIVE];
+    for (int64_t tile = blockIdx.x; tile * BLOCK < na; tile += gridDim.x) {
+        const int64_t slot = tile * BLOCK + threadIdx.x;
+        const bool live = slot < na;
+        float px = 0, py = 0, pz = 0;
+        if (live) sample_pose_point(a, w.active_idx[slot], px, py, pz, nullptr, nullptr);
+        unsigned flags = 0, farflags = 0;
+        for (int p = 0; p < INVR_NUM_PARTS; ++p) {
+            const int len = (int)a.scene.lengths2[p];
+            if (len < KNN_K) continue;
+            const float* verts = a.scene.part_pts + (int64_t)p * a.scene.M * 3;
+            Top4 t;
+            t.init();
+            for (int base = 0; base < len; base += KNN_TILE) {
+                const int m = min(KNN_TILE, len - base);
+                __syncthreads();
+                for (int j = threadIdx.x; j < m; j += BLOCK) {
+                    const float* v = verts + (int64_t)(base + j) * 3;
+                    sv[j] = make_float4(v[0], v[1], v[2], 0.0f);
+                }
+                __syncthreads();
+#pragma unroll 4
+                for (int j = 0; j < m; ++j) {
+                    const float4 v = sv[j];
+                    const float dx = px - v.x, dy = py - v.y, dz = pz - v.z;
+                    t.push(dx * dx + dy * dy + dz * dz, base + j);
+                }
+            }
+            t.finish();
+            float wt[KNN_K];
+            const float ds = knn_weights(t, wt);
+            const bool far = live && t.d[0] > KNN_DFAR2;
+            const bool hit = live && !far && ds < a.scene.thresh;
+            if (far) farflags |= 1u << p;
+            const unsigned long long fb = __ballot(far);
+            if ((threadIdx.x & 63) == 0 && fb) atomicAdd(&w.counters[CNT_FAR + p], __popcll(fb));
+            const unsigned long long hb = __ballot(hit);
+            if ((threadIdx.x & 63) == 0 && hb) atomicAdd(&w.gcount[slot / PAIR_GROUP * INVR_NUM_PARTS + p], __popcll(hb));
+            if (hit) {
+                flags |= 1u << p;
+                reinterpret_cast<int4*>(w.l_nn[p])[slot] = make_int4(t.i[0], t.i[1], t.i[2], t.i[3]);
+                reinterpret_cast<float4*>(w.l_w[p])[slot] = make_float4(wt[0], wt[1], wt[2], wt[3]);
+            }
+        }
+        if (live) {
+            w.pflags[slot] = (uint8_t)flags;
+            w.farflags[slot] = (uint8_t)farflags;
+        }
+    }
+}
 
 struct KnnLds { int voff[INVR_NUM_PARTS], coff[INVR_NUM_PARTS], soff[INVR_NUM_PARTS], len[INVR_NUM_PARTS]; };
 
+// Phase timers of k_knn_pairs (tools/knn_phase_prof.sh builds a second library with -DKNN_PROF; not part of libinvr.so)
+#ifdef KNN_PROF
+__device__ unsigned long long g_knn_prof[16];
+extern "C" int invr_debug_knn_prof(unsigned long long* out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_knn_prof), sizeof(g_knn_prof)) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_knn_prof), z, sizeof(z)) != hipSuccess) return 1; }
+    return 0;
+}
+#define KP_DECL long long kp_t0 = clock64(); long long kp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define KP(i) { const long long kp_now = clock64(); kp_acc[i] += kp_now - kp_t0; kp_t0 = kp_now; }
+#define KP_CNT(i) { kp_acc[i] += 1; }
+#define KP_FLUSH if ((threadIdx.x & 63) == 0) { for (int kp_i = 0; kp_i < 12; ++kp_i) atomicAdd(&g_knn_prof[kp_i], (unsigned long long)kp_acc[kp_i]); }
+#else
+#define KP_DECL
+#define KP(i)
+#define KP_CNT(i)
+#define KP_FLUSH
+#endif
+
+// Outputs per survivor slot: pflags / farflags bytes and, for every flagged part, the 4 neighbour rows and weights at
+// l_nn[p][slot] / l_w[p][slot]; k_pair_lists then builds the dense per-part lists of flagged slots.  (The lists used to be
+// appended here, aggregated per 1024-point workgroup tile: the two barriers per tile made every wave wait for the slowest of
+// the 16 — 64 consecutive survivors are one depth segment of one ray, and the segments differ widely in how many parts they
+// come near — 29 % of the kernel's wave time on a whole frame and 51 % on a 1/8 shard, tools/knn_phase_prof.py.  Now a wave
+// never waits for another one.)
 __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w, int dbg) {
-    // all LDS is dynamic (a static __shared__ in front would misalign the float4 region, guide G17):
-    // [0,1024) B: per-wave pair / far counts + per-part list bases; then vertices; then cluster records
+    // all LDS is dynamic (a static __shared__ in front would misalign the float4 region, guide G17): vertices, then cluster records
     extern __shared__ __attribute__((aligned(16))) float4 lds_raw[];
-    int (*s_cnt)[INVR_NUM_PARTS] = reinterpret_cast<int (*)[INVR_NUM_PARTS]>(lds_raw);
-    int* s_base = reinterpret_cast<int*>(lds_raw) + (KNN_T / 64) * INVR_NUM_PARTS;
-    int (*s_far)[INVR_NUM_PARTS] = reinterpret_cast<int (*)[INVR_NUM_PARTS]>(s_base + 8);
-    float4* lds = lds_raw + KNN_LDS_HDR;
+    float4* lds = lds_raw;
     const KnnIndex& ix = w.knn;
+    KP_DECL
     // LDS carve from the (device-resident) part lengths: [vertices of part 0..4 | records of part 0..4]
     KnnLds L;
     {
@@ -368,8 +446,8 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w, 
             L.voff[p] = off;
             off += (L.len[p] + 63) / 64 * 64;
         }
-        if (off > KNN_LDS_MAX_V) {                       // does not fit the LDS-resident design: k_knn_pairs_bf takes the frame
-            if (threadIdx.x == 0 && blockIdx.x == 0) w.counters[CNT_TICKET] = -1;
+        if (off > KNN_LDS_MAX_V) {                       // does not fit the LDS-resident design
+            knn_pairs_bf<KNN_T>(a, w, lds);
             return;
         }
         for (int p = 0; p < INVR_NUM_PARTS; ++p) { L.coff[p] = off; off += (L.len[p] + 63) / 64 * 3; }
@@ -383,16 +461,21 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w, 
         for (int j = threadIdx.x; j < ncl * 8; j += KNN_T) lds[L.soff[p] + j] = ix.sub[(int64_t)p * ix.cpad * 8 + j];
     }
     __syncthreads();
+    KP(6)
     const int na = w.counters[CNT_ACTIVE];
     const int lane = threadIdx.x & 63;
-    // dynamic tile scheduling (one ticket per 1024-point tile): tile cost varies ~10x with how many
-    // clusters the points of a tile have to sweep, static striding left a long tail
-    for (;;) {
-        if (threadIdx.x == 0) s_base[INVR_NUM_PARTS] = atomicAdd(&w.counters[CNT_TICKET], 1);
-        __syncthreads();
-        const int64_t tile = s_base[INVR_NUM_PARTS];
-        if (tile * KNN_T >= na) break;
-        const int64_t slot = tile * KNN_T + threadIdx.x;
+    int far_cnt[INVR_NUM_PARTS] = {0, 0, 0, 0, 0};          // far pairs seen by this wave (statistics), flushed once at the end
+    // dynamic scheduling, one ticket per wave and 64 survivors: the cost of 64 points varies ~10x with how many clusters they
+    // have to sweep.  A wave's first ticket is its index; further tickets come from 16 counters on separate cache lines
+    // (workgroup b draws from counter b % 16, which owns the tickets = b mod 16): one counter for all 4096 waves serialised
+    // the returned atomics at ~15 ns each and, ordered in front of the wave's loads, slowed every phase of the kernel.
+    const int n_wave = (int)gridDim.x * (KNN_T / 64);
+    const int n_cls = min(16, (int)gridDim.x), my_cls = (int)blockIdx.x % n_cls;
+    int32_t* my_counter = w.counters + CNT_TICKETS + my_cls * 32;
+    int ticket = (int)blockIdx.x * (KNN_T / 64) + (int)(threadIdx.x >> 6);
+    while ((int64_t)ticket * 64 < na) {
+        KP_CNT(8)
+        const int64_t slot = (int64_t)ticket * 64 + lane;
         const bool live = slot < na;
         float px = 0, py = 0, pz = 0;
         if (live) sample_pose_point(a, w.active_idx[slot], px, py, pz, nullptr, nullptr);
@@ -407,10 +490,10 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w, 
             if (ux >= 0.0f && uy >= 0.0f && uz >= 0.0f && ux <= (float)(v.dx - 1) && uy <= (float)(v.dy - 1) && uz <= (float)(v.dz - 1))
                 vcell = ((int)ux * v.dy + (int)uy) * v.dz + (int)uz;
         }
-        int4 res_nn[INVR_NUM_PARTS];
-        float4 res_w[INVR_NUM_PARTS];
+        KP(1)
 #pragma unroll
         for (int p = 0; p < INVR_NUM_PARTS; ++p) {
+            KP(2)
             const int len = L.len[p];
             if (len < KNN_K) continue;                     // reference: inf distances -> NaN dist -> unflagged
             const unsigned c2 = vcell >= 0 ? ix.voxcls[(int64_t)vcell * INVR_NUM_PARTS + p] : 0u;
@@ -472,6 +555,8 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w, 
             const bool scan = live && !is_far && !unflagged;
             if (live && is_far) farflags |= 1u << p;
             if (__ballot(scan) == 0 || (dbg & 1)) continue;
+            KP(2)
+            KP_CNT(9)
             // exact 4-NN: seed with the cluster of the wave's first scanning lane, then a pruned sweep that
             // walks outwards from the seed in Morton order (neighbouring indices are mostly neighbouring
             // patches, so the 4th-best bound tightens early); clusters are pruned as a whole and then per
@@ -501,14 +586,17 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w, 
                     if (!full && !((Mc >> c) & 1ull)) continue;                   // no lane of the wave can have a neighbour there
                     const bool need = scan && aabb_dist2(px, py, pz, lds_ld4(cl + c * 3), lds_ld4(cl + c * 3 + 1)) <= t.worst();
                     if (__ballot(need) == 0) continue;
+                    KP_CNT(10)
 #pragma unroll 1
                     for (int s4 = 0; s4 < 4; ++s4) {
                         const bool need_s = need && aabb_dist2(px, py, pz, lds_ld4(sb + c * 8 + s4 * 2), lds_ld4(sb + c * 8 + s4 * 2 + 1)) <= t.worst();
                         if (__ballot(need_s) == 0) continue;
+                        KP_CNT(11)
                         scan_sub16(sv + c * 64 + s4 * 16, px2, py2, pz2, t);
                     }
                 }
             }
+            KP(3)
             t.finish();
 #pragma unroll
             for (int j = 0; j < KNN_K; ++j) t.i[j] = min(t.i[j] & 0x7FFFFFFF, len - 1);      // (a surviving placeholder would be a bug; never index out of the part)
@@ -516,122 +604,113 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w, 
             const float ds = knn_weights(t, wt);
             if (scan && ds < a.scene.thresh) {                        // pflag (inb_part_network_multiassign.py:90)
                 flags |= 1u << p;
-                res_nn[p] = make_int4(t.i[0], t.i[1], t.i[2], t.i[3]);
-                res_w[p] = make_float4(wt[0], wt[1], wt[2], wt[3]);
+                reinterpret_cast<int4*>(w.l_nn[p])[slot] = make_int4(t.i[0], t.i[1], t.i[2], t.i[3]);
+                reinterpret_cast<float4*>(w.l_w[p])[slot] = make_float4(wt[0], wt[1], wt[2], wt[3]);
             }
+            KP(4)
         }
-        // list append, aggregated per workgroup-tile: 5 global atomics per 1024 points instead of one
-        // returned atomic per wave per part (whose contended latency dominated the kernel)
-        const int wv = threadIdx.x >> 6;
-        unsigned long long bal[INVR_NUM_PARTS];
+        KP(2)
+        int my_cnt = 0;                              // lane p < 5: pairs of this ticket flagged for part p
 #pragma unroll
         for (int p = 0; p < INVR_NUM_PARTS; ++p) {
-            bal[p] = __ballot((flags >> p) & 1u);
-            const unsigned long long fb = __ballot((farflags >> p) & 1u);
-            if (lane == 0) { s_cnt[wv][p] = __popcll(bal[p]); s_far[wv][p] = __popcll(fb); }
+            far_cnt[p] += __popcll(__ballot((farflags >> p) & 1u));
+            const int c = __popcll(__ballot((flags >> p) & 1u));
+            if (lane == p) my_cnt = c;
         }
-        __syncthreads();
-        if (threadIdx.x < INVR_NUM_PARTS) {
-            int tot = 0;
-            for (int k = 0; k < KNN_T / 64; ++k) { int c = s_cnt[k][threadIdx.x]; s_cnt[k][threadIdx.x] = tot; tot += c; }
-            s_base[threadIdx.x] = tot ? atomicAdd(&w.counters[CNT_PAIRS + threadIdx.x], tot) : 0;
-            int ftot = 0;                 // far counts (statistics): one atomic per tile, not one per wave
-            for (int k = 0; k < KNN_T / 64; ++k) ftot += s_far[k][threadIdx.x];
-            if (ftot) atomicAdd(&w.counters[CNT_FAR + threadIdx.x], ftot);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int p = 0; p < INVR_NUM_PARTS; ++p) {
-            if ((flags >> p) & 1u) {
-                const int64_t pos = s_base[p] + s_cnt[wv][p] + __popcll(bal[p] & ((1ull << lane) - 1ull));
-                w.l_slot[p][pos] = (int32_t)slot;
-                reinterpret_cast<int4*>(w.l_nn[p])[pos] = res_nn[p];
-                reinterpret_cast<float4*>(w.l_w[p])[pos] = res_w[p];
-            }
-        }
-        __syncthreads();          // s_cnt / s_base are reused by the next tile
+        if (my_cnt) atomicAdd(&w.gcount[(slot - lane) / PAIR_GROUP * INVR_NUM_PARTS + lane], my_cnt);      // (64 | PAIR_GROUP; not returned)
         if (live) {
             w.pflags[slot] = (uint8_t)flags;
             w.farflags[slot] = (uint8_t)farflags;
         }
+        KP(5)
+        int next = 0;
+        if (lane == 0) next = atomicAdd(my_counter, 1);
+        ticket = n_wave + __builtin_amdgcn_readfirstlane(next) * n_cls + my_cls;
+        KP(0)
     }
+    if (lane == 0)
+#pragma unroll
+        for (int p = 0; p < INVR_NUM_PARTS; ++p)
+            if (far_cnt[p]) atomicAdd(&w.counters[CNT_FAR + p], far_cnt[p]);
+    KP_FLUSH
 }
 
-// Fallback when the posed vertex sets of the five parts do not fit the LDS-resident index together (> 8192 vertex slots, e.g.
-// SMPL-X): brute force per (survivor, part) over LDS tiles of the part's vertices — the arithmetic of k_knn_dense, the outputs of
-// k_knn_pairs (far pairs by the exact nearest distance > 0.68 m, flagged pairs listed).  Runs only when k_knn_pairs left the
-// "does not fit" mark in the ticket counter; otherwise every workgroup exits at once.
-__global__ __launch_bounds__(KNN_BLOCK) void k_knn_pairs_bf(RenderArgs a, Workspace w) {
-    if (w.counters[CNT_TICKET] != -1) return;
-    __shared__ float4 sv[KNN_TILE];
+// The per-part pair lists from the flag bytes k_knn_pairs left per survivor: l_slot[p][0..count) = the survivors flagged for
+// part p, ASCENDING (a deterministic order: consecutive pairs are consecutive samples of a ray); neighbours and weights stay
+// where the KNN wrote them — at the survivor's slot.  One workgroup per group of PAIR_GROUP slots; its list offsets are the sums
+// of the per-group counts the KNN accumulated (gcount) over the groups before it — no atomics here (device-scope atomics on one
+// address serialise at tens of ns each on the 8-XCD part: 1167 claims per part cost this kernel 90 us).  The workgroup of the
+// last group appends one zero-weight pair per part behind the real ones — its field value is the constant every far pair of
+// that part takes (header comment); it lives in the extra slot `cap` — and exports the counters (no extra launches).
+#define PL_BLOCK 256
+#define PL_PER 8
+__global__ __launch_bounds__(PL_BLOCK) void k_pair_lists(Workspace w, int32_t* __restrict__ stats) {
+    __shared__ int s_cnt[PL_BLOCK / 64][INVR_NUM_PARTS];
+    __shared__ int s_red[PL_BLOCK / 64][INVR_NUM_PARTS];
     const int na = w.counters[CNT_ACTIVE];
-    const int lane = threadIdx.x & 63;
-    for (int64_t tile = blockIdx.x; tile * KNN_BLOCK < na; tile += gridDim.x) {
-        const int64_t slot = tile * KNN_BLOCK + threadIdx.x;
-        const bool live = slot < na;
-        float px = 0, py = 0, pz = 0;
-        if (live) sample_pose_point(a, w.active_idx[slot], px, py, pz, nullptr, nullptr);
-        unsigned flags = 0, farflags = 0;
+    const int64_t g = blockIdx.x, g_last = (max(na, 1) - 1) / PAIR_GROUP;
+    if (g > g_last) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // list offsets of this group = counts of the groups before it
+    int base[INVR_NUM_PARTS];
+    {
+        int acc[INVR_NUM_PARTS] = {0, 0, 0, 0, 0};
+        for (int64_t q = threadIdx.x; q < g; q += PL_BLOCK)
+#pragma unroll
+            for (int p = 0; p < INVR_NUM_PARTS; ++p) acc[p] += w.gcount[q * INVR_NUM_PARTS + p];
+#pragma unroll
         for (int p = 0; p < INVR_NUM_PARTS; ++p) {
-            const int len = (int)a.scene.lengths2[p];
-            if (len < KNN_K) continue;
-            const float* verts = a.scene.part_pts + (int64_t)p * a.scene.M * 3;
-            Top4 t;
-            t.init();
-            for (int base = 0; base < len; base += KNN_TILE) {
-                const int m = min(KNN_TILE, len - base);
-                __syncthreads();
-                for (int j = threadIdx.x; j < m; j += KNN_BLOCK) {
-                    const float* v = verts + (int64_t)(base + j) * 3;
-                    sv[j] = make_float4(v[0], v[1], v[2], 0.0f);
-                }
-                __syncthreads();
-#pragma unroll 4
-                for (int j = 0; j < m; ++j) {
-                    const float4 v = sv[j];
-                    const float dx = px - v.x, dy = py - v.y, dz = pz - v.z;
-                    t.push(dx * dx + dy * dy + dz * dz, base + j);
-                }
-            }
-            t.finish();
-            float wt[KNN_K];
-            const float ds = knn_weights(t, wt);
-            const bool far = live && t.d[0] > KNN_DFAR2;
-            const bool hit = live && !far && ds < a.scene.thresh;
-            if (far) farflags |= 1u << p;
-            const unsigned long long hb = __ballot(hit), fb = __ballot(far);
-            int base_pos = 0;
-            if (lane == 0) {
-                if (hb) base_pos = atomicAdd(&w.counters[CNT_PAIRS + p], __popcll(hb));
-                if (fb) atomicAdd(&w.counters[CNT_FAR + p], __popcll(fb));
-            }
-            base_pos = __shfl(base_pos, 0);
-            if (hit) {
-                flags |= 1u << p;
-                const int64_t pos = base_pos + __popcll(hb & ((1ull << lane) - 1ull));
-                w.l_slot[p][pos] = (int32_t)slot;
-                reinterpret_cast<int4*>(w.l_nn[p])[pos] = make_int4(t.i[0], t.i[1], t.i[2], t.i[3]);
-                reinterpret_cast<float4*>(w.l_w[p])[pos] = make_float4(wt[0], wt[1], wt[2], wt[3]);
-            }
+            for (int d = 32; d >= 1; d >>= 1) acc[p] += __shfl_xor(acc[p], d);
+            if (lane == 0) s_red[wv][p] = acc[p];
         }
-        if (live) {
-            w.pflags[slot] = (uint8_t)flags;
-            w.farflags[slot] = (uint8_t)farflags;
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < INVR_NUM_PARTS; ++p) {
+            base[p] = 0;
+            for (int k = 0; k < PL_BLOCK / 64; ++k) base[p] += s_red[k][p];
         }
     }
-}
-
-// one zero-weight pair per part, appended behind the real pairs: its field value is the constant
-// every far pair of that part takes (see the header comment).  It lives in the extra slot `cap`.
-__global__ void k_append_const_pairs(Workspace w) {
-    const int p = threadIdx.x;
-    if (p >= INVR_NUM_PARTS) return;
-    const int pos = w.counters[CNT_PAIRS + p];
-    w.l_slot[p][pos] = (int32_t)w.cap;
-    reinterpret_cast<int4*>(w.l_nn[p])[pos] = make_int4(0, 0, 0, 0);
-    reinterpret_cast<float4*>(w.l_w[p])[pos] = make_float4(0.f, 0.f, 0.f, 0.f);
-    w.counters[CNT_PAIRS + p] = pos + 1;
-    if (p == 0) w.active_idx[w.cap] = 0;
+    for (int64_t t0 = g * PAIR_GROUP; t0 < min((g + 1) * (int64_t)PAIR_GROUP, (int64_t)na); t0 += PL_BLOCK * PL_PER) {
+        // thread -> PL_PER consecutive survivors (one 8-byte load of flag bytes); ranks: inside the thread, the wave, the block
+        const int64_t s0 = t0 + (int64_t)threadIdx.x * PL_PER;
+        unsigned long long fb = 0ull;
+        if (s0 + PL_PER <= na) fb = *reinterpret_cast<const unsigned long long*>(w.pflags + s0);
+        else for (int k = 0; k < PL_PER; ++k) if (s0 + k < na) fb |= (unsigned long long)w.pflags[s0 + k] << (8 * k);
+        int pre[INVR_NUM_PARTS];
+#pragma unroll
+        for (int p = 0; p < INVR_NUM_PARTS; ++p) {
+            const int mine = __popcll(fb & (0x0101010101010101ull << p));
+            int x = mine;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d); if (lane >= d) x += y; }
+            pre[p] = x - mine;
+            if (lane == 63) s_cnt[wv][p] = x;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < INVR_NUM_PARTS; ++p) {
+            int pos = base[p] + pre[p];
+            for (int k = 0; k < PL_BLOCK / 64; ++k) { const int c = s_cnt[k][p]; if (k < wv) pos += c; base[p] += c; }
+            for (int k = 0; k < PL_PER; ++k)
+                if ((fb >> (8 * k + p)) & 1ull) w.l_slot[p][pos++] = (int32_t)(s0 + k);
+        }
+        __syncthreads();                 // s_cnt is reused by the next tile
+    }
+    if (g != g_last) return;
+    // epilogue: base[] = the totals
+    if (threadIdx.x < INVR_NUM_PARTS) {
+        const int p = threadIdx.x;
+        int tot = 0;
+#pragma unroll
+        for (int q = 0; q < INVR_NUM_PARTS; ++q) if (q == p) tot = base[q];
+        w.l_slot[p][tot] = (int32_t)w.cap;
+        reinterpret_cast<int4*>(w.l_nn[p])[w.cap] = make_int4(0, 0, 0, 0);
+        reinterpret_cast<float4*>(w.l_w[p])[w.cap] = make_float4(0.f, 0.f, 0.f, 0.f);
+        w.counters[CNT_PAIRS + p] = tot + 1;
+        if (p == 0) w.active_idx[w.cap] = 0;
+    }
+    __syncthreads();
+    if (stats && threadIdx.x < INVR_STATS_LEN) stats[threadIdx.x] = threadIdx.x < CNT_LEN ? w.counters[threadIdx.x] : 0;
 }
 
 // Per-frame classification of the distance-volume lattice cells (side stream, after k_part_prepare): for every cell
@@ -787,24 +866,19 @@ int launch_knn_prepare(const RenderArgs& a, const Workspace& w, hipStream_t st) 
     return 0;
 }
 
-int launch_knn_pairs(const RenderArgs& a, const Workspace& w, hipStream_t st) {
+int launch_knn_pairs(const RenderArgs& a, const Workspace& w, int32_t* stats, hipStream_t st) {
     const size_t lds_bytes = (size_t)KNN_LDS_FLOAT4 * sizeof(float4);      // ~150 KB: one workgroup per CU
     static bool attr_set = false;
     if (!attr_set) {
         INVR_HIP(hipFuncSetAttribute((const void*)k_knn_pairs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         attr_set = true;
     }
-    int64_t tiles = cdiv(w.cap, KNN_T);
-    unsigned grid = (unsigned)(tiles < 256 ? (tiles > 0 ? tiles : 1) : 256);
+    int64_t tiles = cdiv(w.cap, 64);              // tickets of 64 survivors, taken by single waves
+    unsigned grid = (unsigned)(tiles < 256 * 16 ? (tiles > 0 ? cdiv(tiles, 16) : 1) : 256);
     static int dbg = getenv("INVR_KNN_DBG") ? atoi(getenv("INVR_KNN_DBG")) : 0;
     hipLaunchKernelGGL(k_knn_pairs, dim3(grid), dim3(KNN_T), lds_bytes, st, a, w, dbg);
     INVR_LAUNCH_CHECK();
-    if (a.scene.M * (int64_t)INVR_NUM_PARTS > KNN_LDS_MAX_V) {      // the five parts may not fit the LDS index together: fallback armed
-        int64_t bt = cdiv(w.cap, KNN_BLOCK);
-        hipLaunchKernelGGL(k_knn_pairs_bf, dim3((unsigned)(bt < 2048 ? (bt > 0 ? bt : 1) : 2048)), dim3(KNN_BLOCK), 0, st, a, w);
-        INVR_LAUNCH_CHECK();
-    }
-    hipLaunchKernelGGL(k_append_const_pairs, dim3(1), dim3(64), 0, st, w);
+    hipLaunchKernelGGL(k_pair_lists, dim3((unsigned)w.n_groups), dim3(PL_BLOCK), 0, st, w, stats);
     INVR_LAUNCH_CHECK();
     return 0;
 }

@@ -183,8 +183,8 @@ __global__ __launch_bounds__(WARP_BLOCK) void k_warp_pairs(RenderArgs a, Workspa
     const float4* __restrict__ vm = w.knn.vmat + (int64_t)p * w.knn.mpad * 6;
     for (int64_t i = (int64_t)blockIdx.x * WARP_BLOCK + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * WARP_BLOCK) {
         const int slot = w.l_slot[p][i];
-        const int4 nn = reinterpret_cast<const int4*>(w.l_nn[p])[i];
-        const float4 wt = reinterpret_cast<const float4*>(w.l_w[p])[i];
+        const int4 nn = reinterpret_cast<const int4*>(w.l_nn[p])[slot];       // (stored per survivor slot by k_knn_pairs)
+        const float4 wt = reinterpret_cast<const float4*>(w.l_w[p])[slot];
         const float4* r0 = vm + (int64_t)nn.x * 6;
         const float4* r1 = vm + (int64_t)nn.y * 6;
         const float4* r2 = vm + (int64_t)nn.z * 6;
@@ -585,6 +585,25 @@ __global__ __launch_bounds__(DF_BLOCK) void k_deform_pairs_slice(RenderArgs a, W
     }
 }
 
+static bool deform_slices_fit(const GridDev& dg, DfSliceInfo& si, int cbv) {
+    si.off[0] = 0;
+    for (int l = 0; l < INVR_MAX_LEVELS; ++l) si.off[l + 1] = si.off[l] + (l < dg.L ? dg.res[l] * dg.res[l] : 0);
+    return dg.L == 8 && si.off[8] <= DF_SLICE_MAX && cbv < 10;
+}
+static int deform_cb() {
+    static int cbv = getenv("INVR_DF_CB") ? atoi(getenv("INVR_DF_CB")) : 2;
+    return cbv;
+}
+
+// depends on the grid and frame_dim only (not on the pair lists): launched on the side stream beside the KNN
+int launch_deform_slice(const RenderArgs& a, const Workspace& w, const GridDev& dg, hipStream_t st) {
+    DfSliceInfo si;
+    if (!deform_slices_fit(dg, si, deform_cb())) return 0;
+    hipLaunchKernelGGL(k_deform_slice, dim3((unsigned)cdiv(si.off[8], 256)), dim3(256), 0, st, dg, si, a.scene.frame_dim, w.dslice);
+    INVR_LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_warp_pairs(const RenderArgs& a, const Workspace& w, const GridDev& dg, const MlpDev& dm, hipStream_t st) {
     int64_t tiles = cdiv(w.lcap, WARP_BLOCK);
     unsigned gx = (unsigned)(tiles < 1024 ? (tiles > 0 ? tiles : 1) : 1024);
@@ -592,13 +611,9 @@ int launch_warp_pairs(const RenderArgs& a, const Workspace& w, const GridDev& dg
     INVR_LAUNCH_CHECK();
     int64_t dtiles = cdiv(w.lcap, DF_BLOCK);
     unsigned dgx = (unsigned)(dtiles < 512 ? (dtiles > 0 ? dtiles : 1) : 512);
-    static int cbv = getenv("INVR_DF_CB") ? atoi(getenv("INVR_DF_CB")) : 2;
+    const int cbv = deform_cb();
     DfSliceInfo si;
-    si.off[0] = 0;
-    for (int l = 0; l < INVR_MAX_LEVELS; ++l) si.off[l + 1] = si.off[l] + (l < dg.L ? dg.res[l] * dg.res[l] : 0);
-    if (dg.L == 8 && si.off[8] <= DF_SLICE_MAX && cbv < 10) {
-        hipLaunchKernelGGL(k_deform_slice, dim3((unsigned)cdiv(si.off[8], 256)), dim3(256), 0, st, dg, si, a.scene.frame_dim, w.dslice);
-        INVR_LAUNCH_CHECK();
+    if (deform_slices_fit(dg, si, cbv)) {                 // slices built by launch_deform_slice
         const size_t lds_bytes = (size_t)DF_LDS * sizeof(float) + (size_t)si.off[8] * sizeof(float2);
         if (cbv == 1)
             hipLaunchKernelGGL(k_deform_pairs_slice<1>, dim3(dgx, INVR_NUM_PARTS), dim3(DF_BLOCK), lds_bytes, st, a, w, dg, si, dm.w[0], dm.b[0],

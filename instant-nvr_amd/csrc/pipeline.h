@@ -2,9 +2,11 @@
 #pragma once
 #include "common.h"
 
+#define PAIR_GROUP 4096          // survivor slots per workgroup of k_pair_lists
 enum { CNT_ACTIVE = 0, CNT_PAIRS = 1 /* ..5 */, CNT_OVERFLOW = 6, CNT_FAR = 7 /* ..11 */, CNT_TICKET = 12,
        CNT_NB = 13 /* selected pair-regulariser rows */, CNT_DTOT = 14 /* entries of the deformer backward list */,
-       CNT_LIVE = 15 /* lattice cells that can hold a survivor */, CNT_LEN = 16 };
+       CNT_LIVE = 15 /* lattice cells that can hold a survivor */, CNT_LEN = 16 /* exported as stats[] */,
+              CNT_TICKETS = 32 /* 16 ticket counters of k_knn_pairs, one per 128-byte line */, CNT_ALLOC = 32 + 16 * 32 };
 
 #define CULL_MASK_MAX (4 << 20)   // cells of the per-frame cull mask (bytes); larger distance volumes run unmasked
 #define VOXMASK_MAX_CELLS (1 << 20)  // lattice cells with per-part candidate-cluster masks (40 B each)
@@ -48,7 +50,9 @@ struct Workspace {
     unsigned long long* mask;     // ceil(N/64): survivor bit per ray-sample
     int32_t* block_cnt;           // ceil(N/256)
     int32_t* block_off;           // ceil(N/256)
-    int32_t* counters;            // CNT_LEN
+    int32_t* counters;            // CNT_ALLOC, followed by gcount (one memset clears both)
+    int32_t* gcount;              // [ceil(lcap / PAIR_GROUP)][INVR_NUM_PARTS]: flagged pairs per group of PAIR_GROUP survivor slots
+    int64_t n_groups;
     int32_t* active_idx;          // cap: ray-sample index of every survivor (ordered)
     int32_t* word_off;            // ceil(N/64): rank of the first survivor of every 64-sample mask word (slot of sample i =
                                   // word_off[i>>6] + popcount(mask[i>>6] below bit i&63); 2 MB instead of a 131 MB slot-per-sample array)
@@ -121,7 +125,8 @@ int launch_pose_points(const RenderArgs& a, const int32_t* idx, int64_t n, float
 int launch_knn_prepare(const RenderArgs& a, const Workspace& w, hipStream_t st);
 int launch_vertex_mats(const RenderArgs& a, const Workspace& w, hipStream_t st);
 int launch_knn_voxel_class(const RenderArgs& a, const Workspace& w, hipStream_t st);
-int launch_knn_pairs(const RenderArgs& a, const Workspace& w, hipStream_t st);
+int launch_knn_pairs(const RenderArgs& a, const Workspace& w, int32_t* stats, hipStream_t st);     // stats: exported behind the pair lists when given
+int launch_deform_slice(const RenderArgs& a, const Workspace& w, const GridDev& dg, hipStream_t st);   // per-call t-slices of the deformer grid (no-op when they do not fit)
 int launch_warp_pairs(const RenderArgs& a, const Workspace& w, const GridDev& dg, const MlpDev& dm, hipStream_t st);
 int launch_part_encode(const GridDev& g, const float* x_soa, int64_t stride, const int32_t* count, int64_t cap,
                        float* emb, hipStream_t st);

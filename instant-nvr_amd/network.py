@@ -327,8 +327,9 @@ class Network(nn.Module):
         ray_o, ray_d, near, far = f(ray_o), f(ray_d), f(near), f(far)
         n = ray_o.shape[0]
         S = int(n_samples)
+        # (the library writes every entry of stats unless there is nothing to render)
         out = {'rgb_map': torch.empty(n, 3, device=dev), 'acc_map': torch.empty(n, device=dev),
-               'stats': torch.zeros(_abi.STATS_LEN, dtype=torch.int32, device=dev)}
+               'stats': (torch.empty if n else torch.zeros)(_abi.STATS_LEN, dtype=torch.int32, device=dev)}
         if want_raw:
             out['raw'] = torch.empty(n * S, 4, device=dev)
             out['occ'] = torch.empty(n * S, device=dev)

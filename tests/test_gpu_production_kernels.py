@@ -93,12 +93,13 @@ def test_knn_pairs_vs_brute_force_whole_frame(fr):
             assert float(d2[far, p, 0].min()) > 0.4624
         cnt = int(st[1 + p]) - 1                                                 # last entry = the far-constant pair
         slots = v['l_slot'][p][:cnt].long()
-        assert int(v['l_slot'][p][cnt]) == v['cap'] and int(v['l_nn'][p][cnt].abs().max()) == 0 and float(v['l_w'][p][cnt].abs().max()) == 0
+        cap = v['cap']                                                           # neighbours / weights live at the survivor's slot
+        assert int(v['l_slot'][p][cnt]) == cap and int(v['l_nn'][p][cap].abs().max()) == 0 and float(v['l_w'][p][cap].abs().max()) == 0
         assert cnt == int(listed.sum())
         assert torch.equal(slots.sort()[0], listed.nonzero(as_tuple=True)[0])    # every listed pair exactly once
         # neighbour rows: bit-exact, in (distance,row) order; weights: same arithmetic on the same distances -> bit-exact
-        assert torch.equal(v['l_nn'][p][:cnt], nn[slots, p]), (k, p)
-        wd = ulp_diff(v['l_w'][p][:cnt], w[slots, p])
+        assert torch.equal(v['l_nn'][p][slots], nn[slots, p]), (k, p)
+        wd = ulp_diff(v['l_w'][p][slots], w[slots, p])
         assert int(wd.max()) <= 1, (k, p, int(wd.max()))
         n_listed += cnt
     assert n_listed > 500000

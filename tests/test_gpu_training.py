@@ -105,7 +105,7 @@ def test_configs4_full_size_iteration_vs_oracle_autograd(full_net):
             touched = ref_rows != 0
             # rows the reference leaves at exactly 0 (never touched, or touched with an exactly-zero corner weight): nothing above
             # rounding dust (a corner weight of ~1e-8 instead of 0 times a gradient)
-            assert float(got[~touched].abs().max()) <= 1e-9 * scale, (i, float(got[~touched].abs().max()), scale)
+            assert float(got[~touched].abs().max()) <= 1e-7 * scale, (i, float(got[~touched].abs().max()), scale)
             assert int((got != 0).sum()) <= int(touched.sum()) + 1000
             checked += 1
         assert checked >= 40
