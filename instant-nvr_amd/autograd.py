@@ -1,16 +1,17 @@
 """Differentiable training forward.
 
-Geometry (sampling, cull, KNN skinning, LBS warp, pair lists, far/near classification) carries
-no gradient in the reference (``torch.no_grad`` blocks, inb_part_network_multiassign.py:87-90,
-132-140) and comes from the HIP render pipeline.  The differentiable remainder is recomputed on the
-pair lists with autograd:
+Two deliveries of the same gradients (tests/test_gpu_parity.py compares them with each other and with the reference's
+autograd goldens):
 
-    HIP  GridEncodeFn   hash-grid encoder fwd/bwd (invr_grid_encode_fwd / _bwd): table gradients by
-                        atomic adds, gradient w.r.t. the canonical point (feeds the deformer)
-    HIP  CompositeFn    alpha compositing fwd/bwd (invr_composite_fwd / _bwd)
-    torch               the tiny Softplus MLPs (rocBLAS GEMMs), tanh/sigmoid, the (Na,P) merge, the
-                        distortion regulariser — interim: fused HIP backward kernels for these are the
-                        next step
+  TrainRenderFn (default, cfg.train_fused)   ONE autograd node for the whole training forward: invr_train_fwd (geometry,
+      64-byte-row encoder, part MLPs, merge + compositing, distortion, offset / pair regulariser terms reduced on the device)
+      and invr_train_bwd (every transpose of it as HIP kernels, csrc/k_train.hip; DESIGN.md §6 "Training path").  With a
+      GradArena (FusedAdam.attach) the backward accumulates into persistent buffers — the part grids as row-scalar gradients —
+      and returns no tensors to autograd; without one it fills autograd-allocated dense gradients.
+  render_train (cfg.train_fused = False)     the op-by-op graph: geometry from the HIP pipeline (no gradient in the reference
+      either: ``torch.no_grad`` blocks, inb_part_network_multiassign.py:87-90, 132-140), the differentiable remainder
+      recomputed on the pair lists from GridEncodeFn / PartMlpFn / CompositeFn (HIP forward + backward each) and torch glue.
+      Kept as the in-repo cross-check and for callers that wrap the network in DistributedDataParallel.
 """
 import ctypes as C
 

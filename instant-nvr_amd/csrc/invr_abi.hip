@@ -297,7 +297,7 @@ static int render_impl(const InvrScene* scene, const InvrModel* model,
     a.R = n_rays; a.S = n_samples; a.N = N;
 
     // fork: KNN index build (k_part_prepare, 5 workgroups, ~60 us) on a side stream beside the cull kernels
-    struct SideStream { hipStream_t side = nullptr; hipEvent_t fork = nullptr, join = nullptr, join2 = nullptr; };
+    struct SideStream { hipStream_t side = nullptr; hipEvent_t fork = nullptr, cells = nullptr, join = nullptr, join2 = nullptr; };
     static thread_local std::vector<SideStream> side_of_device;   // one per device this thread renders on (CPX mode: up to 64)
     int dev_id = 0;
     INVR_HIP(hipGetDevice(&dev_id));
@@ -309,16 +309,20 @@ static int render_impl(const InvrScene* scene, const InvrModel* model,
         INVR_HIP(hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming));
         INVR_HIP(hipEventCreateWithFlags(&ss.join, hipEventDisableTiming));
         INVR_HIP(hipEventCreateWithFlags(&ss.join2, hipEventDisableTiming));
+        INVR_HIP(hipEventCreateWithFlags(&ss.cells, hipEventDisableTiming));
     }
     hipStream_t side = ss.side;
-    hipEvent_t ev_fork = ss.fork, ev_join = ss.join, ev_join2 = ss.join2;
-    // cell mask of the distance volume + list of the cells that can hold a survivor (a few us): feeds both the cull (this
-    // stream) and the KNN's lattice classification (side stream)
+    hipEvent_t ev_fork = ss.fork, ev_cells = ss.cells, ev_join = ss.join, ev_join2 = ss.join2;
+    // fork: the KNN index build only needs the posed vertices — it starts at once on the side stream.  On this stream the cell
+    // mask of the distance volume + the list of the cells that can hold a survivor (a few us) feed both the cull (this stream)
+    // and the KNN's lattice classification (side stream, behind the index build)
     INVR_HIP(hipMemsetAsync(w.counters, 0, (CNT_ALLOC + (size_t)w.n_groups * INVR_NUM_PARTS) * sizeof(int32_t), st));
-    const bool have_cells = launch_cull_cells(a, w, st) != 0;
     INVR_HIP(hipEventRecord(ev_fork, st));
     INVR_HIP(hipStreamWaitEvent(side, ev_fork, 0));
     if (launch_knn_prepare(a, w, side)) return 1;
+    const bool have_cells = launch_cull_cells(a, w, st) != 0;
+    INVR_HIP(hipEventRecord(ev_cells, st));
+    INVR_HIP(hipStreamWaitEvent(side, ev_cells, 0));
     // ablation switches: the environment is read once per process, not per frame
     static const bool no_voxmask = getenv("INVR_NO_VOXMASK") != nullptr, no_voxcls = getenv("INVR_NO_VOXCLS") != nullptr,
                       no_merge = getenv("INVR_NO_MERGE") != nullptr;

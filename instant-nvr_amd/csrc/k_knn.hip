@@ -345,7 +345,8 @@ __device__ __forceinline__ void scan_sub16(const float4* sv, v2f px, v2f py, v2f
 #define KNN_T 1024
 #define KNN_LDS_MAX_V 8192          // float4 vertex slots (131 KB) + 11 record float4 per cluster must fit 160 KB
 
-#define KNN_LDS_FLOAT4 (KNN_LDS_MAX_V + (KNN_LDS_MAX_V / 64 + INVR_NUM_PARTS) * 11)
+#define KNN_LDS_HDR 8               // float4: the LDS carve table (offsets / lengths of the five parts)
+#define KNN_LDS_FLOAT4 (KNN_LDS_HDR + KNN_LDS_MAX_V + (KNN_LDS_MAX_V / 64 + INVR_NUM_PARTS) * 11)
 
 // Fallback when the posed vertex sets of the five parts do not fit the LDS-resident index together (> 8192 vertex slots, e.g.
 // SMPL-X): brute force per (survivor, part) over LDS tiles of the part's vertices — the arithmetic of k_knn_dense, the outputs of
@@ -434,7 +435,8 @@ extern "C" int invr_debug_knn_prof(unsigned long long* out, int reset) {
 __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w, int dbg) {
     // all LDS is dynamic (a static __shared__ in front would misalign the float4 region, guide G17): vertices, then cluster records
     extern __shared__ __attribute__((aligned(16))) float4 lds_raw[];
-    float4* lds = lds_raw;
+    float4* lds = lds_raw + KNN_LDS_HDR;
+    int* s_carve = reinterpret_cast<int*>(lds_raw);          // [voff | coff | soff | len] x 5: read per part by the (rolled) part loop
     const KnnIndex& ix = w.knn;
     KP_DECL
     // LDS carve from the (device-resident) part lengths: [vertices of part 0..4 | records of part 0..4]
@@ -452,6 +454,10 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w, 
         }
         for (int p = 0; p < INVR_NUM_PARTS; ++p) { L.coff[p] = off; off += (L.len[p] + 63) / 64 * 3; }
         for (int p = 0; p < INVR_NUM_PARTS; ++p) { L.soff[p] = off; off += (L.len[p] + 63) / 64 * 8; }
+        if (threadIdx.x == 0)
+            for (int p = 0; p < INVR_NUM_PARTS; ++p) {
+                s_carve[p] = L.voff[p]; s_carve[5 + p] = L.coff[p]; s_carve[10 + p] = L.soff[p]; s_carve[15 + p] = L.len[p];
+            }
     }
     // stage vertices and cluster records
     for (int p = 0; p < INVR_NUM_PARTS; ++p) {
@@ -491,10 +497,14 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w, 
                 vcell = ((int)ux * v.dy + (int)uy) * v.dz + (int)uz;
         }
         KP(1)
-#pragma unroll
+        // NOT unrolled: five copies of the classification + sweep made the kernel 70 KB of code — more than the 64 KB instruction
+        // cache two CUs share — and its waves, spread over the copies, stalled on instruction fetch
+#pragma unroll 1
         for (int p = 0; p < INVR_NUM_PARTS; ++p) {
             KP(2)
-            const int len = L.len[p];
+            const int len = __builtin_amdgcn_readfirstlane(s_carve[15 + p]);
+            const int L_voff = __builtin_amdgcn_readfirstlane(s_carve[p]), L_coff = __builtin_amdgcn_readfirstlane(s_carve[5 + p]),
+                      L_soff = __builtin_amdgcn_readfirstlane(s_carve[10 + p]);
             if (len < KNN_K) continue;                     // reference: inf distances -> NaN dist -> unflagged
             const unsigned c2 = vcell >= 0 ? ix.voxcls[(int64_t)vcell * INVR_NUM_PARTS + p] : 0u;
             if (__ballot(live && c2 == 0) == 0) {                   // every live lane sits in a decided cell
@@ -508,8 +518,8 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w, 
                 continue;
             }
             const int ncl = (len + 63) >> 6;
-            const float4* cl = lds + L.coff[p];                       // records {lo, hi, rep}
-            const float4* sv = lds + L.voff[p];
+            const float4* cl = lds + L_coff;                       // records {lo, hi, rep}
+            const float4* sv = lds + L_voff;
             // candidate clusters of the wave: OR of the lattice-cell masks of its undecided lanes (all ones when a lane is
             // outside the lattice, the masks are off or the part has more than 64 clusters).  Lanes in decided cells take the
             // cell's class and request nothing.
@@ -570,7 +580,7 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w, 
 #pragma unroll
                 for (int j = 0; j < KNN_K; ++j) t.k[j] = ph;
             }
-            const float4* sb = lds + L.soff[p];
+            const float4* sb = lds + L_soff;
             const v2f px2 = {px, px}, py2 = {py, py}, pz2 = {pz, pz};
             const int seed_c = __builtin_amdgcn_readlane(seed, __ffsll((long long)__ballot(scan)) - 1);
             if (full) {                                  // no bound to start from: the seed cluster is scanned unconditionally

@@ -4,6 +4,13 @@ Same constructor and ``render(batch, test=False, epoch=-1)`` signature and the s
 dict; the per-chunk Python loop, ``get_wsampling_points``, ``get_density_color``, the network
 forward and ``volume_rendering`` are one stream-ordered libinvr call over the whole ray list
 (chunk-free: HBM holds the full frame's intermediates).
+
+Train mode (``net.training`` and grad enabled) goes through autograd.TrainRenderFn — one fused HIP forward and one fused
+HIP backward — and returns the reference's training dict (rgb_map, acc_map, weights / z_vals, resd, tpts, tocc, oresd,
+distortion) with the large per-pair tensors materialised lazily (LazyTrainRet) plus two scalars the trainer prefers when
+present: ``offset_loss`` and ``pair_loss`` (the reference's means over resd / oresd, reduced on the device).  One deviation:
+``tpts`` of UNFLAGGED pairs is 0 here; the reference fills those rows with the warp of an all-zero blend (a value no loss
+or evaluator reads, inb_part_network_multiassign.py:105-120).
 """
 import ctypes as C
 
