@@ -51,17 +51,28 @@ struct Top4 {
 #pragma unroll
         for (int j = 0; j < KNN_K; ++j) k[j] = 0x7F80000000000000ull;
     }
-    // ONE (usually wave-skipped) branch, the shifting is predicated selects — a nested-branch insert
-    // costs ~10 scalar-ALU instructions per vertex and the CU has a single SALU
+    // Sorted insert as a min/max network on the keys READ AS DOUBLES: the high word of a key is the bit pattern of a non-negative
+    // float <= +inf, so every key is a finite non-negative double and doubles of that kind order like their bit patterns —
+    // v_min_f64 / v_max_f64 are 64-bit unsigned min / max here (fp64 denormals are on by default, no NaN pattern can occur).
+    // 7 full-rate instructions, no compare, no select, no branch; the compare-and-select form was 5 v_cmp_u64 + 14 v_cndmask
+    // + wait states per insert and made the inserts the largest item of the sweep.
+    static __device__ __forceinline__ double kmin(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+    static __device__ __forceinline__ double kmax(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+    __device__ __forceinline__ void push_net(float v, int idx) {
+        double x = __longlong_as_double((long long)(((unsigned long long)__float_as_uint(v) << 32) | (unsigned)idx));
+        const double k0 = __longlong_as_double((long long)k[0]), k1 = __longlong_as_double((long long)k[1]),
+                     k2 = __longlong_as_double((long long)k[2]), k3 = __longlong_as_double((long long)k[3]);
+        const double n0 = kmin(k0, x); x = kmax(k0, x);
+        const double n1 = kmin(k1, x); x = kmax(k1, x);
+        const double n2 = kmin(k2, x); x = kmax(k2, x);
+        const double n3 = kmin(k3, x);
+        k[0] = (unsigned long long)__double_as_longlong(n0); k[1] = (unsigned long long)__double_as_longlong(n1);
+        k[2] = (unsigned long long)__double_as_longlong(n2); k[3] = (unsigned long long)__double_as_longlong(n3);
+    }
+    // guarded form for the brute-force kernels (most vertices fail the guard: one compare, usually wave-skipped branch)
     __device__ __forceinline__ void push(float v, int idx) {
         const unsigned long long key = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)idx;
-        if (key < k[3]) {
-            const bool c2 = key < k[2], c1 = key < k[1], c0 = key < k[0];
-            k[3] = c2 ? k[2] : key;
-            k[2] = c1 ? k[1] : (c2 ? key : k[2]);
-            k[1] = c0 ? k[0] : (c1 ? key : k[1]);
-            k[0] = c0 ? key : k[0];
-        }
+        if (key < k[3]) push_net(v, idx);
     }
     __device__ __forceinline__ float worst() const { return __uint_as_float((unsigned)(k[3] >> 32)); }
     __device__ __forceinline__ void finish() {
@@ -330,8 +341,8 @@ __device__ __forceinline__ void scan_sub16(const float4* sv, v2f px, v2f py, v2f
             const v2f dx = px - (v2f){A[k].x, A[k].y}, dy = py - (v2f){A[k].z, A[k].w}, dz = pz - (v2f){B[k].x, B[k].y};
             const v2f d2 = (dx * dx + dy * dy) + dz * dz;
             if (fminf(d2.x, d2.y) <= t.worst()) {
-                t.push(d2.x, __float_as_int(B[k].z));
-                t.push(d2.y, __float_as_int(B[k].w));
+                t.push_net(d2.x, __float_as_int(B[k].z));
+                t.push_net(d2.y, __float_as_int(B[k].w));
             }
         }
     }
