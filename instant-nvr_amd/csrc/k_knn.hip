@@ -162,6 +162,27 @@ int launch_knn_blend_dense(const SceneDev& s, const float* pose_pts, int64_t n, 
     return 0;
 }
 
+// Phase timers of k_knn_pairs (tools/knn_phase_prof.sh builds a second library with -DKNN_PROF; not part of libinvr.so)
+#ifdef KNN_PROF
+__device__ unsigned long long g_knn_prof[32];
+extern "C" int invr_debug_knn_prof(unsigned long long* out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_knn_prof), sizeof(g_knn_prof)) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_knn_prof), z, sizeof(z)) != hipSuccess) return 1; }
+    return 0;
+}
+#define KP_DECL long long kp_t0 = clock64(); long long kp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define KP(i) { const long long kp_now = clock64(); kp_acc[i] += kp_now - kp_t0; kp_t0 = kp_now; }
+#define KP_CNT(i) { kp_acc[i] += 1; }
+#define KP_FLUSH if ((threadIdx.x & 63) == 0) { for (int kp_i = 0; kp_i < 12; ++kp_i) atomicAdd(&g_knn_prof[kp_i], (unsigned long long)kp_acc[kp_i]); }
+#define KP_FLUSH_AT(base) if (threadIdx.x == 0 && blockIdx.x == 0) { for (int kp_i = 0; kp_i < 12; ++kp_i) atomicAdd(&g_knn_prof[(base) + kp_i], (unsigned long long)kp_acc[kp_i]); }
+#else
+#define KP_DECL
+#define KP(i)
+#define KP_CNT(i)
+#define KP_FLUSH
+#define KP_FLUSH_AT(base)
+#endif
+
 // ---- per-frame prepare: Morton sort + clusters ------------------------------------------------------
 #define PREP_T 1024
 #define PREP_MAX 8192
@@ -183,6 +204,7 @@ __global__ __launch_bounds__(PREP_T) void k_part_prepare(SceneDev s, KnnIndex ix
     const int len = min((int)s.lengths2[p], PREP_MAX);
     const float* v = s.part_pts + (int64_t)p * s.M * 3;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    KP_DECL
     // 1. part AABB
     float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
     float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
@@ -201,6 +223,7 @@ __global__ __launch_bounds__(PREP_T) void k_part_prepare(SceneDev s, KnnIndex ix
     if (threadIdx.x == 0)
 #pragma unroll
         for (int a = 0; a < 3; ++a) { ix.part_aabb[p * 6 + a] = lo[a]; ix.part_aabb[p * 6 + 3 + a] = hi[a]; }
+    KP(0)
     // 2. Morton keys (6 bits / axis) | original index (13 bits)
     for (int j = threadIdx.x; j < len; j += PREP_T) {
         unsigned key = 0xFFFFFFFFu;
@@ -218,8 +241,9 @@ __global__ __launch_bounds__(PREP_T) void k_part_prepare(SceneDev s, KnnIndex ix
         keys[j] = key;
     }
     __syncthreads();
+    KP(1)
     // 3. sort by key: counting sort on the 12 leading Morton bits (4096 buckets for <= 8192 vertices: ~1 vertex per bucket),
-    //    then every bucket is put in key order by one thread.  (A 1024-thread bitonic sort of 4096 keys needs 78
+    //    then every element takes its rank inside its bucket.  (A 1024-thread bitonic sort of 4096 keys needs 78
     //    barrier-separated passes: 40 of this kernel's 70 us, and the kernel is the head of the frame's critical path for
     //    small frames / ray shards.)  The result is the same total order: keys are unique (they end in the vertex index).
     {
@@ -251,20 +275,21 @@ __global__ __launch_bounds__(PREP_T) void k_part_prepare(SceneDev s, KnnIndex ix
             sorted[atomicAdd(&hist[key >> 19], 1u)] = key;
         }
         __syncthreads();
-        // order inside the buckets: thread b owns bucket b = [end(b-1), end(b))
-        for (int b = threadIdx.x; b < 4096; b += PREP_T) {
+        // order inside the buckets: every element finds its rank among the keys of its own bucket [end(b-1), end(b)) — a few
+        // independent LDS reads per thread.  (One thread insertion-sorting a whole bucket was a serial chain of dependent LDS
+        // round trips on the fullest bucket — the vertices lie on a surface, occupied buckets hold up to ~30 — and 70 % of this
+        // kernel, which heads the frame's critical path for small frames / ray shards.)
+        for (int j = threadIdx.x; j < len; j += PREP_T) {
+            const unsigned key = sorted[j];
+            const unsigned b = key >> 19;
             const int lo_b = b ? (int)hist[b - 1] : 0, hi_b = (int)hist[b];
-            for (int i = lo_b + 1; i < hi_b; ++i) {
-                const unsigned key = sorted[i];
-                int q = i - 1;
-                while (q >= lo_b && sorted[q] > key) { sorted[q + 1] = sorted[q]; --q; }
-                sorted[q + 1] = key;
-            }
+            int rank = 0;
+            for (int q = lo_b; q < hi_b; ++q) rank += sorted[q] < key ? 1 : 0;
+            keys[lo_b + rank] = key;
         }
         __syncthreads();
-        for (int j = threadIdx.x; j < len; j += PREP_T) keys[j] = sorted[j];
-        __syncthreads();
     }
+    KP(2)
     // 4. sorted vertices, pair-interleaved {x0,x1,y0,y1} {z0,z1,row0,row1} (packed-fp32 distance math reads
     //    two vertices per register pair), clusters of 64 and their four 16-vertex sub-clusters
     const int64_t voff = (int64_t)p * ix.mpad;
@@ -278,6 +303,7 @@ __global__ __launch_bounds__(PREP_T) void k_part_prepare(SceneDev s, KnnIndex ix
         float* b = svf + (j >> 1) * 8 + (j & 1);
         b[0] = x; b[2] = y; b[4] = z; b[6] = __int_as_float(o);
     }
+    KP(3)
     const int ncl = (len + 63) >> 6;
     for (int c = wv; c < ncl; c += PREP_T / 64) {
         int j = c * 64 + lane;
@@ -307,6 +333,9 @@ __global__ __launch_bounds__(PREP_T) void k_part_prepare(SceneDev s, KnnIndex ix
             ix.cl[co * 3 + 2] = make_float4(x[0], x[1], x[2], 0.f);     // lane 0 = first vertex of the cluster
         }
     }
+    KP(4)
+    KP_CNT(8)
+    KP_FLUSH_AT(16)
 }
 
 // wave-uniform 16-byte LDS read that stays a ds_read_b128 (256 B/clk): when .w is unused the compiler narrows
@@ -417,25 +446,6 @@ __device__ void knn_pairs_bf(const RenderArgs& a, const Workspace& w, float4* sv
 }
 
 struct KnnLds { int voff[INVR_NUM_PARTS], coff[INVR_NUM_PARTS], soff[INVR_NUM_PARTS], len[INVR_NUM_PARTS]; };
-
-// Phase timers of k_knn_pairs (tools/knn_phase_prof.sh builds a second library with -DKNN_PROF; not part of libinvr.so)
-#ifdef KNN_PROF
-__device__ unsigned long long g_knn_prof[16];
-extern "C" int invr_debug_knn_prof(unsigned long long* out, int reset) {
-    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_knn_prof), sizeof(g_knn_prof)) != hipSuccess) return 1;
-    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_knn_prof), z, sizeof(z)) != hipSuccess) return 1; }
-    return 0;
-}
-#define KP_DECL long long kp_t0 = clock64(); long long kp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#define KP(i) { const long long kp_now = clock64(); kp_acc[i] += kp_now - kp_t0; kp_t0 = kp_now; }
-#define KP_CNT(i) { kp_acc[i] += 1; }
-#define KP_FLUSH if ((threadIdx.x & 63) == 0) { for (int kp_i = 0; kp_i < 12; ++kp_i) atomicAdd(&g_knn_prof[kp_i], (unsigned long long)kp_acc[kp_i]); }
-#else
-#define KP_DECL
-#define KP(i)
-#define KP_CNT(i)
-#define KP_FLUSH
-#endif
 
 // Outputs per survivor slot: pflags / farflags bytes and, for every flagged part, the 4 neighbour rows and weights at
 // l_nn[p][slot] / l_w[p][slot]; k_pair_lists then builds the dense per-part lists of flagged slots.  (The lists used to be

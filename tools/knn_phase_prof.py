@@ -43,7 +43,7 @@ with torch.no_grad():
     for _ in range(args.frames):
         rend.render(gb)
     torch.cuda.synchronize()
-buf = (C.c_ulonglong * 16)()
+buf = (C.c_ulonglong * 32)()
 assert fn(buf, 0) == 0
 v = [int(x) for x in buf]
 names = ['0 ticket + barrier', '1 sample point, lattice cell', '2 part classification', '3 sweep', '4 top-4 finish + weights', '5 list append', '6 LDS staging (once per workgroup)']
@@ -54,3 +54,7 @@ tot = sum(v[:6])
 for i, n in enumerate(names):
     print('%-38s %10.0f cycles / wave-tile  %5.1f %%' % (n, v[i] / tiles, 100.0 * v[i] / max(tot + v[6], 1)))
 print('total per wave-tile %.0f cycles (s_memtime ticks: 100 MHz constant clock on gfx9 -> x10 ns)' % (tot / tiles))
+
+n = max(v[16 + 8], 1)
+print('k_part_prepare (workgroup 0 = part 0), cycles per launch: AABB %.0f  keys %.0f  sort %.0f  vertex write %.0f  cluster records %.0f'
+      % tuple(v[16 + i] / n for i in range(5)))
