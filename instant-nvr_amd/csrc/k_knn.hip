@@ -205,12 +205,21 @@ __global__ __launch_bounds__(PREP_T) void k_part_prepare(SceneDev s, KnnIndex ix
     const float* v = s.part_pts + (int64_t)p * s.M * 3;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     KP_DECL
-    // 1. part AABB
+    // 1. part AABB (the thread's <= 8 vertices stay in registers for step 2: one global round trip instead of two)
     float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
     float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
-    for (int j = threadIdx.x; j < len; j += PREP_T)
+    float vr[PREP_MAX / PREP_T][3];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], v[j * 3 + a]); hi[a] = fmaxf(hi[a], v[j * 3 + a]); }
+    for (int k = 0; k < PREP_MAX / PREP_T; ++k) {
+        const int j = threadIdx.x + k * PREP_T;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) vr[k][a] = j < len ? v[j * 3 + a] : 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < PREP_MAX / PREP_T; ++k)
+        if (threadIdx.x + k * PREP_T < len)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], vr[k][a]); hi[a] = fmaxf(hi[a], vr[k][a]); }
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         for (int d = 32; d >= 1; d >>= 1) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], d)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], d)); }
@@ -225,20 +234,20 @@ __global__ __launch_bounds__(PREP_T) void k_part_prepare(SceneDev s, KnnIndex ix
         for (int a = 0; a < 3; ++a) { ix.part_aabb[p * 6 + a] = lo[a]; ix.part_aabb[p * 6 + 3 + a] = hi[a]; }
     KP(0)
     // 2. Morton keys (6 bits / axis) | original index (13 bits)
-    for (int j = threadIdx.x; j < len; j += PREP_T) {
-        unsigned key = 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 0; k < PREP_MAX / PREP_T; ++k) {
+        const int j = threadIdx.x + k * PREP_T;
         if (j < len) {
             unsigned q[3];
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 float e = hi[a] - lo[a];
-                float u = e > 0.f ? (v[j * 3 + a] - lo[a]) / e : 0.f;
+                float u = e > 0.f ? (vr[k][a] - lo[a]) / e : 0.f;
                 q[a] = (unsigned)fminf(fmaxf(u * 64.0f, 0.0f), 63.0f);
             }
             unsigned m = (spread6(q[0]) << 2) | (spread6(q[1]) << 1) | spread6(q[2]);
-            key = (m << 13) | (unsigned)j;
+            keys[j] = (m << 13) | (unsigned)j;
         }
-        keys[j] = key;
     }
     __syncthreads();
     KP(1)
@@ -811,7 +820,15 @@ __global__ __launch_bounds__(128) void k_knn_voxel_class(SceneDev s, KnnIndex ix
                 float k3 = __builtin_inff();
                 float b0 = __builtin_inff(), b1 = b0, b2 = b0;          // the three sub-clusters with the smallest farthest-corner distance
                 int i0 = -1, i1 = -1, i2 = -1;
-                for (int c = 0; c < ncl; ++c)
+                for (int c = 0; c < ncl; ++c) {
+                    // a sub-cluster's farthest-corner distance is at least the centre's distance to the cluster box: clusters beyond
+                    // the current third-best cannot enter (same selection, ~4x fewer sub-cluster evaluations: this loop was the
+                    // longest serial chain of the kernel, which is latency-bound at 13 % VALU busy)
+                    const float4 klo = s_cl[c * 3], khi = s_cl[c * 3 + 1];
+                    const float qx = fmaxf(fmaxf(klo.x - ce[0], ce[0] - khi.x), 0.0f);
+                    const float qy = fmaxf(fmaxf(klo.y - ce[1], ce[1] - khi.y), 0.0f);
+                    const float qz = fmaxf(fmaxf(klo.z - ce[2], ce[2] - khi.z), 0.0f);
+                    if (qx * qx + qy * qy + qz * qz >= b2) continue;
                     for (int s4 = 0; s4 < 4; ++s4) {
                         if (len - (c * 64 + s4 * 16) < KNN_K) continue;
                         const float4 slo = s_sub[c * 8 + s4 * 2], shi = s_sub[c * 8 + s4 * 2 + 1];
@@ -827,6 +844,7 @@ __global__ __launch_bounds__(128) void k_knn_voxel_class(SceneDev s, KnnIndex ix
                             if (b1 < b0) { const float tf = b0; b0 = b1; b1 = tf; const int ti = i0; i0 = i1; i1 = ti; }
                         }
                     }
+                }
                 {   // tighten: the 4th-smallest exact distance among the (up to 48) vertices of those three sub-clusters is still an
                     // upper bound of the 4th-nearest distance from the centre, usually the exact one
                     float e0 = __builtin_inff(), e1 = e0, e2 = e0, e3 = e0;
