@@ -526,6 +526,22 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w, 
             if (ux >= 0.0f && uy >= 0.0f && uz >= 0.0f && ux <= (float)(v.dx - 1) && uy <= (float)(v.dy - 1) && uz <= (float)(v.dz - 1))
                 vcell = ((int)ux * v.dy + (int)uy) * v.dz + (int)uz;
         }
+        // the cell's records of all five parts in ONE round trip (15 independent loads): the classes were written by the kernel
+        // that ran just before this one on another XCD's L2, so a wave's first ticket misses all the way to memory — and fetched
+        // part by part inside the loop that was up to 15 DEPENDENT misses (a 1/8 shard has ~1 ticket per wave: 45 % of its
+        // kernel time).  Class 0 = the cell was never classified (not live; a survivor on a cell face can land there): its
+        // mask / bound are stale and are not used; class 3 = classified, undecided.
+        unsigned cell_cls[INVR_NUM_PARTS];
+        unsigned long long cell_mask[INVR_NUM_PARTS];
+        float cell_u2[INVR_NUM_PARTS];
+#pragma unroll
+        for (int p = 0; p < INVR_NUM_PARTS; ++p) {
+            cell_cls[p] = 0u; cell_mask[p] = ~0ull; cell_u2[p] = __builtin_inff();
+            if (vcell >= 0) {
+                cell_cls[p] = ix.voxcls[(int64_t)vcell * INVR_NUM_PARTS + p];
+                if (ix.voxmask) { cell_mask[p] = ix.voxmask[(int64_t)vcell * INVR_NUM_PARTS + p]; cell_u2[p] = ix.voxu2[(int64_t)vcell * INVR_NUM_PARTS + p]; }
+            }
+        }
         KP(1)
         // NOT unrolled: five copies of the classification + sweep made the kernel 70 KB of code — more than the 64 KB instruction
         // cache two CUs share — and its waves, spread over the copies, stalled on instruction fetch
@@ -536,8 +552,10 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w, 
             const int L_voff = __builtin_amdgcn_readfirstlane(s_carve[p]), L_coff = __builtin_amdgcn_readfirstlane(s_carve[5 + p]),
                       L_soff = __builtin_amdgcn_readfirstlane(s_carve[10 + p]);
             if (len < KNN_K) continue;                     // reference: inf distances -> NaN dist -> unflagged
-            const unsigned c2 = vcell >= 0 ? ix.voxcls[(int64_t)vcell * INVR_NUM_PARTS + p] : 0u;
-            if (__ballot(live && c2 == 0) == 0) {                   // every live lane sits in a decided cell
+            // (p is wave-uniform: the selects below are four scalar-conditioned moves per value)
+            const unsigned c2 = p == 0 ? cell_cls[0] : p == 1 ? cell_cls[1] : p == 2 ? cell_cls[2] : p == 3 ? cell_cls[3] : cell_cls[4];
+            const bool undecided = c2 == 0u || c2 == 3u;
+            if (__ballot(live && undecided) == 0) {                 // every live lane sits in a decided cell
                 if (c2 == 1) farflags |= 1u << p;
                 continue;
             }
@@ -553,9 +571,10 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w, 
             // candidate clusters of the wave: OR of the lattice-cell masks of its undecided lanes (all ones when a lane is
             // outside the lattice, the masks are off or the part has more than 64 clusters).  Lanes in decided cells take the
             // cell's class and request nothing.
-            const bool maybe = live && c2 == 0;
+            const bool maybe = live && undecided;
             unsigned long long mym = 0ull;
-            if (maybe) mym = (ix.voxmask && vcell >= 0) ? ix.voxmask[(int64_t)vcell * INVR_NUM_PARTS + p] : ~0ull;
+            if (maybe && c2 == 3u) mym = p == 0 ? cell_mask[0] : p == 1 ? cell_mask[1] : p == 2 ? cell_mask[2] : p == 3 ? cell_mask[3] : cell_mask[4];
+            else if (maybe) mym = ~0ull;
             unsigned mlo = (unsigned)mym, mhi = (unsigned)(mym >> 32);
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) { mlo |= __shfl_xor(mlo, d); mhi |= __shfl_xor(mhi, d); }
@@ -606,7 +625,7 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w, 
             if (!full && scan) {
                 // lattice cell bound: at least 4 vertices of the part lie within sqrt(u2) of every point of the cell, so four
                 // placeholder entries (u2, row 0xFFFFFFFF) prune from the first vertex on and are all evicted by real ones
-                const unsigned long long ph = ((unsigned long long)__float_as_uint(ix.voxu2[(int64_t)vcell * INVR_NUM_PARTS + p]) << 32) | 0xFFFFFFFFull;
+                const unsigned long long ph = ((unsigned long long)__float_as_uint(p == 0 ? cell_u2[0] : p == 1 ? cell_u2[1] : p == 2 ? cell_u2[2] : p == 3 ? cell_u2[3] : cell_u2[4]) << 32) | 0xFFFFFFFFull;
 #pragma unroll
                 for (int j = 0; j < KNN_K; ++j) t.k[j] = ph;
             }
@@ -807,7 +826,7 @@ __global__ __launch_bounds__(128) void k_knn_voxel_class(SceneDev s, KnnIndex ix
             if (lb2 > KNN_DFAR2) pc = 1;
             else if (lb2 >= s.near_hi2 && ub2 <= s.band_lo2) pc = 2;
         }
-        ix.voxcls[(int64_t)idx * INVR_NUM_PARTS + p] = (uint8_t)pc;
+        ix.voxcls[(int64_t)idx * INVR_NUM_PARTS + p] = (uint8_t)(pc ? pc : 3u);      // 3 = classified, undecided (0 = never classified)
         if (ix.voxmask) {
             // undecided cell: which clusters can hold one of the 4 nearest vertices of ANY point x of the cell?  d4(x) <=
             // D4(centre) + h, so only clusters whose box comes within that of the cell box; the cluster of x's nearest

@@ -38,7 +38,7 @@ struct KnnIndex {
     unsigned long long* voxmask;  // per lattice cell and part: bit c set if cluster c can hold one of the 4 nearest vertices of a
                          //            point of the cell (undecided cells of parts with <= 64 clusters; all ones otherwise); NULL = off
     float* voxu2;        // per (lattice cell, part): squared upper bound of the 4th-nearest distance of any point of the cell
-    uint8_t* voxcls;     // per (lattice cell, part): 0 undecided, 1 far, 2 unflagged; NULL = off
+    uint8_t* voxcls;     // per (lattice cell, part): 0 never classified (mask / bound stale), 1 far, 2 unflagged, 3 undecided; NULL = off
     int32_t* live_cells; // lattice cells with a corner below the cull threshold (k_cull_cells; count in counters[CNT_LIVE])
     float4* vmat;        // P*mpad*6 : per vertex, rows 0..2 of sum_j pbw[v][j] A_j and of sum_j pbw[v][j] big_A_j
     int32_t mpad, cpad;
