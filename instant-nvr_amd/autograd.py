@@ -500,11 +500,11 @@ class TrainRenderFn(torch.autograd.Function):
         if reducer is None:
             run(_abi.BWD_ALL)
         else:
-            # data parallel: the largest gradient blocks first, each part's all-reduce starts as soon as its kernels are enqueued
-            # and runs on the collective's own stream beside the rest of the backward (dist_train.GradReducer)
-            run(_abi.BWD_HEAD)
+            # data parallel: the five parts' chains run side by side inside ONE call (library-owned streams); their row-scalar
+            # gradients — the large blocks, largest first — are then all-reduced on the collective's own stream beside the
+            # deformer stage of the backward, the small tensors after it (dist_train.GradReducer)
+            run(_abi.BWD_ALL & ~_abi.BWD_DEFORMER)
             for p in reducer.part_order:
-                run(2 << p)
                 reducer.reduce_part(p)
             run(_abi.BWD_DEFORMER)
             reducer.reduce_small()

@@ -262,6 +262,23 @@ static PartMlpDev make_part_mlp(const InvrModel* m, int p, const int64_t* latent
     return pm;
 }
 
+// library-owned streams for the five per-part chains of the training forward / backward (one set per device and host thread)
+struct PartStreams { hipStream_t s[INVR_NUM_PARTS] = {}; hipEvent_t fork = nullptr, done[INVR_NUM_PARTS] = {}; };
+static PartStreams* part_streams() {
+    static thread_local std::vector<PartStreams> of_device;
+    int dev_id = 0;
+    if (hipGetDevice(&dev_id) != hipSuccess || dev_id < 0 || dev_id >= 4096) { invr_set_error("invr: bad device index"); return nullptr; }
+    if ((size_t)dev_id >= of_device.size()) of_device.resize((size_t)dev_id + 1);
+    PartStreams& ps = of_device[dev_id];
+    if (!ps.fork) {
+        if (hipEventCreateWithFlags(&ps.fork, hipEventDisableTiming) != hipSuccess) { invr_set_error("invr: event creation failed"); return nullptr; }
+        for (int p = 0; p < INVR_NUM_PARTS; ++p)
+            if (hipStreamCreateWithFlags(&ps.s[p], hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&ps.done[p], hipEventDisableTiming) != hipSuccess) { invr_set_error("invr: stream creation failed"); return nullptr; }
+    }
+    return &ps;
+}
+
 static int render_impl(const InvrScene* scene, const InvrModel* model,
                        const float* ray_o, const float* ray_d, const float* near, const float* far,
                        const float* jitter, const float* wpts, const float* wdirs, int64_t n_rays, int32_t n_samples,
@@ -367,6 +384,8 @@ static int render_impl(const InvrScene* scene, const InvrModel* model,
         { ProfStage ps(INVR_STAGE_ENCODE, st); if (launch_part_encode_all(ea, st)) return 1; }
         { ProfStage ps(INVR_STAGE_MLP, st); if (launch_part_mlp_all(ma, st)) return 1; }
     }
+    // per-part launches (training forward on the 64-byte rows, eval without row sums).  (Running the five encoder -> MLP chains
+    // on separate streams, as the backward does, was measured: no gain — the forward launches are short.)
     for (int p = 0; p < INVR_NUM_PARTS && !geometry_only && !merged; ++p) {
         float* emb = w.emb[p];
         {
@@ -632,10 +651,9 @@ static size_t carve_train(TrainWs& t, void* base, size_t off0, int64_t N, int64_
     t.g_w = c.take<float>(N);
     t.g_rawfull = c.take<float4>(N);
     t.g_raws = c.take<float4>(lcap * INVR_NUM_PARTS);
-    t.g_emb = c.take<float>(lcap * EMB_K);
+    for (int p = 0; p < INVR_NUM_PARTS; ++p) t.g_emb[p] = c.take<float>(lcap * EMB_K);
     for (int p = 0; p < INVR_NUM_PARTS; ++p) t.g_x[p] = c.take<float>(lcap * 3);
-    t.gz = c.take<float>(lcap * 5 * 64);
-    t.a = c.take<float>(lcap * 5 * 72);
+    for (int p = 0; p < INVR_NUM_PARTS; ++p) { t.gz[p] = c.take<float>(lcap * 5 * 64); t.a[p] = c.take<float>(lcap * 5 * 72); }
     t.d_pts = c.take<float>(t.DM * 3);
     t.d_g = c.take<float>(t.DM * 3);
     t.d_uvt = c.take<float>(t.DM * 3);
@@ -745,9 +763,21 @@ extern "C" int invr_train_bwd(const InvrScene* scene, const InvrModel* model, in
         INVR_LAUNCH_CHECK();
     }
     }
-    // per part: MLPs^T -> weight gradients -> encoder^T
+    // per part: MLPs^T -> weight gradients -> encoder^T.  The five chains are independent (own scratch, own gradient tensors) and
+    // each is a handful of latency-bound launches (a part's 1e4-5e4 pairs do not fill the chip: 115 us per MLP^T launch whatever
+    // the pair count), so with more than one part in the call they run on library-owned streams side by side.
+    int n_parts = 0;
+    for (int p = 0; p < INVR_NUM_PARTS; ++p) n_parts += (stages & INVR_BWD_PART(p)) ? 1 : 0;
+    PartStreams* ps = nullptr;
+    if (n_parts > 1) {
+        ps = part_streams();
+        if (!ps) return 1;
+        INVR_HIP(hipEventRecord(ps->fork, st));
+    }
     for (int p = 0; p < INVR_NUM_PARTS; ++p) {
         if (!(stages & INVR_BWD_PART(p))) continue;
+        hipStream_t sp = ps ? ps->s[p] : st;
+        if (ps) INVR_HIP(hipStreamWaitEvent(sp, ps->fork, 0));
         const InvrPartGrads& G = grads->part[p];
         PartMlpDev pm = make_part_mlp(model, p, scene->latent_index);
         const int n_rgb = pm.rgb.n_linear;
@@ -757,13 +787,17 @@ extern "C" int invr_train_bwd(const InvrScene* scene, const InvrModel* model, in
                    pm.rgb.dims[0] == 70 && pm.rgb.dims[1] == 64 && pm.rgb.dims[n_rgb] == 3 && pm.n_freq == 4 && pm.latent_dim == 8 && pm.geo_dim == 16,
                    "invr_train_bwd: supports occ 19-64-17 and rgb 70-64(-64)-3");
         const int32_t* count = w.counters + CNT_PAIRS + p;
-        MlpBwdOut o{t.g_emb, t.gz, t.a, lcap, G.rgb_latent, 1};
-        if (launch_part_mlp_bwd(pm, w.emb[p], w.l_d[p], lcap, lcap, count, reinterpret_cast<const float*>(t.g_raws), w.l_slot[p], p, o, st)) return 1;
+        MlpBwdOut o{t.g_emb[p], t.gz[p], t.a[p], lcap, G.rgb_latent, 1};
+        if (launch_part_mlp_bwd(pm, w.emb[p], w.l_d[p], lcap, lcap, count, reinterpret_cast<const float*>(t.g_raws), w.l_slot[p], p, o, sp)) return 1;
         float* dW[5] = {G.occ_w[0], G.occ_w[1], G.rgb_w[0], n_rgb == 3 ? G.rgb_w[1] : nullptr, G.rgb_w[n_rgb - 1]};
         float* db[5] = {G.occ_b[0], G.occ_b[1], G.rgb_b[0], n_rgb == 3 ? G.rgb_b[1] : nullptr, G.rgb_b[n_rgb - 1]};
-        if (launch_part_wgrad(t.gz, t.a, lcap, n_rgb, dW, db, count, st)) return 1;
+        if (launch_part_wgrad(t.gz[p], t.a[p], lcap, n_rgb, dW, db, count, sp)) return 1;
         GridDev g = make_grid_dev(&model->part[p].grid);
-        if (launch_part_encode_bwd_lists(g, w.l_x[p], t.g_emb, t.g_x[p], lcap, lcap, count, G.row_grad, st)) return 1;
+        if (launch_part_encode_bwd_lists(g, w.l_x[p], t.g_emb[p], t.g_x[p], lcap, lcap, count, G.row_grad, sp)) return 1;
+        if (ps) {
+            INVR_HIP(hipEventRecord(ps->done[p], sp));
+            INVR_HIP(hipStreamWaitEvent(st, ps->done[p], 0));
+        }
     }
     // deformer^T over the listed pairs and the pair-regulariser neighbours (needs the g_x of every part)
     if (!(stages & INVR_BWD_DEFORMER)) return 0;

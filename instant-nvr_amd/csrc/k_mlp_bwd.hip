@@ -40,6 +40,7 @@ __global__ __launch_bounds__(MLP_BLOCK, 1) void k_part_mlp_bwd(PartMlpDev pm, co
     // outputs have `stride` entries per row; g_raw is (n,4) or, with l_slot, the per-(slot, part) array the merge wrote
     const int64_t n = count ? (int64_t)*count : n_host;
     __shared__ float lds[LDS_FLOATS];
+    if ((int64_t)blockIdx.x * ((MLP_BLOCK / 64) * 16) >= n) return;       // (the grid is sized from an upper bound: no staging for nothing)
     stage_weights<NRGB>(pm, lds);
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, col = lane & 15;

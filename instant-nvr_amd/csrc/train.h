@@ -14,9 +14,9 @@ struct TrainWs {
     float* g_w;            // N : gradient w.r.t. the compositing weights (distortion^T)
     float4* g_rawfull;     // N : gradient w.r.t. the merged per-sample raw
     float4* g_raws;        // lcap*P : gradient w.r.t. the per-(slot, part) raw
-    float* g_emb;          // 20*lcap : gradient w.r.t. the encoder output of the part being processed
+    float* g_emb[INVR_NUM_PARTS];   // 20*lcap each : gradient w.r.t. the part's encoder output (own buffers: the parts' chains run concurrently)
     float* g_x[INVR_NUM_PARTS];   // 3*lcap each, SoA : gradient w.r.t. the canonical point (encoder^T)
-    float* gz; float* a;   // (5, lcap, 64), (5, lcap, 72) : per-layer (output gradient, input) of the part being processed
+    float* gz[INVR_NUM_PARTS]; float* a[INVR_NUM_PARTS];   // (5, lcap, 64), (5, lcap, 72) per part : per-layer (output gradient, input)
     // deformer backward list: DM = P*lcap + NB entries
     float* d_pts; float* d_g; float* d_uvt; float* d_gfeat;       // (DM,3) (DM,3) (DM,3) (DM,19)
     float* d_gz1; float* d_gz2; float* d_gz3; float* d_a0; float* d_a1; float* d_a2;   // (DM,32) (DM,32) (DM,4) (DM,20) (DM,32) (DM,32)
