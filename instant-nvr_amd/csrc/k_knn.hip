@@ -778,39 +778,50 @@ __global__ __launch_bounds__(PL_BLOCK) void k_pair_lists(Workspace w, int32_t* _
 // (lower bound >= near_hi and some vertex within band_lo) — the same two tests k_knn_pairs applies per point, so a
 // definite cell class is exactly what the per-point classification would conclude; undecided cells (class 0) and
 // points outside the lattice run the per-point cluster loop.  17x fewer cells than survivors on the bench frame.
-__global__ __launch_bounds__(128) void k_knn_voxel_class(SceneDev s, KnnIndex ix, const int32_t* __restrict__ n_live_dev) {
+// Four lanes per (live cell, part): with one thread per item the kernel was a single latency-bound wave per SIMD (13 % VALU
+// busy, 50 us whatever the frame size, and on the critical path of small frames / ray shards: the KNN waits for it) — every
+// loop over the part's clusters is split over the quad and reduced with two shuffles; all reductions are order-independent
+// (min, OR, lexicographic (distance, id) top-3, the 4th-smallest of a multiset), so the classes, masks and bounds are the
+// one-thread kernel's bit for bit.
+#define VC_BLOCK 256
+#define VC_Q 4
+__device__ __forceinline__ float quad_min(float x) { x = fminf(x, __shfl_xor(x, 1)); return fminf(x, __shfl_xor(x, 2)); }
+
+__global__ __launch_bounds__(VC_BLOCK) void k_knn_voxel_class(SceneDev s, KnnIndex ix, const int32_t* __restrict__ n_live_dev) {
     const VolDev& v = s.pbw;
-    // cluster {lo, hi, rep} and sub-cluster {lo, hi} records of this block's part, staged once (wave-uniform reads below)
+    // the live cells — a corner below the cull threshold, 7 % of the lattice on the bench frame; all other cells are never looked
+    // up — were listed by k_cull_cells
+    const int n_live = n_live_dev[0];
+    const int per_block = VC_BLOCK / VC_Q;
+    if ((int)blockIdx.x * per_block >= n_live) return;
+    // cluster {lo, hi, rep} and sub-cluster {lo, hi} records of this block's part, staged once
     __shared__ float4 s_cl[(PREP_MAX / 64) * 3];
     __shared__ float4 s_sub[(PREP_MAX / 64) * 8];
-    {
-        const int pp = blockIdx.y, ncl_p = (min((int)s.lengths2[pp], PREP_MAX) + 63) >> 6;
-        for (int j = threadIdx.x; j < ncl_p * 3; j += blockDim.x) s_cl[j] = ix.cl[(int64_t)pp * ix.cpad * 3 + j];
-        for (int j = threadIdx.x; j < ncl_p * 8; j += blockDim.x) s_sub[j] = ix.sub[(int64_t)pp * ix.cpad * 8 + j];
-    }
+    const int p = blockIdx.y;
+    const int len = min((int)s.lengths2[p], PREP_MAX), ncl = (len + 63) >> 6;
+    for (int j = threadIdx.x; j < ncl * 3; j += VC_BLOCK) s_cl[j] = ix.cl[(int64_t)p * ix.cpad * 3 + j];
+    for (int j = threadIdx.x; j < ncl * 8; j += VC_BLOCK) s_sub[j] = ix.sub[(int64_t)p * ix.cpad * 8 + j];
     __syncthreads();
-    // one thread per (live cell, part): the live cells — a corner below the cull threshold, 7 % of the lattice on the bench
-    // frame; all other cells are never looked up — were listed by k_cull_cells
-    const int n_live = n_live_dev[0];
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_live; e += gridDim.x * blockDim.x) {
-    const int idx = ix.live_cells[e];
-    const int z0 = idx % v.dz, y0 = (idx / v.dz) % v.dy, x0 = idx / (v.dz * v.dy);
-    const int c0[3] = {x0, y0, z0}, dims[3] = {v.dx, v.dy, v.dz};
-    float lo[3], hi[3], ce[3], h2 = 0.0f;
+    const int q = threadIdx.x & (VC_Q - 1);
+    const int qbase = (threadIdx.x & 63) & ~(VC_Q - 1);            // lane of the quad's first thread inside its wave
+    for (int e = (int)blockIdx.x * per_block + (int)(threadIdx.x >> 2); e < n_live; e += (int)gridDim.x * per_block) {
+        const int idx = ix.live_cells[e];
+        const int z0 = idx % v.dz, y0 = (idx / v.dz) % v.dy, x0 = idx / (v.dz * v.dy);
+        const int c0[3] = {x0, y0, z0}, dims[3] = {v.dx, v.dy, v.dz};
+        float lo[3], hi[3], ce[3], h2 = 0.0f;
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const float b0 = v.bounds[a], e = v.bounds[3 + a] - b0, den = (float)(dims[a] - 1);
-        lo[a] = b0 + e * ((float)c0[a] / den) - 1e-4f;                        // inflated: the point -> cell map below is approximate
-        hi[a] = b0 + e * ((float)min(c0[a] + 1, dims[a] - 1) / den) + 1e-4f;
-        ce[a] = 0.5f * (lo[a] + hi[a]);
-        h2 += 0.25f * (hi[a] - lo[a]) * (hi[a] - lo[a]);
-    }
-    const float h = sqrtf(h2) * 1.0001f;
-    {
-        const int p = blockIdx.y;                       // one thread per (cell, part)
-        const int len = min((int)s.lengths2[p], PREP_MAX), ncl = (len + 63) >> 6;
+        for (int a = 0; a < 3; ++a) {
+            const float b0 = v.bounds[a], ext = v.bounds[3 + a] - b0, den = (float)(dims[a] - 1);
+            lo[a] = b0 + ext * ((float)c0[a] / den) - 1e-4f;                      // inflated: the point -> cell map of k_knn_pairs is approximate
+            hi[a] = b0 + ext * ((float)min(c0[a] + 1, dims[a] - 1) / den) + 1e-4f;
+            ce[a] = 0.5f * (lo[a] + hi[a]);
+            h2 += 0.25f * (hi[a] - lo[a]) * (hi[a] - lo[a]);
+        }
+        const float h = sqrtf(h2) * 1.0001f;
+        // bounds on the nearest-vertex distance of any point of the cell: box-to-box (lower), centre-to-representative + half
+        // diagonal (upper) — the two tests k_knn_pairs applies per point
         float lb2 = __builtin_inff(), ub2 = __builtin_inff();
-        for (int c = 0; c < ncl; ++c) {
+        for (int c = q; c < ncl; c += VC_Q) {
             const float4 klo = s_cl[c * 3], khi = s_cl[c * 3 + 1];
             const float4 rep = s_cl[c * 3 + 2];
             const float gx = fmaxf(fmaxf(klo.x - hi[0], lo[0] - khi.x), 0.0f);
@@ -821,101 +832,127 @@ __global__ __launch_bounds__(128) void k_knn_voxel_class(SceneDev s, KnnIndex ix
             const float u = sqrtf(dx * dx + dy * dy + dz * dz) + h;
             ub2 = fminf(ub2, u * u * 1.0001f);
         }
+        lb2 = quad_min(lb2);
+        ub2 = quad_min(ub2);
         unsigned pc = 0;
         if (len >= KNN_K) {
             if (lb2 > KNN_DFAR2) pc = 1;
             else if (lb2 >= s.near_hi2 && ub2 <= s.band_lo2) pc = 2;
         }
-        ix.voxcls[(int64_t)idx * INVR_NUM_PARTS + p] = (uint8_t)(pc ? pc : 3u);      // 3 = classified, undecided (0 = never classified)
-        if (ix.voxmask) {
-            // undecided cell: which clusters can hold one of the 4 nearest vertices of ANY point x of the cell?  d4(x) <=
-            // D4(centre) + h, so only clusters whose box comes within that of the cell box; the cluster of x's nearest
-            // vertex is always among them, so min-over-candidates of the per-point box bounds equals the min over all.
-            unsigned long long mask = ~0ull;
-            float u2_out = __builtin_inff();
-            if (pc == 0 && len >= KNN_K && ncl <= 64 && s.thresh < 1e8f) {      // (dense stress mode: every cell holds survivors, masks off)
-                // upper bound of the 4th-nearest distance from the cell centre: every 16-vertex sub-cluster box with >= 4 real
-                // vertices holds 4 vertices within the distance to its farthest corner
-                float k3 = __builtin_inff();
-                float b0 = __builtin_inff(), b1 = b0, b2 = b0;          // the three sub-clusters with the smallest farthest-corner distance
-                int i0 = -1, i1 = -1, i2 = -1;
-                for (int c = 0; c < ncl; ++c) {
-                    // a sub-cluster's farthest-corner distance is at least the centre's distance to the cluster box: clusters beyond
-                    // the current third-best cannot enter (same selection, ~4x fewer sub-cluster evaluations: this loop was the
-                    // longest serial chain of the kernel, which is latency-bound at 13 % VALU busy)
-                    const float4 klo = s_cl[c * 3], khi = s_cl[c * 3 + 1];
-                    const float qx = fmaxf(fmaxf(klo.x - ce[0], ce[0] - khi.x), 0.0f);
-                    const float qy = fmaxf(fmaxf(klo.y - ce[1], ce[1] - khi.y), 0.0f);
-                    const float qz = fmaxf(fmaxf(klo.z - ce[2], ce[2] - khi.z), 0.0f);
-                    if (qx * qx + qy * qy + qz * qz >= b2) continue;
-                    for (int s4 = 0; s4 < 4; ++s4) {
-                        if (len - (c * 64 + s4 * 16) < KNN_K) continue;
-                        const float4 slo = s_sub[c * 8 + s4 * 2], shi = s_sub[c * 8 + s4 * 2 + 1];
-                        const float fx = fmaxf(fabsf(ce[0] - slo.x), fabsf(ce[0] - shi.x));
-                        const float fy = fmaxf(fabsf(ce[1] - slo.y), fabsf(ce[1] - shi.y));
-                        const float fz = fmaxf(fabsf(ce[2] - slo.z), fabsf(ce[2] - shi.z));
-                        const float f2 = (fx * fx + fy * fy + fz * fz) * 1.0001f;
-                        k3 = fminf(k3, f2);
-                        const int id = c * 4 + s4;
-                        if (f2 < b2) {
-                            b2 = f2; i2 = id;
-                            if (b2 < b1) { const float tf = b1; b1 = b2; b2 = tf; const int ti = i1; i1 = i2; i2 = ti; }
-                            if (b1 < b0) { const float tf = b0; b0 = b1; b1 = tf; const int ti = i0; i0 = i1; i1 = ti; }
-                        }
-                    }
+        if (q == 0) ix.voxcls[(int64_t)idx * INVR_NUM_PARTS + p] = (uint8_t)(pc ? pc : 3u);      // 3 = classified, undecided (0 = never classified)
+        if (!ix.voxmask) continue;
+        // undecided cell: which clusters can hold one of the 4 nearest vertices of ANY point x of the cell?  d4(x) <=
+        // D4(centre) + h, so only clusters whose box comes within that of the cell box; the cluster of x's nearest
+        // vertex is always among them, so min-over-candidates of the per-point box bounds equals the min over all.
+        unsigned long long mask = ~0ull;
+        float u2_out = __builtin_inff();
+        if (pc == 0 && len >= KNN_K && ncl <= 64 && s.thresh < 1e8f) {      // (dense stress mode: every cell holds survivors, masks off)
+            // upper bound of the 4th-nearest distance from the cell centre: every 16-vertex sub-cluster box with >= 4 real
+            // vertices holds 4 vertices within the distance to its farthest corner.  The three sub-clusters with the smallest
+            // farthest-corner distance, ties to the smaller id: per lane over its clusters, then merged over the quad.
+            float b0 = __builtin_inff(), b1 = b0, b2 = b0;
+            int i0 = 0x7fffffff, i1 = i0, i2 = i0;
+            auto ins3 = [&](float f2, int id) {
+                if (f2 < b2 || (f2 == b2 && id < i2)) {
+                    b2 = f2; i2 = id;
+                    if (b2 < b1 || (b2 == b1 && i2 < i1)) { const float tf = b1; b1 = b2; b2 = tf; const int ti = i1; i1 = i2; i2 = ti; }
+                    if (b1 < b0 || (b1 == b0 && i1 < i0)) { const float tf = b0; b0 = b1; b1 = tf; const int ti = i0; i0 = i1; i1 = ti; }
                 }
-                {   // tighten: the 4th-smallest exact distance among the (up to 48) vertices of those three sub-clusters is still an
-                    // upper bound of the 4th-nearest distance from the centre, usually the exact one
-                    float e0 = __builtin_inff(), e1 = e0, e2 = e0, e3 = e0;
-                    const int ids[3] = {i0, i1, i2};
-                    for (int t3 = 0; t3 < 3; ++t3) {
-                        if (ids[t3] < 0) continue;
-                        // the 16 vertices of the sub-cluster = 8 pair records {x0,x1,y0,y1}{z0,z1,..}: all 16 loads are issued
-                        // before the first use (one L2 round trip per sub-cluster instead of one per vertex)
-                        const float4* rec = ix.sverts + (int64_t)p * ix.mpad + ids[t3] * 16;
-                        float4 ra[8], rb[8];
-#pragma unroll
-                        for (int m = 0; m < 8; ++m) { ra[m] = rec[2 * m]; rb[m] = rec[2 * m + 1]; }
-#pragma unroll
-                        for (int jj = 0; jj < 16; ++jj) {
-                            const float4 A = ra[jj >> 1], B = rb[jj >> 1];
-                            const float vx = (jj & 1) ? A.y : A.x, vy = (jj & 1) ? A.w : A.z, vz = (jj & 1) ? B.y : B.x;
-                            const float dx = ce[0] - vx, dy = ce[1] - vy, dz = ce[2] - vz;
-                            const float d = dx * dx + dy * dy + dz * dz;
-                            if (d < e3) {
-                                e3 = d;
-                                if (e3 < e2) { const float tf = e2; e2 = e3; e3 = tf; }
-                                if (e2 < e1) { const float tf = e1; e1 = e2; e2 = tf; }
-                                if (e1 < e0) { const float tf = e0; e0 = e1; e1 = tf; }
-                            }
-                        }
-                    }
-                    k3 = fminf(k3, e3 * 1.0001f);
-                }
-                const float u = sqrtf(k3) + h;
-                const float u2 = u * u * 1.0002f;
-                u2_out = u2;
-                mask = 0ull;
-                for (int c = 0; c < ncl; ++c) {
-                    const float4 klo = s_cl[c * 3], khi = s_cl[c * 3 + 1];
-                    const float gx = fmaxf(fmaxf(klo.x - hi[0], lo[0] - khi.x), 0.0f);
-                    const float gy = fmaxf(fmaxf(klo.y - hi[1], lo[1] - khi.y), 0.0f);
-                    const float gz = fmaxf(fmaxf(klo.z - hi[2], lo[2] - khi.z), 0.0f);
-                    if ((gx * gx + gy * gy + gz * gz) * 0.9999f <= u2) mask |= 1ull << c;
+            };
+            for (int c = q; c < ncl; c += VC_Q) {
+                // a sub-cluster's farthest-corner distance is at least the centre's distance to the cluster box: clusters beyond
+                // the lane's current third-best cannot enter
+                const float4 klo = s_cl[c * 3], khi = s_cl[c * 3 + 1];
+                const float qx = fmaxf(fmaxf(klo.x - ce[0], ce[0] - khi.x), 0.0f);
+                const float qy = fmaxf(fmaxf(klo.y - ce[1], ce[1] - khi.y), 0.0f);
+                const float qz = fmaxf(fmaxf(klo.z - ce[2], ce[2] - khi.z), 0.0f);
+                if (qx * qx + qy * qy + qz * qz > b2) continue;
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    if (len - (c * 64 + s4 * 16) < KNN_K) continue;
+                    const float4 slo = s_sub[c * 8 + s4 * 2], shi = s_sub[c * 8 + s4 * 2 + 1];
+                    const float fx = fmaxf(fabsf(ce[0] - slo.x), fabsf(ce[0] - shi.x));
+                    const float fy = fmaxf(fabsf(ce[1] - slo.y), fabsf(ce[1] - shi.y));
+                    const float fz = fmaxf(fabsf(ce[2] - slo.z), fabsf(ce[2] - shi.z));
+                    ins3((fx * fx + fy * fy + fz * fz) * 1.0001f, c * 4 + s4);
                 }
             }
+            {   // merge the four lanes' triples (every lane ends with the quad's three best)
+                const float mb[3] = {b0, b1, b2};
+                const int mi[3] = {i0, i1, i2};
+                b0 = b1 = b2 = __builtin_inff();
+                i0 = i1 = i2 = 0x7fffffff;
+#pragma unroll
+                for (int src = 0; src < VC_Q; ++src)
+#pragma unroll
+                    for (int t3 = 0; t3 < 3; ++t3) ins3(__shfl(mb[t3], qbase + src), __shfl(mi[t3], qbase + src));
+            }
+            float k3 = b0;                  // the smallest farthest-corner distance of any sub-cluster
+            {   // tighten: the 4th-smallest exact distance among the (up to 48) vertices of those three sub-clusters is still an
+                // upper bound of the 4th-nearest distance from the centre, usually the exact one.  Lane q takes vertices q, q+4, ..
+                float e0 = __builtin_inff(), e1 = e0, e2 = e0, e3 = e0;
+                auto ins4 = [&](float d) {
+                    if (d < e3) {
+                        e3 = d;
+                        if (e3 < e2) { const float tf = e2; e2 = e3; e3 = tf; }
+                        if (e2 < e1) { const float tf = e1; e1 = e2; e2 = tf; }
+                        if (e1 < e0) { const float tf = e0; e0 = e1; e1 = tf; }
+                    }
+                };
+                const int ids[3] = {i0, i1, i2};
+                float4 ra[3][4], rb[3][4];
+#pragma unroll
+                for (int t3 = 0; t3 < 3; ++t3) {
+                    // the lane's 4 vertices of the sub-cluster sit in pair records (q>>1) + 2m: all 24 loads are issued before the first use
+                    const float4* rec = ix.sverts + (int64_t)p * ix.mpad + (ids[t3] == 0x7fffffff ? 0 : ids[t3]) * 16;
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) { ra[t3][m] = rec[2 * ((q >> 1) + 2 * m)]; rb[t3][m] = rec[2 * ((q >> 1) + 2 * m) + 1]; }
+                }
+#pragma unroll
+                for (int t3 = 0; t3 < 3; ++t3) {
+                    if (ids[t3] == 0x7fffffff) continue;
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        const float4 A = ra[t3][m], B = rb[t3][m];
+                        const float vx = (q & 1) ? A.y : A.x, vy = (q & 1) ? A.w : A.z, vz = (q & 1) ? B.y : B.x;
+                        const float dx = ce[0] - vx, dy = ce[1] - vy, dz = ce[2] - vz;
+                        ins4(dx * dx + dy * dy + dz * dz);
+                    }
+                }
+                const float me[4] = {e0, e1, e2, e3};
+                e0 = e1 = e2 = e3 = __builtin_inff();
+#pragma unroll
+                for (int src = 0; src < VC_Q; ++src)
+#pragma unroll
+                    for (int t4 = 0; t4 < 4; ++t4) ins4(__shfl(me[t4], qbase + src));
+                k3 = fminf(k3, e3 * 1.0001f);
+            }
+            const float u = sqrtf(k3) + h;
+            const float u2 = u * u * 1.0002f;
+            u2_out = u2;
+            unsigned mlo = 0u, mhi = 0u;
+            for (int c = q; c < ncl; c += VC_Q) {
+                const float4 klo = s_cl[c * 3], khi = s_cl[c * 3 + 1];
+                const float gx = fmaxf(fmaxf(klo.x - hi[0], lo[0] - khi.x), 0.0f);
+                const float gy = fmaxf(fmaxf(klo.y - hi[1], lo[1] - khi.y), 0.0f);
+                const float gz = fmaxf(fmaxf(klo.z - hi[2], lo[2] - khi.z), 0.0f);
+                if ((gx * gx + gy * gy + gz * gz) * 0.9999f <= u2) { if (c < 32) mlo |= 1u << c; else mhi |= 1u << (c - 32); }
+            }
+            mlo |= __shfl_xor(mlo, 1); mlo |= __shfl_xor(mlo, 2);
+            mhi |= __shfl_xor(mhi, 1); mhi |= __shfl_xor(mhi, 2);
+            mask = ((unsigned long long)mhi << 32) | mlo;
+        }
+        if (q == 0) {
             ix.voxmask[(int64_t)idx * INVR_NUM_PARTS + p] = mask;
             ix.voxu2[(int64_t)idx * INVR_NUM_PARTS + p] = u2_out;
         }
-    }
     }
 }
 
 int launch_knn_voxel_class(const RenderArgs& a, const Workspace& w, hipStream_t st) {
     const VolDev& v = a.scene.pbw;
-    const int64_t cells = (int64_t)v.dx * v.dy * v.dz;
-    hipLaunchKernelGGL(k_knn_voxel_class, dim3((unsigned)(cells / 128 < 1024 ? cdiv(cells, 128) : 1024), INVR_NUM_PARTS), dim3(128), 0, st, a.scene, w.knn,
-                       w.counters + CNT_LIVE);
+    const int64_t cells = (int64_t)v.dx * v.dy * v.dz, items = VC_BLOCK / VC_Q;
+    hipLaunchKernelGGL(k_knn_voxel_class, dim3((unsigned)(cells / items < 2048 ? cdiv(cells, items) : 2048), INVR_NUM_PARTS), dim3(VC_BLOCK), 0, st,
+                       a.scene, w.knn, w.counters + CNT_LIVE);
     INVR_LAUNCH_CHECK();
     return 0;
 }
