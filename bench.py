@@ -490,7 +490,8 @@ def main():
                 'table_variant': '64-byte trainable rows (8192 B/pair)' if args.full_rows else 'inference row-sum tables (512 B/pair instead of 8192)',
                 'formula': '(%d + 512 + 64) B x evaluated pairs + 1920 B x survivors + (32%s) B x ray-samples + 48 B x rays (SURVEY 8d, rank 0 shard)'
                            % (tab_b, ' + 20' if want_raw else ''),
-                'traffic': (sum(traffic.values()) if traffic else None), 'traffic_source': traffic_src,
+                'traffic': (sum(v for k, v in traffic.items() if k != 'k_row_sums') if traffic else None),      # (the row-sum build runs once per weight version, not per frame)
+                'traffic_source': traffic_src,
                 'note': 'no kernel of the frame is HBM-bound any more (tables are L2 / Infinity-Cache resident through the row sums); the three large '
                         'kernels are VALU / MFMA issue bound — see roofline and roofline_other'},
             'stage_ms_per_step': {k: v / per for k, v in stage_ms.items()},

@@ -173,6 +173,9 @@ struct Carver {
     }
 };
 
+// counters + per-group pair counts, cleared by one memset per frame: a multiple of 256 bytes (an odd size splits the fill in two launches)
+static size_t counters_ints(int64_t n_groups) { return align_up((size_t)CNT_ALLOC + (size_t)n_groups * INVR_NUM_PARTS, 64); }
+
 #define KNN_MAX_PART 8192
 static size_t carve(Workspace& w, void* base, int64_t N, int64_t cap) {
     Carver c{(char*)base, 0};
@@ -181,7 +184,7 @@ static size_t carve(Workspace& w, void* base, int64_t N, int64_t cap) {
     const int64_t lc = cap + 1;          // list / slot capacity incl. the far-constant entry
     w.lcap = lc;
     w.n_groups = cdiv(lc, PAIR_GROUP);
-    w.counters = c.take<int32_t>(CNT_ALLOC + (size_t)w.n_groups * INVR_NUM_PARTS);
+    w.counters = c.take<int32_t>(counters_ints(w.n_groups));
     w.gcount = w.counters ? w.counters + CNT_ALLOC : nullptr;
     w.knn.part_aabb = c.take<float>(INVR_NUM_PARTS * 6);
     w.knn.mpad = KNN_MAX_PART;
@@ -333,7 +336,7 @@ static int render_impl(const InvrScene* scene, const InvrModel* model,
     // fork: the KNN index build only needs the posed vertices — it starts at once on the side stream.  On this stream the cell
     // mask of the distance volume + the list of the cells that can hold a survivor (a few us) feed both the cull (this stream)
     // and the KNN's lattice classification (side stream, behind the index build)
-    INVR_HIP(hipMemsetAsync(w.counters, 0, (CNT_ALLOC + (size_t)w.n_groups * INVR_NUM_PARTS) * sizeof(int32_t), st));
+    INVR_HIP(hipMemsetAsync(w.counters, 0, counters_ints(w.n_groups) * sizeof(int32_t), st));
     INVR_HIP(hipEventRecord(ev_fork, st));
     INVR_HIP(hipStreamWaitEvent(side, ev_fork, 0));
     if (launch_knn_prepare(a, w, side)) return 1;

@@ -238,9 +238,9 @@ def test_row_sum_xcd_encoder_vs_oracle_real_tables(fr):
 def test_render_strict_1e4_on_well_conditioned_pixels(fr):
     """256 rays x 128 samples per pose through the production pipeline against the oracle (full tables).  Survivor /
     flag decisions identical.  Every pixel whose reference arithmetic is well conditioned (the oracle's own fp32 result
-    is within 2e-6 of its fp64 result) must meet the plain 1e-4 bar with no allowance; the remaining pixels (far /
-    band pairs extrapolated by the encoder with 1e3..1e6 weights) may deviate from the fp64 result by
-    1e-4 + 4x what the reference's own fp32 arithmetic deviates on that pixel."""
+    is within 2e-6 of its fp64 result AND the fp64 result moves by less than 2e-6 under an fp32-ulp perturbation of the
+    rays) must meet the plain 1e-4 bar with no allowance; the remaining pixels (far / band pairs extrapolated by the
+    encoder with 1e3..1e6 weights) may deviate from the fp64 result by 1e-4 + 4x that noise scale."""
     f, k = fr, fr['k']
     net, bc, gb, cfg = f['net'], f['bc'], f['gb'], f['cfg']
     n = gb['ray_o'].shape[1]
@@ -257,13 +257,23 @@ def test_render_strict_1e4_on_well_conditioned_pixels(fr):
         sd64 = {k_: (t.double() if t.is_floating_point() else t) for k_, t in sd.items()}
         b64 = {k_: (t.double() if torch.is_tensor(t) and t.is_floating_point() else t) for k_, t in b.items()}
         ref64 = O.render(O.Model(sd64, cfg), b64, n_samples=S, chunk=64)
+        # conditioning of a pixel, independent of one particular rounding sequence: the fp64 result under an fp32-ulp-sized
+        # perturbation of the rays.  (err_ref alone is ONE noisy sample: an ill-conditioned pixel lands within 2e-6 of the exact
+        # value by chance every few hundred pixels, and which ones do depends on the host's thread count — the test flaked.)
+        b64p = dict(b64)
+        b64p['ray_d'] = b64['ray_d'] * (1.0 + 2.0 ** -22)
+        b64p['ray_o'] = b64['ray_o'] + 2.0 ** -23
+        ref64p = O.render(O.Model(sd64, cfg), b64p, n_samples=S, chunk=64)
     assert int((ref['occ'][0, :, 0] != 0).sum()) > 300
     assert bool(((out['raw'].cpu()[:, 3] != 0) == (ref['raw'][0, :, 3] != 0)).all())
     exact = ref64['rgb_map'][0]
     err_gpu = (out['rgb_map'].cpu().double() - exact).abs().max(1)[0]
     err_ref = (ref['rgb_map'][0].double() - exact).abs().max(1)[0]
-    well = err_ref < 2e-6
+    sens = (ref64p['rgb_map'][0] - exact).abs().max(1)[0]
+    noise = torch.maximum(err_ref, sens)
+    well = noise < 2e-6
     assert int(well.sum()) >= 64, int(well.sum())
-    assert float(err_gpu[well].max()) <= 1e-4, float(err_gpu[well].max())              # strict, no err_ref term
-    assert bool((err_gpu <= 1e-4 + 4 * err_ref).all()), (float(err_gpu.max()), float(err_ref.max()))
+    assert float(err_gpu[well].max()) <= 1e-4, ('strict', float(err_gpu[well].max()))           # strict, no allowance
+    worst = (err_gpu - (1e-4 + 4 * noise)).argmax()
+    assert bool((err_gpu <= 1e-4 + 4 * noise).all()), ('ill-conditioned', float(err_gpu[worst]), float(err_ref[worst]), float(sens[worst]))
     assert float(err_gpu.median()) < 2e-6
