@@ -9,8 +9,10 @@ Train mode (``net.training`` and grad enabled) goes through autograd.TrainRender
 HIP backward — and returns the reference's training dict (rgb_map, acc_map, weights / z_vals, resd, tpts, tocc, oresd,
 distortion) with the large per-pair tensors materialised lazily (LazyTrainRet) plus two scalars the trainer prefers when
 present: ``offset_loss`` and ``pair_loss`` (the reference's means over resd / oresd, reduced on the device).  One deviation:
-``tpts`` of UNFLAGGED pairs is 0 here; the reference fills those rows with the warp of an all-zero blend (a value no loss
-or evaluator reads, inb_part_network_multiassign.py:105-120).
+``tpts`` of UNFLAGGED (point, part) pairs is 0 here; the reference returns ``init_bigpose`` — the warp under that part's
+KNN blend weights — for every one of the Na x 5 pairs, flagged or not (inb_part_network_multiassign.py:96-120).  Producing it
+would need the exact 4-NN of every survivor in every part, which is what the pair pruning avoids; the only reader is the pair
+regulariser, which selects rows by ``tocc`` (0 for unflagged pairs) and therefore never sees them.
 """
 import ctypes as C
 
