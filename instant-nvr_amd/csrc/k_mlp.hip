@@ -131,7 +131,7 @@ template <int NRGB>
 __device__ __forceinline__ void mlp_part(float* lds, const PartMlpDev& pm, const float* __restrict__ emb,
                                          const float* __restrict__ ds, int64_t stride, const int32_t* __restrict__ l_slot,
                                          int cnt, int64_t cap, float4* __restrict__ raws, int part,
-                                         float4* __restrict__ raw_direct, const int vblock) {
+                                         float4* __restrict__ raw_direct, const int vblock, const int nblocks) {
     if ((int64_t)vblock * (MLP_BLOCK / 64) * MLP_CB * 16 >= cnt) return;
     __syncthreads();                                   // previous part's weights no longer in use
     stage_weights<NRGB, true>(pm, lds);
@@ -144,7 +144,7 @@ __device__ __forceinline__ void mlp_part(float* lds, const PartMlpDev& pm, const
     const float misc2 = g < 3 ? lat[5 + g] : 0.0f;               // e = 8+g ; e = 11 is padding
     const float fmul = (float)(1 << g);                          // frequency 2^g of this lane group
 
-    const int64_t per_block = (MLP_BLOCK / 64) * MLP_CB * 16, step = (int64_t)gridDim.x * per_block;
+    const int64_t per_block = (MLP_BLOCK / 64) * MLP_CB * 16, step = (int64_t)nblocks * per_block;
     auto load_in = [&](int64_t wbase, MlpCol& A, MlpCol& B) {
         const int64_t pa = min(wbase + col, (int64_t)cnt - 1), pb = min(wbase + 16 + col, (int64_t)cnt - 1);
 #pragma unroll
@@ -219,27 +219,36 @@ __global__ __launch_bounds__(MLP_BLOCK, 3) void k_part_mlp(PartMlpDev pm, const 
                                                         const int32_t* __restrict__ count, int64_t cap,
                                                         float4* __restrict__ raws, int part, float4* __restrict__ raw_direct) {
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
-    mlp_part<NRGB>(lds, pm, emb, ds, stride, l_slot, *count, cap, raws, part, raw_direct, (int)blockIdx.x);
+    mlp_part<NRGB>(lds, pm, emb, ds, stride, l_slot, *count, cap, raws, part, raw_direct, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // all five parts in one persistent launch (see k_part_encode_rs_all): the weights of the next part are staged
 // into the same LDS image when a workgroup has finished its share of the previous one
 __global__ __launch_bounds__(MLP_BLOCK, 3) void k_part_mlp_all(MlpAllArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
-    // the tiles of part p are dealt round-robin starting at the workgroup where part p-1 stopped: with every part starting
-    // at workgroup 0 the low workgroups got the ceil() share of all five parts (7 tile rounds against an average of 5.9 on a
-    // 1/8 shard of a frame, +5 % on a whole frame)
-    const int per_block = (MLP_BLOCK / 64) * MLP_CB * 16;
-    int off = 0;
+    // Every workgroup serves ONE part: the parts get contiguous ranges of workgroups in proportion to their tile counts
+    // (device-side counts), so a workgroup stages one LDS weight image instead of five (5 x ~6 us — a fifth of the kernel on a
+    // 1/8 shard) and the per-part ceil() shares of a walk over all parts disappear.  A part too small for a range of its own
+    // is taken along by the workgroup where its range would start.
+    const int per_block = (MLP_BLOCK / 64) * MLP_CB * 16, G = (int)gridDim.x, b = (int)blockIdx.x;
+    int64_t tiles[INVR_NUM_PARTS], total = 0;          // tile counts weighted by the part's cost per pair (22.1 : 14.0 kFLOP = 8 : 5)
     for (int p = 0; p < INVR_NUM_PARTS; ++p) {
-        const int cnt = a.counts[p];
-        int vb = (int)blockIdx.x - off;
-        if (vb < 0) vb += (int)gridDim.x;
+        tiles[p] = (int64_t)((a.counts[p] + per_block - 1) / per_block) * (a.pm[p].rgb.n_linear == 3 ? 8 : 5);
+        total += tiles[p];
+    }
+    if (total == 0) return;
+    int64_t cum = 0;
+    for (int p = 0; p < INVR_NUM_PARTS; ++p) {
+        const int start = (int)(cum * G / total), end = (int)((cum + tiles[p]) * G / total);
+        cum += tiles[p];
+        if (tiles[p] == 0) continue;
+        int vb, nb;
+        if (end > start) { if (b < start || b >= end) continue; vb = b - start; nb = end - start; }
+        else { if (b != min(start, G - 1)) continue; vb = 0; nb = 1; }
         if (a.pm[p].rgb.n_linear == 3)
-            mlp_part<3>(lds, a.pm[p], a.emb[p], a.ds[p], a.stride, a.l_slot[p], cnt, a.cap, a.raws, p, nullptr, vb);
+            mlp_part<3>(lds, a.pm[p], a.emb[p], a.ds[p], a.stride, a.l_slot[p], a.counts[p], a.cap, a.raws, p, nullptr, vb, nb);
         else
-            mlp_part<2>(lds, a.pm[p], a.emb[p], a.ds[p], a.stride, a.l_slot[p], cnt, a.cap, a.raws, p, nullptr, vb);
-        off = (int)((off + (cnt + per_block - 1) / per_block) % (int)gridDim.x);
+            mlp_part<2>(lds, a.pm[p], a.emb[p], a.ds[p], a.stride, a.l_slot[p], a.counts[p], a.cap, a.raws, p, nullptr, vb, nb);
     }
 }
 
