@@ -170,9 +170,9 @@ typedef struct InvrWsLayout {
     int64_t mask;                          /* uint64[ceil(N/1024)*16]: survivor bit of ray-sample i = bit i&63 of word i>>6;
                                               slot of a surviving sample = word_off[i>>6] + popcount(lower bits)     */
     int64_t pflags, farflags;              /* uint8[lcap]: bit p = (slot, part p) listed / far     */
-    int64_t l_slot[INVR_NUM_PARTS];        /* int32[lcap]: survivor slot of each listed pair       */
-    int64_t l_nn[INVR_NUM_PARTS];          /* int32[lcap*4]                                        */
-    int64_t l_w[INVR_NUM_PARTS];           /* float[lcap*4]                                        */
+    int64_t l_slot[INVR_NUM_PARTS];        /* int32[lcap]: survivor slot of each listed pair, ascending; the last entry is the far constant (slot cap) */
+    int64_t l_nn[INVR_NUM_PARTS];          /* int32[lcap*4] indexed by SURVIVOR SLOT: the 4 neighbour rows inside part_pbw[p] of a flagged (slot, part) */
+    int64_t l_w[INVR_NUM_PARTS];           /* float[lcap*4] indexed by SURVIVOR SLOT: their normalised gaussian weights                                */
     int64_t l_x[INVR_NUM_PARTS];           /* float[3*lcap] SoA: canonical point incl. residual    */
     int64_t l_d[INVR_NUM_PARTS];           /* float[3*lcap] SoA: canonical view direction          */
     int64_t l_r[INVR_NUM_PARTS];           /* float[3*lcap] SoA: residual (resd)                   */
