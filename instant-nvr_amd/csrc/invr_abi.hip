@@ -387,8 +387,25 @@ static int render_impl(const InvrScene* scene, const InvrModel* model,
         { ProfStage ps(INVR_STAGE_ENCODE, st); if (launch_part_encode_all(ea, st)) return 1; }
         { ProfStage ps(INVR_STAGE_MLP, st); if (launch_part_mlp_all(ma, st)) return 1; }
     }
-    // per-part launches (training forward on the 64-byte rows, eval without row sums).  (Running the five encoder -> MLP chains
-    // on separate streams, as the backward does, was measured: no gain — the forward launches are short.)
+    // training forward / eval without row sums: the 64-byte-row encoder, then the same merged MLP launch as the eval path — the
+    // five parts side by side in one launch each (a part's 1e4-5e4 pairs make short, latency-bound launches; the profiler and
+    // INVR_NO_MERGE keep the per-part launches, stage times per part)
+    if (!geometry_only && !merged && !no_merge && !g_prof_on) {
+        EncodeAllArgs ea;
+        MlpAllArgs ma;
+        for (int p = 0; p < INVR_NUM_PARTS; ++p) {
+            ea.g[p] = make_grid_dev(&model->part[p].grid);
+            ea.xs[p] = w.l_x[p]; ea.emb[p] = w.emb[p];
+            ma.pm[p] = make_part_mlp(model, p, scene->latent_index);
+            ma.emb[p] = w.emb[p]; ma.ds[p] = w.l_d[p]; ma.l_slot[p] = w.l_slot[p];
+        }
+        ea.counts = ma.counts = w.counters + CNT_PAIRS;
+        ea.stride = ma.stride = w.lcap; ea.cap = ma.cap = w.lcap;
+        ma.raws = w.raws;
+        if (launch_part_encode_rows_all(ea, st)) return 1;
+        if (launch_part_mlp_all(ma, st)) return 1;
+        merged = true;
+    }
     for (int p = 0; p < INVR_NUM_PARTS && !geometry_only && !merged; ++p) {
         float* emb = w.emb[p];
         {

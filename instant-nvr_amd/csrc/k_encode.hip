@@ -277,11 +277,8 @@ __device__ __forceinline__ float reduce_point(const float4* v, const float* wts)
     return quad_sum((a.x + a.y) + (a.z + a.w));
 }
 
-__global__ __launch_bounds__(ENC_BLOCK) void k_part_encode(GridDev g, const float* __restrict__ xs, int64_t stride,
-                                                           const int32_t* __restrict__ count, int64_t cap,
-                                                           float* __restrict__ emb) {
-    __shared__ float semb[ENC_WAVES][EMB_K][64];
-    const int cnt = *count;
+__device__ __forceinline__ void encode_rows_part(const GridDev& g, const float* __restrict__ xs, int64_t stride, const int cnt, int64_t cap,
+                                                 float* __restrict__ emb, float (*semb)[EMB_K][64]) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int level = lane >> 2, q = lane & 3;
     LaneLevel L;
@@ -324,6 +321,21 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_part_encode(GridDev g, const floa
             for (int k = 0; k < EMB_K; ++k) emb[(int64_t)k * cap + base + lane] = semb[wv][k][lane];
         }
     }
+}
+
+__global__ __launch_bounds__(ENC_BLOCK) void k_part_encode(GridDev g, const float* __restrict__ xs, int64_t stride,
+                                                           const int32_t* __restrict__ count, int64_t cap,
+                                                           float* __restrict__ emb) {
+    __shared__ float semb[ENC_WAVES][EMB_K][64];
+    encode_rows_part(g, xs, stride, *count, cap, emb, semb);
+}
+
+// the five parts in one launch (blockIdx.y = part): the training forward's five encoder launches are short (a part's 1e4-5e4
+// pairs) and latency-bound, side by side they take the time of the largest
+__global__ __launch_bounds__(ENC_BLOCK) void k_part_encode_rows_all(EncodeAllArgs a) {
+    __shared__ float semb[ENC_WAVES][EMB_K][64];
+    const int p = blockIdx.y;
+    encode_rows_part(a.g[p], a.xs[p], a.stride, a.counts[p], a.cap, a.emb[p], semb);
 }
 
 // ---- wave-cooperative backward of the 16x16 sum-over-features grids ----------------------------------
@@ -731,6 +743,21 @@ int launch_row_sums(const GridDev& g, float* out, hipStream_t st) {
         return run(g.hash, (int64_t)(g.L - g.start_hash) * g.T, out + g.dense_rows);
     }
     return run(g.hash, (int64_t)g.L * g.T, out);
+}
+
+int launch_part_encode_rows_all(const EncodeAllArgs& a, hipStream_t st) {
+    for (int p = 0; p < INVR_NUM_PARTS; ++p) {
+        const GridDev& g = a.g[p];
+        if (g.L != 16 || g.F != 16 || !g.sum || !g.sum_over_features || !g.include_input) {
+            invr_set_error("part encoder kernel supports n_levels=16, n_features_per_level=16, sum, sum_over_features, include_input (got L=%d F=%d)", g.L, g.F);
+            return 1;
+        }
+    }
+    int64_t tiles = cdiv(a.cap, 64 * ENC_WAVES);
+    unsigned grid = (unsigned)(tiles < 256 * 4 ? (tiles > 0 ? tiles : 1) : 256 * 4);
+    hipLaunchKernelGGL(k_part_encode_rows_all, dim3(grid, INVR_NUM_PARTS), dim3(ENC_BLOCK), 0, st, a);
+    INVR_LAUNCH_CHECK();
+    return 0;
 }
 
 int launch_part_encode_all(const EncodeAllArgs& a, hipStream_t st) {

@@ -138,6 +138,7 @@ struct EncodeAllArgs {            // k_part_encode_rs_all: the five part grids o
     int64_t stride, cap;
 };
 int launch_part_encode_all(const EncodeAllArgs& a, hipStream_t st);
+int launch_part_encode_rows_all(const EncodeAllArgs& a, hipStream_t st);   // 64-byte rows (training forward), blockIdx.y = part
 struct PartMlpDev {
     MlpDev occ, rgb;
     const float* rgb_latent;
