@@ -3,7 +3,7 @@
 #include <stdio.h>
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-template <int MODE, int NV>   // MODE 0: f32 16x16x4, 1: f16 16x16x16 ; NV = independent VALU fmas per MFMA
+template <int MODE, int NV, int VK = 0>   // MODE 0: f32 16x16x4, 1: f16 16x16x16, 2: no MFMA; NV = independent VALU ops per MFMA slot; VK 0: v_fma_f32, 1: v_exp_f32 (transcendental)
 __global__ __launch_bounds__(256) void k(float* out, int iters, float seed) {
     f4 acc[4];
     for (int i = 0; i < 4; ++i) acc[i] = (f4){0, 0, 0, 0};
@@ -15,11 +15,11 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float seed) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             if (MODE == 0) acc[u & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[u & 3], 0, 0, 0);
-            else acc[u & 3] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh, acc[u & 3], 0, 0, 0);
+            else if (MODE == 1) acc[u & 3] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh, acc[u & 3], 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < NV; ++j) v[(u + j) & 7] = __builtin_fmaf(v[(u + j) & 7], 1.0001f, 0.5f);
-            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x2, NV, 0);
+            for (int j = 0; j < NV; ++j) v[(u + j) & 7] = VK ? __builtin_amdgcn_exp2f(v[(u + j) & 7] * 0.5f) : __builtin_fmaf(v[(u + j) & 7], 1.0001f, 0.5f);
+            if (MODE != 2) __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+            if (MODE != 2) __builtin_amdgcn_sched_group_barrier(0x2, VK ? 2 * NV : NV, 0);
         }
     }
     float s = 0;
@@ -27,11 +27,11 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float seed) {
     for (int i = 0; i < 8; ++i) s += v[i];
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
-template <int MODE, int NV> float run(float* d, int blocks) {
+template <int MODE, int NV, int VK = 0> float run(float* d, int blocks) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    k<MODE, NV><<<blocks, 256>>>(d, 100, 1.0f);
+    k<MODE, NV, VK><<<blocks, 256>>>(d, 100, 1.0f);
     hipEventRecord(e0);
-    k<MODE, NV><<<blocks, 256>>>(d, 20000, 1.0f);
+    k<MODE, NV, VK><<<blocks, 256>>>(d, 20000, 1.0f);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); return ms;
 }
@@ -44,6 +44,11 @@ int main() {
         printf(" f32 mfma + 2 valu    %.3f ms\n", run<0, 2>(d, blocks));
         printf(" f32 mfma + 4 valu    %.3f ms\n", run<0, 4>(d, blocks));
         printf(" f32 mfma + 8 valu    %.3f ms\n", run<0, 8>(d, blocks));
+        printf(" f32 mfma + 2 (mul, exp2) %.3f ms\n", run<0, 2, 1>(d, blocks));
+        printf(" f32 mfma + 4 (mul, exp2) %.3f ms\n", run<0, 4, 1>(d, blocks));
+        printf(" no mfma: 2 fma / slot    %.3f ms\n", run<2, 2, 0>(d, blocks));
+        printf(" no mfma: 2 (mul, exp2)   %.3f ms\n", run<2, 2, 1>(d, blocks));
+        printf(" no mfma: 4 (mul, exp2)   %.3f ms\n", run<2, 4, 1>(d, blocks));
         printf(" f16 mfma only        %.3f ms\n", run<1, 0>(d, blocks));
         printf(" f16 mfma + 1 valu    %.3f ms\n", run<1, 1>(d, blocks));
         printf(" f16 mfma + 2 valu    %.3f ms\n", run<1, 2>(d, blocks));
