@@ -37,7 +37,7 @@ struct MlpCol {
     f32x4 h[4];                 // hidden activations (log2 domain), feature 16 mt + 4 g + r
     f32x4 feat;                 // occ features 1..16 (true scale)
     float occ;
-    float k5[13];               // rgb layer-1 k-slots 5..17: sin/cos (6), [d | latent] (3), feat (4)
+    float k5[11];               // rgb layer-1 k-slots 5..15: sin/cos (6), d (1), feat (4)
 };
 
 // The stages of the two MLPs for ONE column block.  mlp_part runs two column blocks per wave SKEWED by one stage, so that in
@@ -69,7 +69,7 @@ __device__ __forceinline__ void st_occ2(const float* lds, int lane, int g, MlpCo
     const float lg = head_dot_s(c.h, lds + O_V_OCC, g) + lds[O_V_OCC + 64];
     c.occ = one_minus_exp_neg(softplus_f(lg));                    // 1 - exp(-softplus(h0))  (:52)
 }
-__device__ __forceinline__ void st_rgb_in(MlpCol& c, int g, float fmul, float misc0_lat, float misc1, float misc2) {
+__device__ __forceinline__ void st_rgb_in(MlpCol& c, int g, float fmul) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         float sn, cs;
@@ -77,17 +77,15 @@ __device__ __forceinline__ void st_rgb_in(MlpCol& c, int g, float fmul, float mi
         c.k5[2 * k] = sn;
         c.k5[2 * k + 1] = cs;
     }
-    c.k5[6] = g == 0 ? c.dv[0] : (g == 1 ? c.dv[1] : (g == 2 ? c.dv[2] : misc0_lat));
-    c.k5[7] = misc1;
-    c.k5[8] = misc2;
+    c.k5[6] = g == 0 ? c.dv[0] : (g == 1 ? c.dv[1] : (g == 2 ? c.dv[2] : 0.0f));
 #pragma unroll
-    for (int r = 0; r < 4; ++r) c.k5[9 + r] = c.feat[r];
+    for (int r = 0; r < 4; ++r) c.k5[7 + r] = c.feat[r];
 }
 __device__ __forceinline__ void st_rgb1(const float* lds, int lane, int g, MlpCol& c) {
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) c.h[mt] = bias4(lds + O_B_RGB1, mt, g);
 #pragma unroll
-    for (int s = 0; s < RGB1_STEPS; ++s) {
+    for (int s = 0; s < RGB1F_STEPS; ++s) {
         const float4 a = *reinterpret_cast<const float4*>(lds + O_W_RGB1 + (s * 64 + lane) * 4);
         const float b = s < EMB_STEPS ? c.eb[s < EMB_STEPS ? s : 0] : c.k5[s >= EMB_STEPS ? s - EMB_STEPS : 0];
         c.h[0] = mfma4(a.x, b, c.h[0]); c.h[1] = mfma4(a.y, b, c.h[1]);
@@ -137,11 +135,6 @@ __device__ __forceinline__ void mlp_part(float* lds, const PartMlpDev& pm, const
     stage_weights<NRGB, true>(pm, lds);
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, col = lane & 15;
-    // per-lane constant k-slots of the [d, latent, pad] block of the rgb input
-    const float* lat = pm.rgb_latent + pm.latent_index[0] * pm.latent_dim;
-    const float misc0_lat = lat[0];                              // e = 3 (g == 3)
-    const float misc1 = lat[1 + g];                              // e = 4+g
-    const float misc2 = g < 3 ? lat[5 + g] : 0.0f;               // e = 8+g ; e = 11 is padding
     const float fmul = (float)(1 << g);                          // frequency 2^g of this lane group
 
     const int64_t per_block = (MLP_BLOCK / 64) * MLP_CB * 16, step = (int64_t)nblocks * per_block;
@@ -174,14 +167,14 @@ __device__ __forceinline__ void mlp_part(float* lds, const PartMlpDev& pm, const
         st_occ2(lds, lane, g, A); st_act(B);
         mlp_interleave<16, 5>();
         MLP_FENCE();
-        st_occ2(lds, lane, g, B); st_rgb_in(A, g, fmul, misc0_lat, misc1, misc2);
+        st_occ2(lds, lane, g, B); st_rgb_in(A, g, fmul);
         mlp_interleave<16, 4>();
         MLP_FENCE();
-        st_rgb1(lds, lane, g, A); st_rgb_in(B, g, fmul, misc0_lat, misc1, misc2);
+        st_rgb1(lds, lane, g, A); st_rgb_in(B, g, fmul);
         mlp_interleave<30, 1>();
         MLP_FENCE();
         st_rgb1(lds, lane, g, B); st_act(A);
-        mlp_interleave<72, 1>();
+        mlp_interleave<64, 1>();
         MLP_FENCE();
         float4 rA, rB;
         if (NRGB == 3) {

@@ -10,6 +10,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define HID 64
 #define EMB_STEPS 5              // 20 / 4
 #define RGB1_STEPS 18            // 72 / 4
+#define RGB1F_STEPS 16           // forward kernels: the 8 latent inputs are constant per call and folded into the bias (64 / 4)
 
 // LDS carve (floats)
 #define O_W_OCC1 0                                   // 5*4*64
@@ -32,6 +33,15 @@ __device__ __forceinline__ int rgb1_col(int s, int g) {
     if (s < 11) { int u = s - 5, comp = u >> 1, fn = u & 1; return 19 + 3 + g * 6 + fn * 3 + comp; }
     if (s < 14) { int e = 4 * (s - 11) + g; return e < 3 ? 19 + e : (e < 11 ? 62 + (e - 3) : -1); }
     return 46 + 4 * g + (s - 14);
+}
+// forward kernels (LOG2DOM staging): [emb 0..18 + pad | sin / cos 24 | d 3 + pad | feat 16] = 16 k-steps; the latent code is the
+// same for every pair of a call (one frame), so W[:, 62..69] . latent is added to the layer's bias when the weights are staged —
+// 8 of the part's 108 / 172 MFMAs per 16-pair tile less.
+__device__ __forceinline__ int rgb1f_col(int s, int g) {
+    if (s < 5) { int e = 4 * s + g; return e < 19 ? e : -1; }
+    if (s < 11) { int u = s - 5, comp = u >> 1, fn = u & 1; return 19 + 3 + g * 6 + fn * 3 + comp; }
+    if (s == 11) return g < 3 ? 19 + g : -1;
+    return 46 + 4 * g + (s - 12);
 }
 // hidden unit held by lane group g for k-step s of a 64-wide hidden layer
 __device__ __forceinline__ int hid_col(int s, int g) { return 16 * (s >> 2) + 4 * g + (s & 3); }
@@ -57,9 +67,9 @@ __device__ void stage_weights(const PartMlpDev& pm, float* lds) {
         int ln = t & 63, s = t >> 6, g = ln >> 4, i = ln & 15;
         lds[O_W_OCC2 + (LOG2DOM ? ((s >> 2) * 64 + ln) * 4 + (s & 3) : t)] = W1[(1 + i) * HID + hid_col(s, g)] * s_out;
     }
-    for (int t = threadIdx.x; t < RGB1_STEPS * 4 * 64; t += MLP_BLOCK) {
+    for (int t = threadIdx.x; t < (LOG2DOM ? RGB1F_STEPS : RGB1_STEPS) * 4 * 64; t += MLP_BLOCK) {
         int ln = t & 63, mt = (t >> 6) & 3, s = t >> 8, g = ln >> 4, i = ln & 15;
-        int col = rgb1_col(s, g);
+        int col = LOG2DOM ? rgb1f_col(s, g) : rgb1_col(s, g);
         lds[O_W_RGB1 + (LOG2DOM ? (s * 64 + ln) * 4 + mt : t)] = col >= 0 ? R0[(16 * mt + i) * 70 + col] * s_in : 0.0f;
     }
     if (NRGB == 3)
@@ -69,7 +79,13 @@ __device__ void stage_weights(const PartMlpDev& pm, float* lds) {
         }
     for (int t = threadIdx.x; t < 64; t += MLP_BLOCK) {
         lds[O_B_OCC1 + t] = pm.occ.b[0][t] * s_in;
-        lds[O_B_RGB1 + t] = pm.rgb.b[0][t] * s_in;
+        float b1 = pm.rgb.b[0][t];
+        if (LOG2DOM) {                                           // + W[:, latent] . latent (the latent block of the rgb input)
+            const float* lat = pm.rgb_latent + pm.latent_index[0] * pm.latent_dim;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) b1 = fmaf(R0[t * 70 + 62 + j], lat[j], b1);
+        }
+        lds[O_B_RGB1 + t] = b1 * s_in;
         if (NRGB == 3) lds[O_B_RGB2 + t] = pm.rgb.b[1][t] * s_in;      // (rgb2 weights: ln2 * log2e = 1, unscaled)
         int g = t >> 4, u = t & 15;                              // slot order: [g][mt*4+r]
         int hc = 16 * (u >> 2) + 4 * g + (u & 3);
