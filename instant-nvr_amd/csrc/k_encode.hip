@@ -361,7 +361,6 @@ struct EncBwdIO {
     float* g_xyz; int64_t gx_ps, gx_cs;
     int64_t n_host; const int32_t* count;
     float* g_dense; float* g_hash; float* rowgrad;
-    int dbg_tp, dbg_noatom;
 };
 
 __global__ __launch_bounds__(ENC_BLOCK) void k_part_encode_bwd(GridDev g, EncBwdIO io) {
@@ -379,7 +378,6 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_part_encode_bwd(GridDev g, EncBwd
     if (n <= 0) return;
     int tp = 64;                                      // points per wave tile: enough waves to fill the GPU, long enough runs to combine
     while (tp > 16 && n / tp < 4096) tp >>= 1;
-    if (io.dbg_tp) tp = io.dbg_tp;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int level = lane >> 2, q = lane & 3;
     LaneLevel L;
@@ -411,7 +409,7 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_part_encode_bwd(GridDev g, EncBwd
     }
     for (int j = threadIdx.x; j < small_total; j += ENC_BLOCK) ssmall[j] = 0.0f;
     for (int j = threadIdx.x; j < BWD_CACHE; j += ENC_BLOCK) { ckey[j] = 0xFFFFFFFFu; cval[j] = 0.0f; }
-    const bool cached = small_off < 0 && !L.hashed && g.separate_dense && L.res <= BWD_CACHE_RES && !io.dbg_noatom;
+    const bool cached = small_off < 0 && !L.hashed && g.separate_dense && L.res <= BWD_CACHE_RES;
     __syncthreads();
     const float b0x = g.bounds[0], b0y = g.bounds[1], b0z = g.bounds[2];
     const float ex = g.bounds[3] - b0x, ey = g.bounds[4] - b0y, ez = g.bounds[5] - b0z;
@@ -439,7 +437,6 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_part_encode_bwd(GridDev g, EncBwd
 #pragma unroll
         for (int k = 0; k < 8; ++k) { prow[k] = 0xFFFFFFFFu; pval[k] = 0.0f; }
         auto flush = [&](unsigned r, float vsum) {
-            if (io.dbg_noatom) return;
             if (small_off >= 0) { atomicAdd(&ssmall[small_off + r], vsum); return; }
             if (cached) {
                 const unsigned key = ((unsigned)level << 24) | r;
@@ -541,9 +538,7 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_part_encode_bwd(GridDev g, EncBwd
 }
 
 static int launch_part_encode_bwd_io(const GridDev& g, const EncBwdIO& io_in, hipStream_t st) {
-    EncBwdIO io = io_in;
-    static const int dbg_tp = getenv("INVR_ENCB_TP") ? atoi(getenv("INVR_ENCB_TP")) : 0, dbg_na = getenv("INVR_ENCB_NOATOM") ? 1 : 0;
-    io.dbg_tp = dbg_tp; io.dbg_noatom = dbg_na;
+    const EncBwdIO& io = io_in;
     const int64_t n = io.n_host;                             // the count or its upper bound (device count given)
     int tp = 64;
     while (tp > 16 && n / tp < 4096) tp >>= 1;
@@ -557,7 +552,7 @@ static int launch_part_encode_bwd_io(const GridDev& g, const EncBwdIO& io_in, hi
 
 int launch_part_encode_bwd(const GridDev& g, const float* xyz, const float* gout, int64_t n, float* g_dense, float* g_hash,
                            float* g_xyz, hipStream_t st) {
-    EncBwdIO io{xyz, 3, 1, gout, 19, 1, g_xyz, 3, 1, n, nullptr, g_dense, g_hash, nullptr, 0, 0};
+    EncBwdIO io{xyz, 3, 1, gout, 19, 1, g_xyz, 3, 1, n, nullptr, g_dense, g_hash, nullptr};
     return launch_part_encode_bwd_io(g, io, st);
 }
 
@@ -568,7 +563,7 @@ int launch_part_encode_bwd_lists(const GridDev& g, const float* x_soa, const flo
         invr_set_error("part encoder backward supports n_levels=16, n_features_per_level=16, sum, sum_over_features, include_input");
         return 1;
     }
-    EncBwdIO io{x_soa, 1, stride, gout_soa, 1, stride, gx_soa, 1, stride, n_max, count, nullptr, nullptr, rowgrad, 0, 0};
+    EncBwdIO io{x_soa, 1, stride, gout_soa, 1, stride, gx_soa, 1, stride, n_max, count, nullptr, nullptr, rowgrad};
     return launch_part_encode_bwd_io(g, io, st);
 }
 
