@@ -1,0 +1,76 @@
+"""CPU mirrors of two integer schedules the kernels compute from device-side counts (no GPU needed): they pin the arithmetic the
+comments in csrc/k_mlp.hip (k_part_mlp_all: one part per workgroup) and csrc/k_knn.hip (k_pair_lists: list offsets from the
+per-group pair counts) describe, over random and degenerate count vectors."""
+import numpy as np
+
+P = 5
+PER_BLOCK = 128          # (MLP_BLOCK / 64) * MLP_CB * 16
+PAIR_GROUP = 4096
+
+
+def mlp_ranges(counts, n_linear, G):
+    """csrc/k_mlp.hip:k_part_mlp_all — [(part, first workgroup, number of workgroups, stride)] per workgroup b."""
+    tiles = [((c + PER_BLOCK - 1) // PER_BLOCK) * (8 if nl == 3 else 5) for c, nl in zip(counts, n_linear)]
+    total = sum(tiles)
+    served = {b: [] for b in range(G)}
+    if total == 0:
+        return served
+    cum = 0
+    for p in range(P):
+        start, end = cum * G // total, (cum + tiles[p]) * G // total
+        cum += tiles[p]
+        if tiles[p] == 0:
+            continue
+        if end > start:
+            for b in range(start, end):
+                served[b].append((p, b - start, end - start))
+        else:
+            served[min(start, G - 1)].append((p, 0, 1))
+    return served
+
+
+def test_every_mlp_tile_is_served_exactly_once():
+    rng = np.random.default_rng(0)
+    cases = [[1162270, 1379147, 615803, 721528, 769595], [145000, 172000, 77000, 90000, 96000], [51324, 1, 11574, 1, 10810],
+             [0, 0, 0, 0, 0], [1, 1, 1, 1, 1], [0, 5, 0, 0, 70000], [129, 128, 127, 1, 0]]
+    cases += [list(rng.integers(0, 10 ** rng.integers(1, 7), P)) for _ in range(200)]
+    for counts in cases:
+        for G in (1, 3, 16, 768):
+            nl = [3, 2, 2, 3, 2]
+            served = mlp_ranges([int(c) for c in counts], nl, G)
+            seen = [np.zeros((int(c) + PER_BLOCK - 1) // PER_BLOCK, np.int32) for c in counts]
+            for b, lst in served.items():
+                assert len({p for p, _, _ in lst}) == len(lst)
+                for p, vb, nb in lst:
+                    t = vb
+                    while t * PER_BLOCK < counts[p]:          # mlp_part: tiles vb, vb + nb, ...
+                        seen[p][t] += 1
+                        t += nb
+            for p in range(P):
+                assert (seen[p] == 1).all(), (counts, G, p)
+            if G == 768 and min(counts) > 100 * PER_BLOCK:      # large parts: one weight staging per workgroup
+                assert max(len(v) for v in served.values()) == 1
+
+
+def test_pair_list_offsets_give_ascending_dense_lists():
+    """csrc/k_knn.hip:k_pair_lists — a group's list offset is the sum of the counts of the groups before it; inside a group the
+    ranks follow the slot order."""
+    rng = np.random.default_rng(1)
+    for na in (0, 1, 63, 4096, 4097, 300000):
+        flags = rng.integers(0, 32, na).astype(np.uint8) * (rng.random(na) < 0.6)
+        flags = flags.astype(np.uint8)
+        n_groups = (max(na, 1) - 1) // PAIR_GROUP + 1
+        gcount = np.zeros((n_groups, P), np.int64)
+        for p in range(P):                                        # what k_knn_pairs accumulates per ticket of 64
+            bit = (flags >> p) & 1
+            for g in range(n_groups):
+                gcount[g, p] = bit[g * PAIR_GROUP:(g + 1) * PAIR_GROUP].sum()
+        lists = [np.full(int(gcount[:, p].sum()) + 1, -7, np.int64) for p in range(P)]
+        for g in range(n_groups):
+            base = gcount[:g].sum(0)
+            for p in range(P):
+                sl = np.nonzero((flags[g * PAIR_GROUP:(g + 1) * PAIR_GROUP] >> p) & 1)[0] + g * PAIR_GROUP
+                lists[p][base[p]:base[p] + sl.size] = sl
+        for p in range(P):
+            want = np.nonzero((flags >> p) & 1)[0]
+            assert np.array_equal(lists[p][:-1], want)            # dense, ascending, every flagged slot once
