@@ -11,11 +11,18 @@ N GPUs (python -m torch.distributed.run ... bench.py --gpus N): the frame's rays
 ranks tile-cyclically, every rank renders its tiles with a full model replica and ONE RCCL
 all-gather assembles [r,g,b,acc]; total work is fixed -> "scaling": "strong".
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     — the dominant roofline-bound kernel (k_part_mlp_all, fp32 MFMA): algorithmic FLOPs
-                 (SURVEY.md §8d per pair) / its HIP-event time, vs 157.3 TFLOP/s; roofline_other: KNN, encoder
-  cpu_baseline — the oracle (CPU PyTorch port of the reference path) timed on the host cores on a
-                 bounded sample of the same workload (N=1 only)
+Prints ONE JSON line on rank 0 (contract in the task statement) with these extra objects:
+  roofline      — the dominant roofline-bound kernel (k_part_mlp_all, fp32 MFMA): algorithmic FLOPs
+                  (SURVEY.md §8d per pair) / its HIP-event time, vs 157.3 TFLOP/s; roofline_other: KNN, encoder
+  path_roofline — the WHOLE frame against SURVEY §8d's byte model (HBM), with the PMC-measured traffic per frame
+  cpu_baseline  — the oracle (CPU PyTorch port of the reference path) timed on the host cores on a
+                  bounded sample of the same workload (N=1 only): one 4096-ray chunk + BASELINE configs[0]
+  train_step    — informational: a few configs[4]-shaped training iterations (N=1 only)
+The timed region is blocks of exactly --steps frames between fences, repeated until >= --min-time seconds.
+
+`--train [--train-config 377|lan] [--gpus N]` benches the training iteration instead (BASELINE configs[4] / configs[3]:
+fused forward + backward + dense Adam over the full-size model, data-parallel over N ranks), see main_train.
+`--shard-of W` renders rank 0's shard of a W-way split on one GPU (strong-scaling evidence without an 8-GPU node).
 """
 import argparse
 import json
