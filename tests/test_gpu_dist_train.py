@@ -94,7 +94,7 @@ def test_two_rank_dp_equals_single_rank_averaged_gradients(tmp_path):
             b['iter_step'] = it + 2
             ret, loss, stats, _ = wrap(b, split='train')
             (0.5 * loss.mean()).backward()
-            ref_losses[r].append(float(loss))
+            ref_losses[r].append(float(loss.detach()))
         opt.step()
     ref = {k: v.detach().cpu() for k, v in net.state_dict().items()}
     assert np.allclose(r0['losses'], ref_losses[0], rtol=2e-4) and np.allclose(r1['losses'], ref_losses[1], rtol=2e-4), (r0['losses'], ref_losses)
