@@ -270,6 +270,11 @@ def test_render_64x64x32_vs_reference_golden(gpu_setup, golden, row_sums):
     assert int(stats[0]) >= int(golden['render_n_active_samples'])   # survivors of the cull >= samples with occ != 0
     err = np.abs(ret['rgb_map'].numpy() - golden['render_rgb_map']).max(-1)[0]
     assert int((err > 1e-4).sum()) == 0, float(err.max())
+    # PSNR against the frame's target colours within 0.1 dB of the reference's (BASELINE metric; here it follows from the pixel bound)
+    from invr.driver import psnr_metric
+    gt = batch['rgb'][0].numpy().astype(np.float64)
+    d_psnr = psnr_metric(ret['rgb_map'][0].numpy().astype(np.float64), gt) - psnr_metric(golden['render_rgb_map'][0].astype(np.float64), gt)
+    assert abs(d_psnr) < 0.1, d_psnr
     assert maxerr(ret['acc_map'], golden['render_acc_map']) < 1e-4
     raw = ret['raw'][0].numpy()
     nz = golden['render_raw_nz_idx']
