@@ -621,13 +621,19 @@ __device__ __forceinline__ float level_rowsum(const GridDev& g, const float* __r
         const bool far1 = (unsigned)c1z > z0 + 1u;
         const unsigned bb[4] = {b00, b01, b10, b11};
         float vv[8];
+        // all four pair loads are issued before the first use; the rare reload of a far second corner comes after them (inside
+        // the loop its predicated load made the compiler wait for every pair load in turn: four serial round trips per level)
+        float2 pr[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) __builtin_memcpy(&pr[j], tab + bb[j] + z0, sizeof(float2));   // 4-byte aligned 8-byte load (global_load_dwordx2)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float2 pr;
-            __builtin_memcpy(&pr, tab + bb[j] + z0, sizeof(pr));             // 4-byte aligned 8-byte load (global_load_dwordx2)
-            vv[2 * j] = s0 ? pr.y : pr.x;
-            vv[2 * j + 1] = s1 ? pr.y : pr.x;
-            if (far1) vv[2 * j + 1] = tab[bb[j] + (unsigned)c1z];
+            vv[2 * j] = s0 ? pr[j].y : pr[j].x;
+            vv[2 * j + 1] = s1 ? pr[j].y : pr[j].x;
+        }
+        if (far1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) vv[2 * j + 1] = tab[bb[j] + (unsigned)c1z];
         }
         const float ux = 1.0f - tx, uy = 1.0f - ty, uz = 1.0f - tz;
         float acc = 0.0f;
