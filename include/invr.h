@@ -177,7 +177,15 @@ typedef struct InvrWsLayout {
     int64_t l_d[INVR_NUM_PARTS];           /* float[3*lcap] SoA: canonical view direction          */
     int64_t l_r[INVR_NUM_PARTS];           /* float[3*lcap] SoA: residual (resd)                   */
     int64_t emb[INVR_NUM_PARTS];           /* float[20*lcap] SoA [k][pair]: encoder output (19 values + pad) of every listed pair */
-    int64_t raws;                          /* float4[lcap*5]: [rgb, occ] per (slot, part)          */
+    int64_t occp[INVR_NUM_PARTS];          /* float[lcap]: occupancy of every listed pair (list order; last entry = the part's far constant) */
+    int64_t wl[INVR_NUM_PARTS];            /* int32[lcap]: list indices of the pairs that win their survivor's max-occupancy merge (the only
+                                              pairs the colour MLP evaluates), segmented by groups of 4096 slots: the winners of group g
+                                              start at the list offset of the group's first pair, wcnt[g][p] of them                   */
+    int64_t wcnt;                          /* int32[n_groups*5]                                     */
+    int64_t wsel;                          /* uint8[lcap]: merge result per survivor: p = listed pair of part p, 8+p = far constant of
+                                              part p, 255 = zeros                                                                    */
+    int64_t rgbw;                          /* float4[lcap+8]: [rgb, occ] of the winning listed pair per survivor; [lcap+p] = far constant of part p */
+    int64_t n_groups;
 } InvrWsLayout;
 int invr_workspace_layout(int64_t n_rays, int32_t n_samples, int64_t max_active, InvrWsLayout* out);
 

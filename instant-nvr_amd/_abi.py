@@ -78,7 +78,8 @@ class InvrWsLayout(C.Structure):
                 ('word_off', C.c_int64), ('mask', C.c_int64), ('pflags', C.c_int64), ('farflags', C.c_int64),
                 ('l_slot', C.c_int64 * NUM_PARTS), ('l_nn', C.c_int64 * NUM_PARTS), ('l_w', C.c_int64 * NUM_PARTS),
                 ('l_x', C.c_int64 * NUM_PARTS), ('l_d', C.c_int64 * NUM_PARTS), ('l_r', C.c_int64 * NUM_PARTS),
-                ('emb', C.c_int64 * NUM_PARTS), ('raws', C.c_int64)]
+                ('emb', C.c_int64 * NUM_PARTS), ('occp', C.c_int64 * NUM_PARTS), ('wl', C.c_int64 * NUM_PARTS),
+                ('wcnt', C.c_int64), ('wsel', C.c_int64), ('rgbw', C.c_int64), ('n_groups', C.c_int64)]
 
 
 EXPORTS = ['invr_last_error', 'invr_version', 'invr_sizeof', 'invr_workspace_bytes', 'invr_render_fwd',
@@ -214,7 +215,11 @@ def ws_views(ws, n_rays, S, max_active, n_active=None):
          'word_off': view(lay.word_off, (n_rays * S + 1023) // 1024 * 16, torch.int32),
          'mask': view(lay.mask, (n_rays * S + 1023) // 1024 * 16, torch.int64),
          'pflags': view(lay.pflags, lc, torch.uint8), 'farflags': view(lay.farflags, lc, torch.uint8),
-         'raws': view(lay.raws, lc * NUM_PARTS * 4, torch.float32).view(lc, NUM_PARTS, 4)}
+         'wsel': view(lay.wsel, lc, torch.uint8),                   # merge result per survivor (p / 8 + p / 255)
+         'rgbw': view(lay.rgbw, (lc + 8) * 4, torch.float32).view(lc + 8, 4),      # winner's [rgb, occ] per slot; far constants at lc + p
+         'wcnt': view(lay.wcnt, lay.n_groups * NUM_PARTS, torch.int32).view(lay.n_groups, NUM_PARTS)}
+    v['occp'] = [view(lay.occp[p], lc, torch.float32) for p in range(NUM_PARTS)]      # occupancy of every listed pair
+    v['wl'] = [view(lay.wl[p], lc, torch.int32) for p in range(NUM_PARTS)]
     for k in ('l_slot', 'l_x', 'l_d', 'l_r'):
         offs = getattr(lay, k)
         if k == 'l_slot':

@@ -213,7 +213,14 @@ static size_t carve(Workspace& w, void* base, int64_t N, int64_t cap) {
         w.l_r[p] = c.take<float>(lc * 3);
     }
     for (int p = 0; p < INVR_NUM_PARTS; ++p) w.emb[p] = c.take<float>(lc * EMB_K);
-    w.raws = c.take<float4>(lc * INVR_NUM_PARTS);
+    for (int p = 0; p < INVR_NUM_PARTS; ++p) {
+        w.occp[p] = c.take<float>(lc);
+        w.feat[p] = c.take<float4>(lc * 4);
+        w.wl[p] = c.take<int32_t>(lc);
+    }
+    w.wcnt = c.take<int32_t>(w.n_groups * INVR_NUM_PARTS);
+    w.wsel = c.take<uint8_t>(lc);
+    w.rgbw = c.take<float4>(lc + 8);
     w.dslice = c.take<float2>(DF_SLICE_MAX);
     w.cullmask = c.take<uint8_t>(CULL_MASK_MAX);
     return align_up(c.off, 256);
@@ -236,7 +243,8 @@ extern "C" int invr_workspace_layout(int64_t n_rays, int32_t n_samples, int64_t 
         o->l_x[p] = off(w.l_x[p]); o->l_d[p] = off(w.l_d[p]); o->l_r[p] = off(w.l_r[p]);
     }
     for (int p = 0; p < INVR_NUM_PARTS; ++p) o->emb[p] = off(w.emb[p]);
-    o->raws = off(w.raws);
+    for (int p = 0; p < INVR_NUM_PARTS; ++p) { o->occp[p] = off(w.occp[p]); o->wl[p] = off(w.wl[p]); }
+    o->wcnt = off(w.wcnt); o->wsel = off(w.wsel); o->rgbw = off(w.rgbw); o->n_groups = w.n_groups;
     return 0;
 }
 
@@ -369,10 +377,13 @@ static int render_impl(const InvrScene* scene, const InvrModel* model,
         MlpDev dm = make_mlp_dev(&model->deform_mlp);
         if (launch_warp_pairs(a, w, dgrid, dm, st)) return 1;
     }
-    bool merged = !geometry_only && !no_merge;
-    for (int p = 0; p < INVR_NUM_PARTS; ++p) merged = merged && model->part[p].grid.row_sums != nullptr;
-    if (merged) {
-        // eval path: the five parts in one encoder launch and one MLP launch (stage times are booked on part 0)
+    if (!geometry_only) {
+        // The five parts in one encoder launch and one launch per MLP phase (stage times are booked on part 0).  Eval reads the
+        // row-sum tables; the training forward / eval without row sums read the trainable 64-byte rows — a part's 1e4-5e4 pairs
+        // make short, latency-bound launches, so the parts also run side by side there (the profiler and INVR_NO_MERGE keep
+        // per-part encoder launches, stage times per part).
+        bool row_sums = true;
+        for (int p = 0; p < INVR_NUM_PARTS; ++p) row_sums = row_sums && model->part[p].grid.row_sums != nullptr;
         EncodeAllArgs ea;
         MlpAllArgs ma;
         for (int p = 0; p < INVR_NUM_PARTS; ++p) {
@@ -380,44 +391,21 @@ static int render_impl(const InvrScene* scene, const InvrModel* model,
             ea.xs[p] = w.l_x[p]; ea.emb[p] = w.emb[p];
             ma.pm[p] = make_part_mlp(model, p, scene->latent_index);
             ma.emb[p] = w.emb[p]; ma.ds[p] = w.l_d[p]; ma.l_slot[p] = w.l_slot[p];
+            ma.occp[p] = w.occp[p]; ma.feat[p] = w.feat[p]; ma.wl[p] = w.wl[p];
         }
         ea.counts = ma.counts = w.counters + CNT_PAIRS;
         ea.stride = ma.stride = w.lcap; ea.cap = ma.cap = w.lcap;
-        ma.raws = w.raws;
-        { ProfStage ps(INVR_STAGE_ENCODE, st); if (launch_part_encode_all(ea, st)) return 1; }
-        { ProfStage ps(INVR_STAGE_MLP, st); if (launch_part_mlp_all(ma, st)) return 1; }
-    }
-    // training forward / eval without row sums: the 64-byte-row encoder, then the same merged MLP launch as the eval path — the
-    // five parts side by side in one launch each (a part's 1e4-5e4 pairs make short, latency-bound launches; the profiler and
-    // INVR_NO_MERGE keep the per-part launches, stage times per part)
-    if (!geometry_only && !merged && !no_merge && !g_prof_on) {
-        EncodeAllArgs ea;
-        MlpAllArgs ma;
-        for (int p = 0; p < INVR_NUM_PARTS; ++p) {
-            ea.g[p] = make_grid_dev(&model->part[p].grid);
-            ea.xs[p] = w.l_x[p]; ea.emb[p] = w.emb[p];
-            ma.pm[p] = make_part_mlp(model, p, scene->latent_index);
-            ma.emb[p] = w.emb[p]; ma.ds[p] = w.l_d[p]; ma.l_slot[p] = w.l_slot[p];
+        ma.wcnt = w.wcnt; ma.gcount = w.gcount; ma.n_active = w.counters + CNT_ACTIVE; ma.rgbw = w.rgbw;
+        if (no_merge || (g_prof_on && !row_sums)) {
+            for (int p = 0; p < INVR_NUM_PARTS; ++p) {
+                ProfStage ps(INVR_STAGE_ENCODE + p, st);
+                if (launch_part_encode(ea.g[p], w.l_x[p], w.lcap, w.counters + CNT_PAIRS + p, w.lcap, w.emb[p], st)) return 1;
+            }
+        } else {
+            ProfStage ps(INVR_STAGE_ENCODE, st);
+            if (row_sums ? launch_part_encode_all(ea, st) : launch_part_encode_rows_all(ea, st)) return 1;
         }
-        ea.counts = ma.counts = w.counters + CNT_PAIRS;
-        ea.stride = ma.stride = w.lcap; ea.cap = ma.cap = w.lcap;
-        ma.raws = w.raws;
-        if (launch_part_encode_rows_all(ea, st)) return 1;
-        if (launch_part_mlp_all(ma, st)) return 1;
-        merged = true;
-    }
-    for (int p = 0; p < INVR_NUM_PARTS && !geometry_only && !merged; ++p) {
-        float* emb = w.emb[p];
-        {
-            ProfStage ps(INVR_STAGE_ENCODE + p, st);
-            GridDev g = make_grid_dev(&model->part[p].grid);
-            if (launch_part_encode(g, w.l_x[p], w.lcap, w.counters + CNT_PAIRS + p, w.lcap, emb, st)) return 1;
-        }
-        {
-            ProfStage ps(INVR_STAGE_MLP + p, st);
-            PartMlpDev pm = make_part_mlp(model, p, scene->latent_index);
-            if (launch_part_mlp(pm, emb, w.l_d[p], w.lcap, w.l_slot[p], w.counters + CNT_PAIRS + p, w.lcap, w.raws, p, nullptr, st)) return 1;
-        }
+        { ProfStage ps(INVR_STAGE_MLP, st); if (launch_part_mlp_all(ma, w, st)) return 1; }
     }
     if (!geometry_only) {
         ProfStage ps(INVR_STAGE_COMPOSITE, st);
@@ -550,7 +538,7 @@ extern "C" int invr_part_field_fwd(const InvrModel* model, int32_t pid, const in
     INVR_LAUNCH_CHECK();
     if (launch_part_encode(make_grid_dev(&model->part[pid].grid), xs, n, count, n, emb, st)) return 1;
     PartMlpDev pm = make_part_mlp(model, pid, latent_index);
-    return launch_part_mlp(pm, emb, ds, n, nullptr, count, n, nullptr, pid, reinterpret_cast<float4*>(raw), st);
+    return launch_part_mlp(pm, emb, ds, n, count, n, reinterpret_cast<float4*>(raw), st);
 }
 
 extern "C" int invr_deform_fwd(const InvrScene* scene, const InvrModel* model, const float* pts, int64_t n, float* resd,
@@ -640,7 +628,7 @@ extern "C" int invr_part_mlp_fwd(const InvrModel* model, int32_t pid, const int6
     if (n == 0) return 0;
     INVR_CHECK(emb_soa && dirs_soa && count_dev && raw, "invr_part_mlp_fwd: null pointer");
     PartMlpDev pm = make_part_mlp(model, pid, latent_index);
-    return launch_part_mlp(pm, emb_soa, dirs_soa, n, nullptr, count_dev, n, nullptr, pid, reinterpret_cast<float4*>(raw), (hipStream_t)stream);
+    return launch_part_mlp(pm, emb_soa, dirs_soa, n, count_dev, n, reinterpret_cast<float4*>(raw), (hipStream_t)stream);
 }
 
 extern "C" int invr_part_mlp_bwd(const InvrModel* model, int32_t pid, const int64_t* latent_index, const float* emb_soa,

@@ -31,9 +31,8 @@ struct DenseRaw {      // raw (R,S,4) given
 struct MergedRaw {     // merge per-part results of the survivor slot of sample i
     const unsigned long long* mask;      // survivor bit of sample i: bit i&63 of word i>>6
     const int32_t* word_off;             // rank of the first survivor of every word
-    const uint8_t* pflags;
-    const uint8_t* farflags;
-    const float4* raws;
+    const uint8_t* wsel;                 // the merge's choice per survivor (k_winner_lists)
+    const float4* rgbw;                  // [rgb, occ] of the winning listed pair at the survivor's slot; far constants at [lcap + p]
     int64_t const_slot;
     __device__ __forceinline__ float4 get(int64_t i) const {
         const unsigned long long m = mask[i >> 6];
@@ -42,15 +41,10 @@ struct MergedRaw {     // merge per-part results of the survivor slot of sample 
         if (slot >= const_slot) slot = -1;                   // survivor beyond max_active (reported in stats[6])
         float4 best = make_float4(0.f, 0.f, 0.f, 0.f);
         if (slot >= 0) {
-            const unsigned fl = pflags[slot], ff = farflags[slot];
-            // argmax over the 5 parts with zeros for unflagged parts, first maximum wins (:253-255)
-#pragma unroll
-            for (int p = 0; p < INVR_NUM_PARTS; ++p) {
-                float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (fl & (1u << p)) c = raws[(int64_t)slot * INVR_NUM_PARTS + p];
-                else if (ff & (1u << p)) c = raws[const_slot * INVR_NUM_PARTS + p];   // far pair: per-part constant
-                if (p == 0 || c.w > best.w) best = c;
-            }
+            // argmax over the 5 parts with zeros for unflagged parts, first maximum wins (:253-255): decided by k_winner_lists
+            const unsigned sel = wsel[slot];
+            if (sel < (unsigned)INVR_NUM_PARTS) best = rgbw[slot];
+            else if (sel < 16u) best = rgbw[const_slot + 1 + (sel - 8u)];      // far pair: per-part constant
         }
         return best;
     }
@@ -101,7 +95,7 @@ int launch_composite(const float* raw, int64_t n_rays, int S, float* weights, fl
 int launch_merge_composite(const RenderArgs& a, const Workspace& w, float* rgb_map, float* acc_map, float* raw,
                            float* occ, float* weights, hipStream_t st) {
     if (a.R == 0) return 0;
-    MergedRaw src{w.mask, w.word_off, w.pflags, w.farflags, w.raws, w.cap};
+    MergedRaw src{w.mask, w.word_off, w.wsel, w.rgbw, w.cap};
     hipLaunchKernelGGL(k_composite<MergedRaw>, dim3((unsigned)cdiv(a.R, CMP_BLOCK / 64)), dim3(CMP_BLOCK), 0, st,
                        src, a.R, a.S, weights, rgb_map, acc_map, reinterpret_cast<float4*>(raw), occ);
     INVR_LAUNCH_CHECK();

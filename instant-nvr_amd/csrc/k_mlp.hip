@@ -127,9 +127,8 @@ __device__ __forceinline__ void mlp_interleave() {
 
 template <int NRGB>
 __device__ __forceinline__ void mlp_part(float* lds, const PartMlpDev& pm, const float* __restrict__ emb,
-                                         const float* __restrict__ ds, int64_t stride, const int32_t* __restrict__ l_slot,
-                                         int cnt, int64_t cap, float4* __restrict__ raws, int part,
-                                         float4* __restrict__ raw_direct, const int vblock, const int nblocks) {
+                                         const float* __restrict__ ds, int64_t stride,
+                                         int cnt, int64_t cap, float4* __restrict__ raw_direct, const int vblock, const int nblocks) {
     if ((int64_t)vblock * (MLP_BLOCK / 64) * MLP_CB * 16 >= cnt) return;
     __syncthreads();                                   // previous part's weights no longer in use
     stage_weights<NRGB, true>(pm, lds);
@@ -194,8 +193,8 @@ __device__ __forceinline__ void mlp_part(float* lds, const PartMlpDev& pm, const
         }
         const int64_t pa = wbase + col, pb = wbase + 16 + col;
         if (g == 0) {
-            if (pa < cnt) { if (raw_direct) raw_direct[pa] = rA; else raws[(int64_t)l_slot[pa] * INVR_NUM_PARTS + part] = rA; }
-            if (pb < cnt) { if (raw_direct) raw_direct[pb] = rB; else raws[(int64_t)l_slot[pb] * INVR_NUM_PARTS + part] = rB; }
+            if (pa < cnt) raw_direct[pa] = rA;
+            if (pb < cnt) raw_direct[pb] = rB;
         }
 #pragma unroll
         for (int s = 0; s < EMB_STEPS; ++s) { A.eb[s] = nA_eb[s]; B.eb[s] = nB_eb[s]; }
@@ -205,43 +204,380 @@ __device__ __forceinline__ void mlp_part(float* lds, const PartMlpDev& pm, const
 }
 
 
+// One part's MLPs over a dense pair list, every pair fully evaluated: the stage-level entry points (invr_part_field_fwd /
+// invr_part_mlp_fwd).  The render path runs the two phases below instead.
 template <int NRGB>
 __global__ __launch_bounds__(MLP_BLOCK, 3) void k_part_mlp(PartMlpDev pm, const float* __restrict__ emb,
                                                         const float* __restrict__ ds, int64_t stride,
-                                                        const int32_t* __restrict__ l_slot,
                                                         const int32_t* __restrict__ count, int64_t cap,
-                                                        float4* __restrict__ raws, int part, float4* __restrict__ raw_direct) {
+                                                        float4* __restrict__ raw_direct) {
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
-    mlp_part<NRGB>(lds, pm, emb, ds, stride, l_slot, *count, cap, raws, part, raw_direct, (int)blockIdx.x, (int)gridDim.x);
+    mlp_part<NRGB>(lds, pm, emb, ds, stride, *count, cap, raw_direct, (int)blockIdx.x, (int)gridDim.x);
 }
 
-// all five parts in one persistent launch (see k_part_encode_rs_all): the weights of the next part are staged
-// into the same LDS image when a workgroup has finished its share of the previous one
-__global__ __launch_bounds__(MLP_BLOCK, 3) void k_part_mlp_all(MlpAllArgs a) {
-    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
-    // Every workgroup serves ONE part: the parts get contiguous ranges of workgroups in proportion to their tile counts
-    // (device-side counts), so a workgroup stages one LDS weight image instead of five (5 x ~6 us — a fifth of the kernel on a
-    // 1/8 shard) and the per-part ceil() shares of a walk over all parts disappear.  A part too small for a range of its own
-    // is taken along by the workgroup where its range would start.
+// ---- render path -------------------------------------------------------------------------------------------------------
+// TPoseHuman.forward keeps, per survivor, only the raw of the part with the largest occupancy (first maximum;
+// inb_part_network_multiassign.py:253-256): the colour MLP of every other evaluated pair is dead work — 17.5 k (body, head) /
+// 9.3 k (leg, arms) of a pair's 22.1 k / 14.0 kFLOP, for 49 % of the pairs of the bench frame.  So the part MLPs run in two
+// phases with identical results:
+//   k_part_occ_all    every listed pair: 19 -> 64 -> 17, occupancy to occp[p][pair], the 16 geometry features to feat[p][pair]
+//   k_winner_lists    per survivor the arg-max over {listed occupancies, far constants, 0 for unflagged parts} -> wsel[slot];
+//                     the winning LISTED pairs (+ the far-constant pair of every part) as per-part lists, segmented by slot group
+//   k_part_rgb_all    70 -> 64 (-> 64) -> 3 on the winners only; [rgb, occ] to rgbw[slot] (far constants: rgbw[lcap + p])
+// A pair's arithmetic does not depend on its column or tile, so both phases reproduce the one-kernel results bit for bit.
+
+#define OCC_LDS_FLOATS O_W_RGB1
+__device__ __forceinline__ void occ_part(float* lds, const PartMlpDev& pm, const float* __restrict__ emb, int cnt, int64_t cap,
+                                         float* __restrict__ occp, float4* __restrict__ feat, const int vblock, const int nblocks) {
+    const int64_t per_block = (MLP_BLOCK / 64) * MLP_CB * 16, step = (int64_t)nblocks * per_block;
+    if ((int64_t)vblock * per_block >= cnt) return;
+    __syncthreads();                                   // previous part's weights no longer in use
+    stage_weights<2, true, 1>(pm, lds);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, col = lane & 15;
+    auto load_in = [&](int64_t wbase, float* ea, float* eb) {
+        const int64_t pa = min(wbase + col, (int64_t)cnt - 1), pb = min(wbase + 16 + col, (int64_t)cnt - 1);
+#pragma unroll
+        for (int s = 0; s < EMB_STEPS; ++s) { ea[s] = emb[(int64_t)(4 * s + g) * cap + pa]; eb[s] = emb[(int64_t)(4 * s + g) * cap + pb]; }
+    };
+    int64_t wbase = (int64_t)vblock * per_block + (int64_t)wv * MLP_CB * 16;
+    if (wbase >= cnt) return;
+    MlpCol A, B;
+    float nA[EMB_STEPS], nB[EMB_STEPS];                // inputs of the NEXT tile: loaded a whole tile ahead
+    load_in(wbase, A.eb, B.eb);
+    for (; wbase < cnt; wbase += step) {
+        load_in(min(wbase + step, (int64_t)cnt - 1), nA, nB);
+        st_occ1(lds, lane, g, A);
+        MLP_FENCE();
+        st_occ1(lds, lane, g, B); st_act(A);
+        mlp_interleave<20, 4>();
+        MLP_FENCE();
+        st_occ2(lds, lane, g, A); st_act(B);
+        mlp_interleave<16, 5>();
+        MLP_FENCE();
+        st_occ2(lds, lane, g, B);
+        MLP_FENCE();
+        const int64_t pa = wbase + col, pb = wbase + 16 + col;
+        if (pa < cnt) { feat[pa * 4 + g] = make_float4(A.feat[0], A.feat[1], A.feat[2], A.feat[3]); if (g == 0) occp[pa] = A.occ; }
+        if (pb < cnt) { feat[pb * 4 + g] = make_float4(B.feat[0], B.feat[1], B.feat[2], B.feat[3]); if (g == 0) occp[pb] = B.occ; }
+#pragma unroll
+        for (int s = 0; s < EMB_STEPS; ++s) { A.eb[s] = nA[s]; B.eb[s] = nB[s]; }
+    }
+}
+
+// Every workgroup serves ONE part: the parts get contiguous ranges of workgroups in proportion to their (cost-weighted) tile
+// counts (device-side counts), so a workgroup stages one LDS weight image instead of five and the per-part ceil() shares of a
+// walk over all parts disappear.  A part too small for a range of its own is taken along by the workgroup where its range
+// would start.  -> (vb, nb) of this workgroup inside part p's range, false if it does not serve p.
+__device__ __forceinline__ bool part_range(const int64_t* tiles, int64_t total, int p, int b, int G, int& vb, int& nb) {
+    int64_t cum = 0;
+    for (int q = 0; q < p; ++q) cum += tiles[q];
+    const int start = (int)(cum * G / total), end = (int)((cum + tiles[p]) * G / total);
+    if (tiles[p] == 0) return false;
+    if (end > start) { if (b < start || b >= end) return false; vb = b - start; nb = end - start; }
+    else { if (b != min(start, G - 1)) return false; vb = 0; nb = 1; }
+    return true;
+}
+
+__global__ __launch_bounds__(MLP_BLOCK, 4) void k_part_occ_all(MlpAllArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[OCC_LDS_FLOATS];
     const int per_block = (MLP_BLOCK / 64) * MLP_CB * 16, G = (int)gridDim.x, b = (int)blockIdx.x;
-    int64_t tiles[INVR_NUM_PARTS], total = 0;          // tile counts weighted by the part's cost per pair (22.1 : 14.0 kFLOP = 8 : 5)
+    int64_t tiles[INVR_NUM_PARTS], total = 0;
+    for (int p = 0; p < INVR_NUM_PARTS; ++p) { tiles[p] = (a.counts[p] + per_block - 1) / per_block; total += tiles[p]; }
+    if (total == 0) return;
     for (int p = 0; p < INVR_NUM_PARTS; ++p) {
-        tiles[p] = (int64_t)((a.counts[p] + per_block - 1) / per_block) * (a.pm[p].rgb.n_linear == 3 ? 8 : 5);
+        int vb, nb;
+        if (!part_range(tiles, total, p, b, G, vb, nb)) continue;
+        occ_part(lds, a.pm[p], a.emb[p], a.counts[p], a.cap, a.occp[p], a.feat[p], vb, nb);
+    }
+}
+
+// The merge of one survivor = arg-max of the occupancies over the five parts, zeros for unflagged parts, the first maximum wins
+// (inb_part_network_multiassign.py:229-256 with cfg.aggr == ""), evaluated here from the phase-1 occupancies; the survivors whose
+// winner is a LISTED pair are what the colour MLP still has to see.  One workgroup per group of PAIR_GROUP survivor slots — the
+// layout of k_pair_lists: the pairs of group g sit at [off_g, off_g + gcount[g][p]) of part p's list, off_g = the counts of the
+// groups before it — which writes its winners, ascending, to wl[p][off_g ...) and their number to wcnt[g][p]: no global offsets,
+// no atomics; k_part_rgb_all walks the segments.  The last group appends the far-constant pair of every part.
+#define WL_BLOCK 256
+#define WL_PER 8
+__global__ __launch_bounds__(WL_BLOCK) void k_winner_lists(Workspace w) {
+    __shared__ int s_cnt[WL_BLOCK / 64][INVR_NUM_PARTS];
+    __shared__ int s_red[WL_BLOCK / 64][INVR_NUM_PARTS];
+    const int na = w.counters[CNT_ACTIVE];
+    const int64_t g = blockIdx.x, g_last = (max(na, 1) - 1) / PAIR_GROUP;
+    if (g > g_last) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int base[INVR_NUM_PARTS], wbase[INVR_NUM_PARTS], cidx[INVR_NUM_PARTS];
+    float occc[INVR_NUM_PARTS];
+    {
+        int acc[INVR_NUM_PARTS] = {0, 0, 0, 0, 0};
+        for (int64_t q = threadIdx.x; q < g; q += WL_BLOCK)
+#pragma unroll
+            for (int p = 0; p < INVR_NUM_PARTS; ++p) acc[p] += w.gcount[q * INVR_NUM_PARTS + p];
+#pragma unroll
+        for (int p = 0; p < INVR_NUM_PARTS; ++p) {
+            for (int d = 32; d >= 1; d >>= 1) acc[p] += __shfl_xor(acc[p], d);
+            if (lane == 0) s_red[wv][p] = acc[p];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < INVR_NUM_PARTS; ++p) {
+            base[p] = 0;
+            for (int k = 0; k < WL_BLOCK / 64; ++k) base[p] += s_red[k][p];
+            wbase[p] = 0;
+            cidx[p] = w.counters[CNT_PAIRS + p] - 1;               // list index of the part's far-constant pair
+            occc[p] = w.occp[p][cidx[p]];
+        }
+    }
+    const int pbase0[INVR_NUM_PARTS] = {base[0], base[1], base[2], base[3], base[4]};
+    for (int64_t t0 = g * PAIR_GROUP; t0 < min((g + 1) * (int64_t)PAIR_GROUP, (int64_t)na); t0 += WL_BLOCK * WL_PER) {
+        const int64_t s0 = t0 + (int64_t)threadIdx.x * WL_PER;
+        unsigned long long fb = 0ull, ffb = 0ull;
+        if (s0 + WL_PER <= na) {
+            fb = *reinterpret_cast<const unsigned long long*>(w.pflags + s0);
+            ffb = *reinterpret_cast<const unsigned long long*>(w.farflags + s0);
+        } else
+            for (int k = 0; k < WL_PER; ++k) if (s0 + k < na) { fb |= (unsigned long long)w.pflags[s0 + k] << (8 * k); ffb |= (unsigned long long)w.farflags[s0 + k] << (8 * k); }
+        // list index of this thread's first pair of every part: ranks inside the thread, the wave, the block (= k_pair_lists)
+        int pos[INVR_NUM_PARTS];
+#pragma unroll
+        for (int p = 0; p < INVR_NUM_PARTS; ++p) {
+            const int mine = __popcll(fb & (0x0101010101010101ull << p));
+            int x = mine;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d); if (lane >= d) x += y; }
+            pos[p] = x - mine;
+            if (lane == 63) s_cnt[wv][p] = x;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < INVR_NUM_PARTS; ++p) {
+            pos[p] += base[p];
+            for (int k = 0; k < WL_BLOCK / 64; ++k) { const int c = s_cnt[k][p]; if (k < wv) pos[p] += c; base[p] += c; }
+        }
+        __syncthreads();                 // s_cnt is reused below
+        // the merge of the thread's WL_PER survivors
+        unsigned long long wb = 0ull, sel8 = 0ull;
+        int widx[WL_PER];
+#pragma unroll
+        for (int k = 0; k < WL_PER; ++k) {
+            const unsigned fl = (unsigned)(fb >> (8 * k)) & 0xffu, ff = (unsigned)(ffb >> (8 * k)) & 0xffu;
+            float best = 0.0f;
+            unsigned bsel = 255u;
+            int bidx = 0;
+#pragma unroll
+            for (int p = 0; p < INVR_NUM_PARTS; ++p) {
+                float c = 0.0f;
+                unsigned sel = 255u;
+                int idx = 0;
+                if (fl & (1u << p)) { idx = pos[p]++; c = w.occp[p][idx]; sel = (unsigned)p; }
+                else if (ff & (1u << p)) { c = occc[p]; sel = 8u + (unsigned)p; }
+                if (p == 0 || c > best) { best = c; bsel = sel; bidx = idx; }
+            }
+            widx[k] = bidx;
+            sel8 |= (unsigned long long)bsel << (8 * k);
+            if (bsel < (unsigned)INVR_NUM_PARTS) wb |= 1ull << (8 * k + bsel);
+        }
+        if (s0 + WL_PER <= na) *reinterpret_cast<unsigned long long*>(w.wsel + s0) = sel8;
+        else for (int k = 0; k < WL_PER; ++k) if (s0 + k < na) w.wsel[s0 + k] = (uint8_t)(sel8 >> (8 * k));
+        // winner ranks, then the lists
+        int wpos[INVR_NUM_PARTS];
+#pragma unroll
+        for (int p = 0; p < INVR_NUM_PARTS; ++p) {
+            const int mine = __popcll(wb & (0x0101010101010101ull << p));
+            int x = mine;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d); if (lane >= d) x += y; }
+            wpos[p] = x - mine;
+            if (lane == 63) s_cnt[wv][p] = x;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < INVR_NUM_PARTS; ++p) {
+            int q = pbase0[p] + wbase[p] + wpos[p];
+            for (int k = 0; k < WL_BLOCK / 64; ++k) { const int c = s_cnt[k][p]; if (k < wv) q += c; wbase[p] += c; }
+#pragma unroll
+            for (int k = 0; k < WL_PER; ++k)
+                if ((wb >> (8 * k + p)) & 1ull) w.wl[p][q++] = widx[k];
+        }
+        __syncthreads();                 // s_cnt is reused by the next tile
+    }
+    if (threadIdx.x < INVR_NUM_PARTS) {
+        const int p = threadIdx.x;
+        int nw = 0, off = 0, ci = 0;
+#pragma unroll
+        for (int q = 0; q < INVR_NUM_PARTS; ++q) if (q == p) { nw = wbase[q]; off = pbase0[q]; ci = cidx[q]; }
+        if (g == g_last) w.wl[p][off + nw++] = ci;               // the far-constant pair: always evaluated
+        w.wcnt[g * INVR_NUM_PARTS + p] = nw;
+    }
+}
+
+// Phase 2.  A wave's unit of work is a tile of 32 winners (two 16-pair column blocks) of ONE segment (slot group); tile t of a
+// part -> (segment, offset) through a wave-cooperative cursor: 64 segments per window (lane = segment), tile / pair prefix sums
+// by wave scans, the window advanced as the wave's tile index grows — no per-part scan kernel, no LDS, any number of groups.
+struct SegCursor {
+    int g0, tiles_before, pairs_before;      // window start; tiles / pairs of the segments before it
+    int wc, tl, ti, pe;                      // this lane's segment: winners, tiles, inclusive tile prefix, exclusive pair prefix
+    int win_tiles, win_pairs;
+};
+__device__ __forceinline__ void seg_window(SegCursor& c, const int32_t* __restrict__ wcnt, const int32_t* __restrict__ gcount,
+                                           int part, int g_last, int lane) {
+    const int gi = c.g0 + lane;
+    const bool ok = gi <= g_last;
+    c.wc = ok ? wcnt[(int64_t)gi * INVR_NUM_PARTS + part] : 0;
+    const int gc = ok ? gcount[(int64_t)gi * INVR_NUM_PARTS + part] : 0;
+    c.tl = (c.wc + 31) >> 5;
+    int x = c.tl, y = gc;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int x2 = __shfl_up(x, d), y2 = __shfl_up(y, d);
+        if (lane >= d) { x += x2; y += y2; }
+    }
+    c.ti = x; c.pe = y - gc;
+    c.win_tiles = __shfl(x, 63); c.win_pairs = __shfl(y, 63);
+}
+// -> first tile of the segment that holds tile T, the segment's offset in the lists and its winner count
+__device__ __forceinline__ void seg_locate(SegCursor& c, int T, const int32_t* __restrict__ wcnt, const int32_t* __restrict__ gcount,
+                                           int part, int g_last, int lane, int& seg_tile0, int& sb, int& sn) {
+    while (T >= c.tiles_before + c.win_tiles && c.g0 + 64 <= g_last) {
+        c.tiles_before += c.win_tiles; c.pairs_before += c.win_pairs; c.g0 += 64;
+        seg_window(c, wcnt, gcount, part, g_last, lane);
+    }
+    const unsigned long long m = __ballot(c.tiles_before + c.ti > T);
+    const int L = m ? __ffsll((long long)m) - 1 : 63;
+    seg_tile0 = c.tiles_before + __shfl(c.ti - c.tl, L);
+    sb = c.pairs_before + __shfl(c.pe, L);
+    sn = __shfl(c.wc, L);
+}
+
+struct RgbIn { float eb[EMB_STEPS]; float dv[3]; float4 ft; };
+
+template <int NRGB>
+__device__ __forceinline__ void rgb_part(float* lds, const MlpAllArgs& a, const int part, const int g_last, const int total_tiles,
+                                         const int vblock, const int nblocks) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, col = lane & 15;
+    if (vblock * (MLP_BLOCK / 64) >= total_tiles) return;
+    __syncthreads();                                   // previous part's weights no longer in use
+    stage_weights<NRGB, true, 2>(a.pm[part], lds);
+    __syncthreads();
+    const float fmul = (float)(1 << g);                          // frequency 2^g of this lane group
+    const float* __restrict__ emb = a.emb[part];
+    const float* __restrict__ ds = a.ds[part];
+    const float4* __restrict__ feat = a.feat[part];
+    const float* __restrict__ occp = a.occp[part];
+    const int32_t* __restrict__ l_slot = a.l_slot[part];
+    const int32_t* __restrict__ wl = a.wl[part];
+    const int64_t cap = a.cap;
+    const int step = nblocks * (MLP_BLOCK / 64);
+    int T = vblock * (MLP_BLOCK / 64) + wv;
+    if (T >= total_tiles) return;
+    SegCursor cur;
+    cur.g0 = 0; cur.tiles_before = 0; cur.pairs_before = 0;
+    seg_window(cur, a.wcnt, a.gcount, part, g_last, lane);
+    // pair indices of tile T (-1 = column beyond the segment's winners; the loads then read the segment's last winner)
+    auto tile_pairs = [&](int T_, int& ia, int& ib, bool& va, bool& vb_) {
+        int t0, sb, sn;
+        seg_locate(cur, T_, a.wcnt, a.gcount, part, g_last, lane, t0, sb, sn);
+        const int ja = (T_ - t0) * 32 + col, jb = ja + 16;
+        va = ja < sn; vb_ = jb < sn;
+        ia = wl[sb + min(ja, sn - 1)]; ib = wl[sb + min(jb, sn - 1)];
+    };
+    auto load_in = [&](int pa, int pb, RgbIn& A, RgbIn& B) {
+#pragma unroll
+        for (int s = 0; s < EMB_STEPS; ++s) { A.eb[s] = emb[(int64_t)(4 * s + g) * cap + pa]; B.eb[s] = emb[(int64_t)(4 * s + g) * cap + pb]; }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { A.dv[c] = ds[(int64_t)c * a.stride + pa]; B.dv[c] = ds[(int64_t)c * a.stride + pb]; }
+        A.ft = feat[(int64_t)pa * 4 + g]; B.ft = feat[(int64_t)pb * 4 + g];
+    };
+    // software pipeline: inputs one tile ahead, pair indices two tiles ahead (a list read and the gathers it feeds are two
+    // dependent round trips)
+    int ia, ib, n_ia, n_ib, nn_ia = 0, nn_ib = 0;
+    bool va, vb, n_va, n_vb, nn_va = false, nn_vb = false;
+    RgbIn inA, inB, nA, nB;
+    tile_pairs(T, ia, ib, va, vb);
+    load_in(ia, ib, inA, inB);
+    n_ia = ia; n_ib = ib; n_va = n_vb = false;
+    if (T + step < total_tiles) tile_pairs(T + step, n_ia, n_ib, n_va, n_vb);
+    for (; T < total_tiles; T += step) {
+        load_in(n_ia, n_ib, nA, nB);                              // (tile T + step; unused past the last tile)
+        nn_ia = n_ia; nn_ib = n_ib; nn_va = nn_vb = false;
+        if (T + 2 * step < total_tiles) tile_pairs(T + 2 * step, nn_ia, nn_ib, nn_va, nn_vb);
+        const int slotA = l_slot[ia], slotB = l_slot[ib];         // consumed by the stores at the end of the tile
+        const float occA = occp[ia], occB = occp[ib];
+        MlpCol A, B;
+#pragma unroll
+        for (int s = 0; s < EMB_STEPS; ++s) { A.eb[s] = inA.eb[s]; B.eb[s] = inB.eb[s]; }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { A.dv[c] = inA.dv[c]; B.dv[c] = inB.dv[c]; }
+        A.feat[0] = inA.ft.x; A.feat[1] = inA.ft.y; A.feat[2] = inA.ft.z; A.feat[3] = inA.ft.w;
+        B.feat[0] = inB.ft.x; B.feat[1] = inB.ft.y; B.feat[2] = inB.ft.z; B.feat[3] = inB.ft.w;
+        A.occ = occA; B.occ = occB;
+        st_rgb_in(A, g, fmul);
+        MLP_FENCE();
+        st_rgb1(lds, lane, g, A); st_rgb_in(B, g, fmul);
+        mlp_interleave<30, 1>();
+        MLP_FENCE();
+        st_rgb1(lds, lane, g, B); st_act(A);
+        mlp_interleave<64, 1>();
+        MLP_FENCE();
+        float4 rA, rB;
+        if (NRGB == 3) {
+            st_rgb2(lds, lane, g, A); st_act(B);
+            mlp_interleave<64, 1>();
+            MLP_FENCE();
+            st_rgb2(lds, lane, g, B); st_act(A);
+            mlp_interleave<64, 1>();
+            MLP_FENCE();
+            rA = st_head(lds, g, A); st_act(B);
+            MLP_FENCE();
+            rB = st_head(lds, g, B);
+        } else {
+            rA = st_head(lds, g, A); st_act(B);
+            MLP_FENCE();
+            rB = st_head(lds, g, B);
+        }
+        if (g == 0) {
+            if (va) a.rgbw[slotA == (int)(cap - 1) ? cap + part : (int64_t)slotA] = rA;
+            if (vb) a.rgbw[slotB == (int)(cap - 1) ? cap + part : (int64_t)slotB] = rB;
+        }
+        inA = nA; inB = nB;
+        ia = n_ia; ib = n_ib; va = n_va; vb = n_vb;
+        n_ia = nn_ia; n_ib = nn_ib; n_va = nn_va; n_vb = nn_vb;
+    }
+}
+
+__global__ __launch_bounds__(MLP_BLOCK, 3) void k_part_rgb_all(MlpAllArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    __shared__ int s_tot[INVR_NUM_PARTS];
+    const int G = (int)gridDim.x, b = (int)blockIdx.x, lane = threadIdx.x & 63;
+    const int na = a.n_active[0], g_last = (max(na, 1) - 1) / PAIR_GROUP;
+    if (threadIdx.x < INVR_NUM_PARTS) s_tot[threadIdx.x] = 0;
+    __syncthreads();
+    {   // winner tiles per part (every workgroup sums the segment counts itself)
+        int acc[INVR_NUM_PARTS] = {0, 0, 0, 0, 0};
+        for (int q = threadIdx.x; q <= g_last; q += MLP_BLOCK)
+#pragma unroll
+            for (int p = 0; p < INVR_NUM_PARTS; ++p) acc[p] += (a.wcnt[(int64_t)q * INVR_NUM_PARTS + p] + 31) >> 5;
+#pragma unroll
+        for (int p = 0; p < INVR_NUM_PARTS; ++p) {
+            for (int d = 32; d >= 1; d >>= 1) acc[p] += __shfl_xor(acc[p], d);
+            if (lane == 0 && acc[p]) atomicAdd(&s_tot[p], acc[p]);
+        }
+    }
+    __syncthreads();
+    int ntile[INVR_NUM_PARTS];
+    int64_t tiles[INVR_NUM_PARTS], total = 0;          // tile counts weighted by the part's colour-MLP cost per pair (17.5 : 9.3 kFLOP)
+    for (int p = 0; p < INVR_NUM_PARTS; ++p) {
+        ntile[p] = s_tot[p];
+        tiles[p] = (int64_t)((ntile[p] + (MLP_BLOCK / 64) - 1) / (MLP_BLOCK / 64)) * (a.pm[p].rgb.n_linear == 3 ? 15 : 8);
         total += tiles[p];
     }
     if (total == 0) return;
-    int64_t cum = 0;
     for (int p = 0; p < INVR_NUM_PARTS; ++p) {
-        const int start = (int)(cum * G / total), end = (int)((cum + tiles[p]) * G / total);
-        cum += tiles[p];
-        if (tiles[p] == 0) continue;
         int vb, nb;
-        if (end > start) { if (b < start || b >= end) continue; vb = b - start; nb = end - start; }
-        else { if (b != min(start, G - 1)) continue; vb = 0; nb = 1; }
-        if (a.pm[p].rgb.n_linear == 3)
-            mlp_part<3>(lds, a.pm[p], a.emb[p], a.ds[p], a.stride, a.l_slot[p], a.counts[p], a.cap, a.raws, p, nullptr, vb, nb);
-        else
-            mlp_part<2>(lds, a.pm[p], a.emb[p], a.ds[p], a.stride, a.l_slot[p], a.counts[p], a.cap, a.raws, p, nullptr, vb, nb);
+        if (!part_range(tiles, total, p, b, G, vb, nb)) continue;
+        if (a.pm[p].rgb.n_linear == 3) rgb_part<3>(lds, a, p, g_last, ntile[p], vb, nb);
+        else rgb_part<2>(lds, a, p, g_last, ntile[p], vb, nb);
     }
 }
 
@@ -254,7 +590,7 @@ static bool part_mlp_supported(const PartMlpDev& pm) {
            pm.n_freq == 4 && pm.latent_dim == 8 && pm.geo_dim == 16;
 }
 
-int launch_part_mlp_all(const MlpAllArgs& a, hipStream_t st) {
+int launch_part_mlp_all(const MlpAllArgs& a, const Workspace& w, hipStream_t st) {
     for (int p = 0; p < INVR_NUM_PARTS; ++p)
         if (!part_mlp_supported(a.pm[p])) {
             invr_set_error("part MLP kernel supports occ 19-64-17 and rgb 70-64(-64)-3 with 4 view-dir frequencies, latent 8, geo feature 16");
@@ -262,15 +598,19 @@ int launch_part_mlp_all(const MlpAllArgs& a, hipStream_t st) {
         }
     const int64_t per_block = (MLP_BLOCK / 64) * MLP_CB * 16;
     int64_t tiles = cdiv(a.cap, per_block);
-    unsigned grid = (unsigned)(tiles < 256 * 3 ? (tiles > 0 ? tiles : 1) : 256 * 3);
-    hipLaunchKernelGGL(k_part_mlp_all, dim3(grid), dim3(MLP_BLOCK), 0, st, a);
+    unsigned grid_occ = (unsigned)(tiles < 256 * 4 ? (tiles > 0 ? tiles : 1) : 256 * 4);
+    unsigned grid_rgb = (unsigned)(tiles < 256 * 3 ? (tiles > 0 ? tiles : 1) : 256 * 3);
+    hipLaunchKernelGGL(k_part_occ_all, dim3(grid_occ), dim3(MLP_BLOCK), 0, st, a);
+    INVR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_winner_lists, dim3((unsigned)w.n_groups), dim3(WL_BLOCK), 0, st, w);
+    INVR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_part_rgb_all, dim3(grid_rgb), dim3(MLP_BLOCK), 0, st, a);
     INVR_LAUNCH_CHECK();
     return 0;
 }
 
 int launch_part_mlp(const PartMlpDev& pm, const float* emb, const float* d_soa, int64_t stride,
-                    const int32_t* l_slot, const int32_t* count, int64_t cap, float4* raws, int part,
-                    float4* raw_direct, hipStream_t st) {
+                    const int32_t* count, int64_t cap, float4* raw_direct, hipStream_t st) {
     const MlpDev& o = pm.occ;
     const MlpDev& r = pm.rgb;
     bool ok = o.n_linear == 2 && o.dims[0] == 19 && o.dims[1] == HID && o.dims[2] == 17 &&
@@ -286,9 +626,9 @@ int launch_part_mlp(const PartMlpDev& pm, const float* emb, const float* d_soa, 
     static int wpb = getenv("INVR_MLP_BPC") ? atoi(getenv("INVR_MLP_BPC")) : 3;
     unsigned grid = (unsigned)(tiles < 256 * wpb ? (tiles > 0 ? tiles : 1) : 256 * wpb);
     if (r.n_linear == 3)
-        hipLaunchKernelGGL(k_part_mlp<3>, dim3(grid), dim3(MLP_BLOCK), 0, st, pm, emb, d_soa, stride, l_slot, count, cap, raws, part, raw_direct);
+        hipLaunchKernelGGL(k_part_mlp<3>, dim3(grid), dim3(MLP_BLOCK), 0, st, pm, emb, d_soa, stride, count, cap, raw_direct);
     else
-        hipLaunchKernelGGL(k_part_mlp<2>, dim3(grid), dim3(MLP_BLOCK), 0, st, pm, emb, d_soa, stride, l_slot, count, cap, raws, part, raw_direct);
+        hipLaunchKernelGGL(k_part_mlp<2>, dim3(grid), dim3(MLP_BLOCK), 0, st, pm, emb, d_soa, stride, count, cap, raw_direct);
     INVR_LAUNCH_CHECK();
     return 0;
 }

@@ -63,8 +63,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_train_terms(Workspace w, TrainWs t
         const float r0 = w.l_r[p][i], r1 = w.l_r[p][w.lcap + i], r2 = w.l_r[p][2 * w.lcap + i];
         acc += sqrtf(r0 * r0 + r1 * r1 + r2 * r2);
         if (!noise) continue;
-        const bool listed = (w.pflags[slot] >> p) & 1u;
-        const float tocc = w.raws[(listed ? (int64_t)slot : w.cap) * INVR_NUM_PARTS + p].w;
+        const float tocc = w.occp[p][i];
         if (fabsf(tocc - 0.5f) < 0.02f) {
             const int k = atomicAdd(&w.counters[CNT_NB], 1);
             if (k < t.NB) {
@@ -195,18 +194,10 @@ __global__ __launch_bounds__(256) void k_distortion_bwd(const float* __restrict_
 __global__ __launch_bounds__(256) void k_merge_bwd(Workspace w, const float4* __restrict__ g_rawfull, float4* __restrict__ g_raws) {
     const int na = w.counters[CNT_ACTIVE];
     for (int slot = blockIdx.x * blockDim.x + threadIdx.x; slot < na; slot += gridDim.x * blockDim.x) {
-        const unsigned fl = w.pflags[slot], ff = w.farflags[slot];
-        int best_p = 0;
-        float best = 0.0f;
-        bool best_far = false;
-#pragma unroll
-        for (int p = 0; p < INVR_NUM_PARTS; ++p) {
-            float occ = 0.0f;
-            bool far = false;
-            if (fl & (1u << p)) occ = w.raws[(int64_t)slot * INVR_NUM_PARTS + p].w;
-            else if (ff & (1u << p)) { occ = w.raws[w.cap * INVR_NUM_PARTS + p].w; far = true; }
-            if (p == 0 || occ > best) { best = occ; best_p = p; best_far = far; }
-        }
+        // the forward's merge (k_winner_lists): p = the listed pair of part p, 8 + p = the far constant of part p, 255 = zeros
+        const unsigned sel = w.wsel[slot];
+        const int best_p = sel < 16u ? (int)(sel & 7u) : -1;
+        const bool best_far = sel >= 8u && sel < 16u;
         const float4 g = g_rawfull[w.active_idx[slot]];
 #pragma unroll
         for (int p = 0; p < INVR_NUM_PARTS; ++p)

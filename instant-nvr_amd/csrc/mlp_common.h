@@ -53,50 +53,58 @@ __device__ __forceinline__ int hid_col(int s, int g) { return 16 * (s >> 2) + 4 
 // and bias), a layer that consumes Softplus outputs by ln2; for a hidden-to-hidden layer the two cancel exactly (only its bias is
 // scaled).  The activation then costs {min, exp2, add, log2} = 4 single-issue VALU per value instead of 4.5 issue slots with packed
 // multiplies, which are expensive beside MFMAs (MI355X_MICROARCH.md "price of one filler beside MFMAs").
-template <int NRGB, bool LOG2DOM = false>   // number of rgb linears: 2 (70-64-3) or 3 (70-64-64-3)
+template <int NRGB, bool LOG2DOM = false, int WHAT = 3>   // NRGB: number of rgb linears, 2 (70-64-3) or 3 (70-64-64-3); WHAT: 1 = occ MLP, 2 = rgb MLP, 3 = both
 __device__ void stage_weights(const PartMlpDev& pm, float* lds) {
     const float s_in = LOG2DOM ? INVR_LOG2E : 1.0f, s_out = LOG2DOM ? INVR_LN2 : 1.0f;
     const float* W0 = pm.occ.w[0]; const float* W1 = pm.occ.w[1];
     const float* R0 = pm.rgb.w[0]; const float* R1 = pm.rgb.w[1]; const float* R2 = pm.rgb.w[NRGB - 1];
-    for (int t = threadIdx.x; t < EMB_STEPS * 4 * 64; t += MLP_BLOCK) {
-        int ln = t & 63, mt = (t >> 6) & 3, s = t >> 8, g = ln >> 4, i = ln & 15;
-        int col = 4 * s + g;
-        lds[O_W_OCC1 + (LOG2DOM ? (s * 64 + ln) * 4 + mt : t)] = col < 19 ? W0[(16 * mt + i) * 19 + col] * s_in : 0.0f;
-    }
-    for (int t = threadIdx.x; t < 16 * 64; t += MLP_BLOCK) {
-        int ln = t & 63, s = t >> 6, g = ln >> 4, i = ln & 15;
-        lds[O_W_OCC2 + (LOG2DOM ? ((s >> 2) * 64 + ln) * 4 + (s & 3) : t)] = W1[(1 + i) * HID + hid_col(s, g)] * s_out;
-    }
-    for (int t = threadIdx.x; t < (LOG2DOM ? RGB1F_STEPS : RGB1_STEPS) * 4 * 64; t += MLP_BLOCK) {
-        int ln = t & 63, mt = (t >> 6) & 3, s = t >> 8, g = ln >> 4, i = ln & 15;
-        int col = LOG2DOM ? rgb1f_col(s, g) : rgb1_col(s, g);
-        lds[O_W_RGB1 + (LOG2DOM ? (s * 64 + ln) * 4 + mt : t)] = col >= 0 ? R0[(16 * mt + i) * 70 + col] * s_in : 0.0f;
-    }
-    if (NRGB == 3)
-        for (int t = threadIdx.x; t < 16 * 4 * 64; t += MLP_BLOCK) {
+    if (WHAT & 1) {
+        for (int t = threadIdx.x; t < EMB_STEPS * 4 * 64; t += MLP_BLOCK) {
             int ln = t & 63, mt = (t >> 6) & 3, s = t >> 8, g = ln >> 4, i = ln & 15;
-            lds[O_W_RGB2 + (LOG2DOM ? (s * 64 + ln) * 4 + mt : t)] = R1[(16 * mt + i) * HID + hid_col(s, g)];
+            int col = 4 * s + g;
+            lds[O_W_OCC1 + (LOG2DOM ? (s * 64 + ln) * 4 + mt : t)] = col < 19 ? W0[(16 * mt + i) * 19 + col] * s_in : 0.0f;
         }
+        for (int t = threadIdx.x; t < 16 * 64; t += MLP_BLOCK) {
+            int ln = t & 63, s = t >> 6, g = ln >> 4, i = ln & 15;
+            lds[O_W_OCC2 + (LOG2DOM ? ((s >> 2) * 64 + ln) * 4 + (s & 3) : t)] = W1[(1 + i) * HID + hid_col(s, g)] * s_out;
+        }
+    }
+    if (WHAT & 2) {
+        for (int t = threadIdx.x; t < (LOG2DOM ? RGB1F_STEPS : RGB1_STEPS) * 4 * 64; t += MLP_BLOCK) {
+            int ln = t & 63, mt = (t >> 6) & 3, s = t >> 8, g = ln >> 4, i = ln & 15;
+            int col = LOG2DOM ? rgb1f_col(s, g) : rgb1_col(s, g);
+            lds[O_W_RGB1 + (LOG2DOM ? (s * 64 + ln) * 4 + mt : t)] = col >= 0 ? R0[(16 * mt + i) * 70 + col] * s_in : 0.0f;
+        }
+        if (NRGB == 3)
+            for (int t = threadIdx.x; t < 16 * 4 * 64; t += MLP_BLOCK) {
+                int ln = t & 63, mt = (t >> 6) & 3, s = t >> 8, g = ln >> 4, i = ln & 15;
+                lds[O_W_RGB2 + (LOG2DOM ? (s * 64 + ln) * 4 + mt : t)] = R1[(16 * mt + i) * HID + hid_col(s, g)];
+            }
+    }
     for (int t = threadIdx.x; t < 64; t += MLP_BLOCK) {
-        lds[O_B_OCC1 + t] = pm.occ.b[0][t] * s_in;
-        float b1 = pm.rgb.b[0][t];
-        if (LOG2DOM) {                                           // + W[:, latent] . latent (the latent block of the rgb input)
-            const float* lat = pm.rgb_latent + pm.latent_index[0] * pm.latent_dim;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) b1 = fmaf(R0[t * 70 + 62 + j], lat[j], b1);
-        }
-        lds[O_B_RGB1 + t] = b1 * s_in;
-        if (NRGB == 3) lds[O_B_RGB2 + t] = pm.rgb.b[1][t] * s_in;      // (rgb2 weights: ln2 * log2e = 1, unscaled)
         int g = t >> 4, u = t & 15;                              // slot order: [g][mt*4+r]
         int hc = 16 * (u >> 2) + 4 * g + (u & 3);
-        lds[O_V_OCC + t] = W1[hc] * s_out;                       // occ logit row 0
+        if (WHAT & 1) {
+            lds[O_B_OCC1 + t] = pm.occ.b[0][t] * s_in;
+            lds[O_V_OCC + t] = W1[hc] * s_out;                   // occ logit row 0
+        }
+        if (WHAT & 2) {
+            float b1 = pm.rgb.b[0][t];
+            if (LOG2DOM) {                                       // + W[:, latent] . latent (the latent block of the rgb input)
+                const float* lat = pm.rgb_latent + pm.latent_index[0] * pm.latent_dim;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) lds[O_V_OUT + c * 64 + t] = R2[c * HID + hc] * s_out;
+                for (int j = 0; j < 8; ++j) b1 = fmaf(R0[t * 70 + 62 + j], lat[j], b1);
+            }
+            lds[O_B_RGB1 + t] = b1 * s_in;
+            if (NRGB == 3) lds[O_B_RGB2 + t] = pm.rgb.b[1][t] * s_in;      // (rgb2 weights: ln2 * log2e = 1, unscaled)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) lds[O_V_OUT + c * 64 + t] = R2[c * HID + hc] * s_out;
+        }
     }
-    if (threadIdx.x < 16) lds[O_B_OCC2 + threadIdx.x] = pm.occ.b[1][1 + threadIdx.x];
+    if ((WHAT & 1) && threadIdx.x < 16) lds[O_B_OCC2 + threadIdx.x] = pm.occ.b[1][1 + threadIdx.x];
     if (threadIdx.x == 0) {
-        lds[O_V_OCC + 64] = pm.occ.b[1][0];
-        for (int c = 0; c < 3; ++c) lds[O_V_OUT + 3 * 64 + c] = pm.rgb.b[NRGB - 1][c];
+        if (WHAT & 1) lds[O_V_OCC + 64] = pm.occ.b[1][0];
+        if (WHAT & 2) for (int c = 0; c < 3; ++c) lds[O_V_OUT + 3 * 64 + c] = pm.rgb.b[NRGB - 1][c];
     }
 }
 

@@ -67,7 +67,16 @@ struct Workspace {
     float* l_d[INVR_NUM_PARTS];           // 3*cap : canonical view dir, SoA
     float* l_r[INVR_NUM_PARTS];           // 3*cap : residual deformation (resd), SoA
     float* emb[INVR_NUM_PARTS];           // EMB_K*cap each : encoder output of part p, SoA [k][pair]
-    float4* raws;                         // cap*P : [rgb, occ] per (slot, part)
+    // part MLPs, phase 1 (every listed pair): occupancy + the 16 geometry features; phase 2 (the rgb MLP) only runs for the
+    // pair that wins the max-occupancy merge of its survivor (inb_part_network_multiassign.py:253-256 keeps nothing else)
+    float* occp[INVR_NUM_PARTS];          // cap : occupancy of every listed pair (list order; last entry = the far constant)
+    float4* feat[INVR_NUM_PARTS];         // 4*cap : occ-MLP outputs 1..16 of every listed pair, [pair][16]
+    int32_t* wl[INVR_NUM_PARTS];          // cap : winner lists, segmented by slot group: the winners of group g sit at
+                                          //       wl[p][pair offset of g ...), wcnt[g][p] of them (pair indices, ascending)
+    int32_t* wcnt;                        // [n_groups][INVR_NUM_PARTS]
+    uint8_t* wsel;                        // cap : merge result per survivor: p = listed pair of part p wins, 8 + p = far constant of
+                                          //       part p wins, 255 = zeros (no flagged part, or an unflagged part 0 ties at 0)
+    float4* rgbw;                         // cap + 8 : [rgb, occ] of the winning listed pair per survivor; [lcap + p] = far constant of part p
     uint8_t* cullmask;                    // CULL_MASK_MAX : 1 if the trilinear cell can hold a survivor (k_cull.hip)
     float2* dslice;                       // DF_SLICE_MAX : per-frame t-slices of the deformer grid (k_warp.hip)
     int64_t cap;                          // max survivors
@@ -146,8 +155,7 @@ struct PartMlpDev {
     int32_t latent_dim, n_freq, geo_dim;
 };
 int launch_part_mlp(const PartMlpDev& pm, const float* emb, const float* d_soa, int64_t stride,
-                    const int32_t* l_slot, const int32_t* count, int64_t cap, float4* raws, int part,
-                    float4* raw_direct, hipStream_t st);
+                    const int32_t* count, int64_t cap, float4* raw_direct, hipStream_t st);
 struct MlpBwdOut {                 // k_mlp_bwd.hip; mirrors InvrMlpBwdOut
     float* g_emb; float* gz; float* a; int64_t n_pad; float* g_latent;
     int latent_full;       // 1: g_latent is the whole (num_latent_code, latent_dim) gradient tensor, row latent_index is accumulated
@@ -161,8 +169,15 @@ struct MlpAllArgs {               // k_part_mlp_all
     const int32_t* l_slot[INVR_NUM_PARTS];
     const int32_t* counts;
     int64_t stride, cap;
-    float4* raws;
+    float* occp[INVR_NUM_PARTS];
+    float4* feat[INVR_NUM_PARTS];
+    const int32_t* wl[INVR_NUM_PARTS];
+    const int32_t* wcnt;
+    const int32_t* gcount;
+    const int32_t* n_active;      // counters + CNT_ACTIVE
+    float4* rgbw;                 // [slot]; far constants at [cap + p] (cap = the list capacity lcap here)
 };
-int launch_part_mlp_all(const MlpAllArgs& a, hipStream_t st);
+// occ phase over every listed pair -> k_winner_lists -> rgb phase over the winners
+int launch_part_mlp_all(const MlpAllArgs& a, const Workspace& w, hipStream_t st);
 int launch_merge_composite(const RenderArgs& a, const Workspace& w, float* rgb_map, float* acc_map, float* raw,
                            float* occ, float* weights, hipStream_t st);

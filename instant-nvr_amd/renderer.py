@@ -142,7 +142,7 @@ class Renderer:
         resd = torch.zeros(Na + 1, P, 3, device=dev)
         tpts = torch.zeros(Na + 1, P, 3, device=dev)
         tocc = torch.zeros(Na + 1, P, device=dev)
-        raws = v['raws']
+        occp = v['occp']
         far = v['farflags'][:Na].to(torch.int32)
         for p in range(P):
             cnt = int(stats[1 + p])
@@ -151,7 +151,7 @@ class Renderer:
             r = v['l_r'][p][:, :cnt].t()
             resd[rows, p] = r
             tpts[rows, p] = v['l_x'][p][:, :cnt].t() - r
-            tocc[rows, p] = raws[slots, p, 3]
+            tocc[rows, p] = occp[p][:cnt]
             fr = ((far >> p) & 1).nonzero(as_tuple=True)[0]
             if fr.numel():
                 resd[fr, p] = resd[Na, p]
@@ -202,7 +202,7 @@ class Renderer:
         resd = torch.zeros(Na + 1, P, 3, device=dev)
         tpts = torch.zeros(Na + 1, P, 3, device=dev)
         tocc = torch.zeros(Na + 1, P, device=dev)
-        raws = v['raws']
+        occp = v['occp']
         far = v['farflags'][:Na].to(torch.int32)
         for p in range(P):
             cnt = int(stats[1 + p])
@@ -211,7 +211,7 @@ class Renderer:
             r = v['l_r'][p][:, :cnt].t()
             resd[rows, p] = r
             tpts[rows, p] = v['l_x'][p][:, :cnt].t() - r                                 # init_bigpose
-            tocc[rows, p] = raws[slots, p, 3]
+            tocc[rows, p] = occp[p][:cnt]
             fr = ((far >> p) & 1).nonzero(as_tuple=True)[0]                              # far pairs take the constant
             if fr.numel():
                 resd[fr, p] = resd[Na, p]
