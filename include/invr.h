@@ -186,6 +186,7 @@ typedef struct InvrWsLayout {
                                               part p, 255 = zeros                                                                    */
     int64_t rgbw;                          /* float4[lcap+8]: [rgb, occ] of the winning listed pair per survivor; [lcap+p] = far constant of part p */
     int64_t n_groups;
+    int64_t knn_dfar2;                     /* float[1]: squared far-fold distance of the frame (0.4624 = (0.68 m)^2 while |A|, |big_A| entries <= 2) */
 } InvrWsLayout;
 int invr_workspace_layout(int64_t n_rays, int32_t n_samples, int64_t max_active, InvrWsLayout* out);
 

@@ -79,7 +79,7 @@ class InvrWsLayout(C.Structure):
                 ('l_slot', C.c_int64 * NUM_PARTS), ('l_nn', C.c_int64 * NUM_PARTS), ('l_w', C.c_int64 * NUM_PARTS),
                 ('l_x', C.c_int64 * NUM_PARTS), ('l_d', C.c_int64 * NUM_PARTS), ('l_r', C.c_int64 * NUM_PARTS),
                 ('emb', C.c_int64 * NUM_PARTS), ('occp', C.c_int64 * NUM_PARTS), ('wl', C.c_int64 * NUM_PARTS),
-                ('wcnt', C.c_int64), ('wsel', C.c_int64), ('rgbw', C.c_int64), ('n_groups', C.c_int64)]
+                ('wcnt', C.c_int64), ('wsel', C.c_int64), ('rgbw', C.c_int64), ('n_groups', C.c_int64), ('knn_dfar2', C.c_int64)]
 
 
 EXPORTS = ['invr_last_error', 'invr_version', 'invr_sizeof', 'invr_workspace_bytes', 'invr_render_fwd',
@@ -215,6 +215,7 @@ def ws_views(ws, n_rays, S, max_active, n_active=None):
          'word_off': view(lay.word_off, (n_rays * S + 1023) // 1024 * 16, torch.int32),
          'mask': view(lay.mask, (n_rays * S + 1023) // 1024 * 16, torch.int64),
          'pflags': view(lay.pflags, lc, torch.uint8), 'farflags': view(lay.farflags, lc, torch.uint8),
+         'knn_dfar2': view(lay.knn_dfar2, 1, torch.float32),
          'wsel': view(lay.wsel, lc, torch.uint8),                   # merge result per survivor (p / 8 + p / 255)
          'rgbw': view(lay.rgbw, (lc + 8) * 4, torch.float32).view(lc + 8, 4),      # winner's [rgb, occ] per slot; far constants at lc + p
          'wcnt': view(lay.wcnt, lay.n_groups * NUM_PARTS, torch.int32).view(lay.n_groups, NUM_PARTS)}

@@ -278,7 +278,7 @@ def distortion(weights, z):
     return ((weights[:, :, None] * weights[:, None, :]) * (mid[:, :, None] - mid[:, None, :]).abs()).sum(-1).sum(-1)
 
 
-def render_train(net, batch, geo, views, stats, n_rays, S, pair_noise):
+def render_train(net, batch, geo, views, stats, n_rays, S, pair_noise, ctx=None, rays=None, jitter=None):
     """Differentiable recomputation of one training forward on the pair lists `views` left by the HIP
     geometry pass `geo` (= Network.render_rays output).  Returns the reference's train-mode dict."""
     cfg = net.cfg
@@ -325,6 +325,17 @@ def render_train(net, batch, geo, views, stats, n_rays, S, pair_noise):
     raws = raws_flat.view(Na + 1, P, 4)[:Na]
     resd = resd_flat.view(Na + 1, P, 3)[:Na]
     tpts = tpts_flat.view(Na + 1, P, 3)[:Na]
+    if ctx is not None and Na:
+        # rows that are neither listed nor far: init_bigpose under that part's 4-NN weights, as the reference computes it for
+        # all Na x P rows (inb_part_network_multiassign.py:96-120) — see renderer.dense_train_rows
+        from . import stages
+        ro, rd, nr, fa = rays
+        with torch.no_grad():
+            pts, pdirs = stages.pose_points(ctx.scene, ro, rd, nr, fa, S, views['active_idx'][:Na], jitter=jitter)
+            bw, _ = stages.knn_blend(ctx.scene, pts)
+            tp, _, _ = stages.warp_deform(ctx.scene, ctx.model, pts, pdirs, bw, torch.zeros(Na, P, dtype=torch.uint8, device=dev))
+            known = (((views['pflags'][:Na].to(torch.int32) | far)[:, None] >> torch.arange(P, device=dev)[None]) & 1).bool()
+        tpts = torch.where(known[..., None], tpts, tp)
     tocc = raws[..., 3]
     ind = tocc.argmax(dim=1)                                                             # :253
     merged = raws[torch.arange(Na, device=dev), ind]

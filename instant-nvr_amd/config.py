@@ -69,6 +69,8 @@ DEFAULTS = {
     'num_train_frame': 100,
     'num_latent_code': 100,
     'knn_k': 4,
+    'use_knn': True,
+    'part_deform': False,
     'use_batch_bounds': True,
     'bbox_overlap': 0.2,
     'pair_loss_weight': 10.0,
@@ -114,6 +116,37 @@ def make_cfg(**overrides):
     return c
 
 
+# Switches of the reference's path that this build does not implement.  A value other than the one listed makes
+# Network.__init__ / adopt() RAISE: the HIP path would otherwise silently render the default behaviour (arg-max merge, K = 4, no
+# background, shared deformer) under a config that asks for something else.  (cfg.N_importance — 128 in inb_377.yaml — is read by
+# nothing in the reference's lib/: it is ignored here as it is there.)
+UNSUPPORTED = {
+    'aggr': ('', "cfg.aggr in {'mean', 'dist', 'mindist'} (inb_part_network_multiassign.py:237-251): only the default max-occupancy merge is built"),
+    'knn_k': (4, 'cfg.knn_k != 4 (blend_utils.py:732-763): the KNN / skinning kernels are built for K = 4'),
+    'random_bg': (False, 'cfg.random_bg (inb_renderer.py:72, net_utils.py:29-44): only the background-free compositing is built'),
+    'part_deform': (False, 'cfg.part_deform (inb_part_network_multiassign.py:72,110): the reference itself asserts it off on this path'),
+    'tpose_viewdir': (True, 'cfg.tpose_viewdir = False: TPoseHuman.forward indexes the (Na,P,3) view directions per part; the reference cannot run it either'),
+    'use_knn': (True, 'cfg.use_knn = False: Network.__init__ of the reference asserts it'),
+}
+
+
+def validate(c):
+    """Raise ValueError if `c` asks for a reference switch this build does not implement (see UNSUPPORTED)."""
+    for k, (want, why) in UNSUPPORTED.items():
+        have = c.get(k, want) if hasattr(c, 'get') else getattr(c, k, want)
+        if have is None:
+            have = want
+        if isinstance(want, bool):
+            ok = bool(have) == want
+        elif isinstance(want, int):
+            ok = int(have) == want
+        else:
+            ok = have == want
+        if not ok:
+            raise ValueError('invr: unsupported configuration %s = %r — %s' % (k, have, why))
+    return c
+
+
 cfg = make_cfg()
 
 
@@ -139,4 +172,4 @@ def adopt(host_cfg):
         pn = merged['partnet'][p]
         if 'color_network' not in pn:
             pn['color_network'] = {'kwargs': dict(d_hidden=64, n_layers=2)}
-    return set_cfg(_node(merged))
+    return set_cfg(validate(_node(merged)))

@@ -187,6 +187,7 @@ static size_t carve(Workspace& w, void* base, int64_t N, int64_t cap) {
     w.counters = c.take<int32_t>(counters_ints(w.n_groups));
     w.gcount = w.counters ? w.counters + CNT_ALLOC : nullptr;
     w.knn.part_aabb = c.take<float>(INVR_NUM_PARTS * 6);
+    w.knn.dfar2 = c.take<float>(1);
     w.knn.mpad = KNN_MAX_PART;
     w.knn.cpad = KNN_MAX_PART / 64;
     w.knn.sverts = c.take<float4>((size_t)INVR_NUM_PARTS * w.knn.mpad);
@@ -237,7 +238,7 @@ extern "C" int invr_workspace_layout(int64_t n_rays, int32_t n_samples, int64_t 
     auto off = [&](const void* p) { return (int64_t)(reinterpret_cast<const char*>(p) - base); };
     o->cap = w.cap; o->lcap = w.lcap;
     o->counters = off(w.counters); o->active_idx = off(w.active_idx); o->word_off = off(w.word_off); o->mask = off(w.mask);
-    o->pflags = off(w.pflags); o->farflags = off(w.farflags);
+    o->pflags = off(w.pflags); o->farflags = off(w.farflags); o->knn_dfar2 = off(w.knn.dfar2);
     for (int p = 0; p < INVR_NUM_PARTS; ++p) {
         o->l_slot[p] = off(w.l_slot[p]); o->l_nn[p] = off(w.l_nn[p]); o->l_w[p] = off(w.l_w[p]);
         o->l_x[p] = off(w.l_x[p]); o->l_d[p] = off(w.l_d[p]); o->l_r[p] = off(w.l_r[p]);

@@ -37,7 +37,17 @@
 #define KNN_EPS 1e-8f
 // 2 * radius**2 with radius = 0.075 (blend_utils.py:741,747), evaluated in double like Python does
 #define KNN_TWO_R2 ((float)(2.0 * 0.075 * 0.075))
-#define KNN_DFAR2 0.4624f        // (0.68 m)^2, see the header comment
+#define KNN_TWO_R2_F 0.01125f
+#define KNN_DFAR2 0.4624f        // (0.68 m)^2, see the header comment: valid while the entries of A / big_A are <= 2 in magnitude
+// The bound above scales with the largest entry M of the frame's A / big_A matrices (|A_bw| <= s M, |x_b| <= s |t_big|): the far
+// distance actually used is derived per frame by k_part_prepare from the matrices themselves — 0.68 m for M <= 2, the distance at
+// which 4 exp(-d^2 / 0.01125) / 1e-8 * M falls to the same 1.1e-9 beyond that, +inf (no folding) for non-finite / absurd
+// matrices — and read by the kernels from ix.dfar2.
+__device__ __forceinline__ float knn_far_dist2(float m_abs) {
+    if (!(m_abs <= 1e6f)) return __builtin_inff();
+    if (m_abs <= 2.0f) return KNN_DFAR2;
+    return fmaxf(KNN_DFAR2, KNN_TWO_R2_F * logf(4.0f * m_abs / 1.12e-17f));
+}
 
 // Sorted 4-best list on 64-bit keys (squared distance bits << 32 | vertex row): non-negative floats
 // order like their bit patterns, so one unsigned compare orders by (distance, row) and the result
@@ -232,6 +242,15 @@ __global__ __launch_bounds__(PREP_T) void k_part_prepare(SceneDev s, KnnIndex ix
     if (threadIdx.x == 0)
 #pragma unroll
         for (int a = 0; a < 3; ++a) { ix.part_aabb[p * 6 + a] = lo[a]; ix.part_aabb[p * 6 + 3 + a] = hi[a]; }
+    if (p == 0 && wv == 0) {          // far-fold distance of this frame from the largest |entry| of A / big_A (header comment)
+        float m = 0.0f;
+        for (int j = lane; j < INVR_NUM_JOINTS * 16; j += 64) {
+            const float x = fabsf(s.A[j]), y = fabsf(s.big_A[j]);
+            m = (x != x || y != y) ? __builtin_inff() : fmaxf(m, fmaxf(x, y));
+        }
+        for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+        if (lane == 0) ix.dfar2[0] = knn_far_dist2(m);
+    }
     KP(0)
     // 2. Morton keys (6 bits / axis) | original index (13 bits)
 #pragma unroll
@@ -404,6 +423,7 @@ __device__ __forceinline__ void scan_sub16(const float4* sv, v2f px, v2f py, v2f
 template <int BLOCK>
 __device__ void knn_pairs_bf(const RenderArgs& a, const Workspace& w, float4* sv) {
     const int na = w.counters[CNT_ACTIVE];
+    const float dfar2 = w.knn.dfar2[0];
     for (int64_t tile = blockIdx.x; tile * BLOCK < na; tile += gridDim.x) {
         const int64_t slot = tile * BLOCK + threadIdx.x;
         const bool live = slot < na;
@@ -434,7 +454,7 @@ __device__ void knn_pairs_bf(const RenderArgs& a, const Workspace& w, float4* sv
             t.finish();
             float wt[KNN_K];
             const float ds = knn_weights(t, wt);
-            const bool far = live && t.d[0] > KNN_DFAR2;
+            const bool far = live && t.d[0] > dfar2;
             const bool hit = live && !far && ds < a.scene.thresh;
             if (far) farflags |= 1u << p;
             const unsigned long long fb = __ballot(far);
@@ -462,7 +482,13 @@ struct KnnLds { int voff[INVR_NUM_PARTS], coff[INVR_NUM_PARTS], soff[INVR_NUM_PA
 // the 16 — 64 consecutive survivors are one depth segment of one ray, and the segments differ widely in how many parts they
 // come near — 29 % of the kernel's wave time on a whole frame and 51 % on a 1/8 shard, tools/knn_phase_prof.py.  Now a wave
 // never waits for another one.)
-__global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w, int dbg) {
+// KNN_DBG: ablation switch of the profiling builds only (tools/knn_phase_prof.sh: -DKNN_DBG=1 no exact scans, 2 seed cluster
+// only — WRONG results); the shipped library is compiled without it.
+#ifndef KNN_DBG
+#define KNN_DBG 0
+#endif
+__global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w) {
+    constexpr int dbg = KNN_DBG;
     // all LDS is dynamic (a static __shared__ in front would misalign the float4 region, guide G17): vertices, then cluster records
     extern __shared__ __attribute__((aligned(16))) float4 lds_raw[];
     float4* lds = lds_raw + KNN_LDS_HDR;
@@ -499,6 +525,7 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w, 
     __syncthreads();
     KP(6)
     const int na = w.counters[CNT_ACTIVE];
+    const float dfar2 = ix.dfar2[0];                        // far-fold distance^2 of this frame (k_part_prepare)
     const int lane = threadIdx.x & 63;
     int far_cnt[INVR_NUM_PARTS] = {0, 0, 0, 0, 0};          // far pairs seen by this wave (statistics), flushed once at the end
     // dynamic scheduling, one ticket per wave and 64 survivors: the cost of 64 points varies ~10x with how many clusters they
@@ -561,7 +588,7 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w, 
             }
             const float* bb = ix.part_aabb + p * 6;
             const float lbp = aabb_dist2(px, py, pz, make_float4(bb[0], bb[1], bb[2], 0.f), make_float4(bb[3], bb[4], bb[5], 0.f));
-            if (__ballot(live && !(lbp > KNN_DFAR2)) == 0) {          // whole wave far from this part
+            if (__ballot(live && !(lbp > dfar2)) == 0) {          // whole wave far from this part
                 if (live) farflags |= 1u << p;
                 continue;
             }
@@ -609,7 +636,7 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w, 
                     lb2 = fminf(lb2, aabb_dist2(px, py, pz, klo, khi));
                 }
             }
-            const bool is_far = maybe ? lb2 > KNN_DFAR2 : (live && c2 == 1);
+            const bool is_far = maybe ? lb2 > dfar2 : (live && c2 == 1);
             const bool unflagged = maybe ? (lb2 >= a.scene.near_hi2 && ub2 <= a.scene.band_lo2) : (c2 == 2);
             const bool scan = live && !is_far && !unflagged;
             if (live && is_far) farflags |= 1u << p;
@@ -792,6 +819,7 @@ __global__ __launch_bounds__(VC_BLOCK) void k_knn_voxel_class(SceneDev s, KnnInd
     // the live cells — a corner below the cull threshold, 7 % of the lattice on the bench frame; all other cells are never looked
     // up — were listed by k_cull_cells
     const int n_live = n_live_dev[0];
+    const float dfar2 = ix.dfar2[0];
     const int per_block = VC_BLOCK / VC_Q;
     if ((int)blockIdx.x * per_block >= n_live) return;
     // cluster {lo, hi, rep} and sub-cluster {lo, hi} records of this block's part, staged once
@@ -836,7 +864,7 @@ __global__ __launch_bounds__(VC_BLOCK) void k_knn_voxel_class(SceneDev s, KnnInd
         ub2 = quad_min(ub2);
         unsigned pc = 0;
         if (len >= KNN_K) {
-            if (lb2 > KNN_DFAR2) pc = 1;
+            if (lb2 > dfar2) pc = 1;
             else if (lb2 >= s.near_hi2 && ub2 <= s.band_lo2) pc = 2;
         }
         if (q == 0) ix.voxcls[(int64_t)idx * INVR_NUM_PARTS + p] = (uint8_t)(pc ? pc : 3u);      // 3 = classified, undecided (0 = never classified)
@@ -980,8 +1008,7 @@ int launch_knn_pairs(const RenderArgs& a, const Workspace& w, int32_t* stats, hi
     }
     int64_t tiles = cdiv(w.cap, 64);              // tickets of 64 survivors, taken by single waves
     unsigned grid = (unsigned)(tiles < 256 * 16 ? (tiles > 0 ? cdiv(tiles, 16) : 1) : 256);
-    static int dbg = getenv("INVR_KNN_DBG") ? atoi(getenv("INVR_KNN_DBG")) : 0;
-    hipLaunchKernelGGL(k_knn_pairs, dim3(grid), dim3(KNN_T), lds_bytes, st, a, w, dbg);
+    hipLaunchKernelGGL(k_knn_pairs, dim3(grid), dim3(KNN_T), lds_bytes, st, a, w);
     INVR_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_pair_lists, dim3((unsigned)w.n_groups), dim3(PL_BLOCK), 0, st, w, stats);
     INVR_LAUNCH_CHECK();

@@ -298,7 +298,7 @@ __global__ __launch_bounds__(MLP_BLOCK, 4) void k_part_occ_all(MlpAllArgs a) {
 // layout of k_pair_lists: the pairs of group g sit at [off_g, off_g + gcount[g][p]) of part p's list, off_g = the counts of the
 // groups before it — which writes its winners, ascending, to wl[p][off_g ...) and their number to wcnt[g][p]: no global offsets,
 // no atomics; k_part_rgb_all walks the segments.  The last group appends the far-constant pair of every part.
-#define WL_BLOCK 256
+#define WL_BLOCK 512         // x WL_PER = PAIR_GROUP: one pass per group (the kernel is a chain of dependent round trips)
 #define WL_PER 8
 __global__ __launch_bounds__(WL_BLOCK) void k_winner_lists(Workspace w) {
     __shared__ int s_cnt[WL_BLOCK / 64][INVR_NUM_PARTS];
@@ -308,7 +308,6 @@ __global__ __launch_bounds__(WL_BLOCK) void k_winner_lists(Workspace w) {
     if (g > g_last) return;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int base[INVR_NUM_PARTS], wbase[INVR_NUM_PARTS], cidx[INVR_NUM_PARTS];
-    float occc[INVR_NUM_PARTS];
     {
         int acc[INVR_NUM_PARTS] = {0, 0, 0, 0, 0};
         for (int64_t q = threadIdx.x; q < g; q += WL_BLOCK)
@@ -326,7 +325,6 @@ __global__ __launch_bounds__(WL_BLOCK) void k_winner_lists(Workspace w) {
             for (int k = 0; k < WL_BLOCK / 64; ++k) base[p] += s_red[k][p];
             wbase[p] = 0;
             cidx[p] = w.counters[CNT_PAIRS + p] - 1;               // list index of the part's far-constant pair
-            occc[p] = w.occp[p][cidx[p]];
         }
     }
     const int pbase0[INVR_NUM_PARTS] = {base[0], base[1], base[2], base[3], base[4]};
@@ -356,9 +354,23 @@ __global__ __launch_bounds__(WL_BLOCK) void k_winner_lists(Workspace w) {
             for (int k = 0; k < WL_BLOCK / 64; ++k) { const int c = s_cnt[k][p]; if (k < wv) pos[p] += c; base[p] += c; }
         }
         __syncthreads();                 // s_cnt is reused below
-        // the merge of the thread's WL_PER survivors
+        // the merge of the thread's WL_PER survivors.  All occupancies are fetched first, unconditionally (an unflagged / far
+        // (survivor, part) reads the part's far constant): loads under per-part conditions would be 40 serial round trips
         unsigned long long wb = 0ull, sel8 = 0ull;
-        int widx[WL_PER];
+        int widx[WL_PER], pidx[WL_PER][INVR_NUM_PARTS];
+        float oc[WL_PER][INVR_NUM_PARTS];
+#pragma unroll
+        for (int k = 0; k < WL_PER; ++k)
+#pragma unroll
+            for (int p = 0; p < INVR_NUM_PARTS; ++p) {
+                const bool listed = (fb >> (8 * k + p)) & 1ull;
+                pidx[k][p] = listed ? pos[p] : cidx[p];
+                pos[p] += listed ? 1 : 0;
+            }
+#pragma unroll
+        for (int k = 0; k < WL_PER; ++k)
+#pragma unroll
+            for (int p = 0; p < INVR_NUM_PARTS; ++p) oc[k][p] = w.occp[p][pidx[k][p]];
 #pragma unroll
         for (int k = 0; k < WL_PER; ++k) {
             const unsigned fl = (unsigned)(fb >> (8 * k)) & 0xffu, ff = (unsigned)(ffb >> (8 * k)) & 0xffu;
@@ -369,10 +381,9 @@ __global__ __launch_bounds__(WL_BLOCK) void k_winner_lists(Workspace w) {
             for (int p = 0; p < INVR_NUM_PARTS; ++p) {
                 float c = 0.0f;
                 unsigned sel = 255u;
-                int idx = 0;
-                if (fl & (1u << p)) { idx = pos[p]++; c = w.occp[p][idx]; sel = (unsigned)p; }
-                else if (ff & (1u << p)) { c = occc[p]; sel = 8u + (unsigned)p; }
-                if (p == 0 || c > best) { best = c; bsel = sel; bidx = idx; }
+                if (fl & (1u << p)) { c = oc[k][p]; sel = (unsigned)p; }
+                else if (ff & (1u << p)) { c = oc[k][p]; sel = 8u + (unsigned)p; }
+                if (p == 0 || c > best) { best = c; bsel = sel; bidx = pidx[k][p]; }
             }
             widx[k] = bidx;
             sel8 |= (unsigned long long)bsel << (8 * k);

@@ -35,6 +35,8 @@ struct KnnIndex {
     float4* cl;          // P*cpad*3 : per 64-vertex cluster {AABB min, AABB max, first vertex (an upper
                          //            bound of the nearest distance)}
     float* part_aabb;    // P*6
+    float* dfar2;        // 1 : squared distance beyond which a (point, part) pair is folded into the part's far constant, derived per
+                         //     frame from the magnitude of A / big_A (k_part_prepare)
     unsigned long long* voxmask;  // per lattice cell and part: bit c set if cluster c can hold one of the 4 nearest vertices of a
                          //            point of the cell (undecided cells of parts with <= 64 clusters; all ones otherwise); NULL = off
     float* voxu2;        // per (lattice cell, part): squared upper bound of the 4th-nearest distance of any point of the cell

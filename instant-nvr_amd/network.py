@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from . import _abi, params
-from .config import cfg as global_cfg, PART_NAMES, NUM_PARTS
+from .config import cfg as global_cfg, PART_NAMES, NUM_PARTS, validate as validate_cfg
 
 
 class Embedder(nn.Module):
@@ -209,6 +209,7 @@ class Network(nn.Module):
     def __init__(self, init_network=True, cfg=None):
         super().__init__()
         self.cfg = cfg or global_cfg
+        validate_cfg(self.cfg)                  # raises on reference switches this build does not implement
         self.tpose_deformer = Deformer(self.cfg)
         self.tpose_human = TPoseHuman(self.cfg)
         self._ws = None

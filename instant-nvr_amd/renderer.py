@@ -8,11 +8,10 @@ forward and ``volume_rendering`` are one stream-ordered libinvr call over the wh
 Train mode (``net.training`` and grad enabled) goes through autograd.TrainRenderFn — one fused HIP forward and one fused
 HIP backward — and returns the reference's training dict (rgb_map, acc_map, weights / z_vals, resd, tpts, tocc, oresd,
 distortion) with the large per-pair tensors materialised lazily (LazyTrainRet) plus two scalars the trainer prefers when
-present: ``offset_loss`` and ``pair_loss`` (the reference's means over resd / oresd, reduced on the device).  One deviation:
-``tpts`` of UNFLAGGED (point, part) pairs is 0 here; the reference returns ``init_bigpose`` — the warp under that part's
-KNN blend weights — for every one of the Na x 5 pairs, flagged or not (inb_part_network_multiassign.py:96-120).  Producing it
-would need the exact 4-NN of every survivor in every part, which is what the pair pruning avoids; the only reader is the pair
-regulariser, which selects rows by ``tocc`` (0 for unflagged pairs) and therefore never sees them.
+present: ``offset_loss`` and ``pair_loss`` (the reference's means over resd / oresd, reduced on the device).  ``tpts`` is the
+reference's ``init_bigpose`` for every one of the Na x 5 (survivor, part) rows, flagged or not
+(inb_part_network_multiassign.py:96-120,162-166): rows the pair pruning never listed are filled through the dense stage entry
+points when the tensor is materialised (``dense_train_rows``).
 """
 import ctypes as C
 
@@ -22,6 +21,46 @@ from . import _abi
 from .config import cfg as global_cfg, NUM_PARTS
 
 MAX_SAMPLES_PER_CALL = (1 << 31) - 1
+
+
+def dense_train_rows(v, stats, ctx, rays, S, jitter):
+    """The reference's dense train-mode tensors resd / tpts / tocc, (Na, P, .) in its row order
+    (inb_part_network_multiassign.py:96-120,162-166), from what a forward left in the workspace views `v`:
+      * listed pairs: the pair lists (l_r = resd, l_x - l_r = init_bigpose, occp = tocc),
+      * far pairs: the part's far constant (last list entry; the reference's value differs from it by < 1.1e-9 m, k_knn.hip),
+      * every other (survivor, part): resd = 0 and tocc = 0 as in the reference (deformer / part network skip unflagged rows),
+        tpts = init_bigpose under that part's 4-NN weights — the reference warps all Na x P rows — through the dense stage
+        entry points invr_pose_points -> invr_knn_blend -> invr_warp_deform (Na is a training patch's ~4e4 survivors).
+    `stats` is the host copy of the statistics block, `rays` = (ray_o, ray_d, near, far) of the forward, `jitter` its z jitter."""
+    from . import stages
+    Na, cap, P = int(stats[0]), v['cap'], NUM_PARTS
+    dev = v['pflags'].device
+    resd = torch.zeros(Na + 1, P, 3, device=dev)
+    tpts = torch.zeros(Na + 1, P, 3, device=dev)
+    tocc = torch.zeros(Na + 1, P, device=dev)
+    far = v['farflags'][:Na].to(torch.int32)
+    for p in range(P):
+        cnt = int(stats[1 + p])
+        slots = v['l_slot'][p][:cnt].long()
+        rows = torch.where(slots == cap, torch.full_like(slots, Na), slots)       # const pair -> extra row
+        r = v['l_r'][p][:, :cnt].t()
+        resd[rows, p] = r
+        tpts[rows, p] = v['l_x'][p][:, :cnt].t() - r                                 # init_bigpose
+        tocc[rows, p] = v['occp'][p][:cnt]
+        fr = ((far >> p) & 1).nonzero(as_tuple=True)[0]                              # far pairs take the constant
+        if fr.numel():
+            resd[fr, p] = resd[Na, p]
+            tpts[fr, p] = tpts[Na, p]
+            tocc[fr, p] = tocc[Na, p]
+    resd, tpts, tocc = resd[:Na], tpts[:Na], tocc[:Na]
+    if Na:
+        ro, rd, nr, fa = rays
+        pts, dirs = stages.pose_points(ctx.scene, ro, rd, nr, fa, S, v['active_idx'][:Na], jitter=jitter)
+        bw, _ = stages.knn_blend(ctx.scene, pts)
+        tp, _, _ = stages.warp_deform(ctx.scene, ctx.model, pts, dirs, bw, torch.zeros(Na, P, dtype=torch.uint8, device=dev))
+        known = (((v['pflags'][:Na].to(torch.int32) | far)[:, None] >> torch.arange(P, device=dev)[None]) & 1).bool()
+        tpts = torch.where(known[..., None], tpts, tp)
+    return resd, tpts, tocc
 
 
 class Renderer:
@@ -128,36 +167,17 @@ class Renderer:
 
         def materialise():
             with torch.no_grad():
-                return self._train_extras(net, ctx, ws, stats, n, S, max_active, noise)
+                return self._train_extras(net, ctx, ws, stats, n, S, max_active, noise, (ray_o, ray_d, near, far), jitter)
         return ag.LazyTrainRet(base, lazy, materialise)
 
-    def _train_extras(self, net, ctx, ws, stats_dev, n, S, max_active, noise_dense):
+    def _train_extras(self, net, ctx, ws, stats_dev, n, S, max_active, noise_dense, rays, jitter):
         """resd / tpts / tocc (dense (Na*P, .) layouts in the reference's row order) and oresd from the pair lists of the
         last forward (host read-back of the counts: synchronises)."""
         cfg = self.cfg
         stats = stats_dev.cpu()
-        Na = int(stats[0])
         v = _abi.ws_views(ws, n, S, max_active)
-        cap, dev, P = v['cap'], ws.device, NUM_PARTS
-        resd = torch.zeros(Na + 1, P, 3, device=dev)
-        tpts = torch.zeros(Na + 1, P, 3, device=dev)
-        tocc = torch.zeros(Na + 1, P, device=dev)
-        occp = v['occp']
-        far = v['farflags'][:Na].to(torch.int32)
-        for p in range(P):
-            cnt = int(stats[1 + p])
-            slots = v['l_slot'][p][:cnt].long()
-            rows = torch.where(slots == cap, torch.full_like(slots, Na), slots)
-            r = v['l_r'][p][:, :cnt].t()
-            resd[rows, p] = r
-            tpts[rows, p] = v['l_x'][p][:, :cnt].t() - r
-            tocc[rows, p] = occp[p][:cnt]
-            fr = ((far >> p) & 1).nonzero(as_tuple=True)[0]
-            if fr.numel():
-                resd[fr, p] = resd[Na, p]
-                tpts[fr, p] = tpts[Na, p]
-                tocc[fr, p] = tocc[Na, p]
-        resd, tpts, tocc = resd[:Na], tpts[:Na], tocc[:Na]
+        dev = ws.device
+        resd, tpts, tocc = dense_train_rows(v, stats, ctx, rays, S, jitter)
         out = {'resd': resd.reshape(1, -1, 3), 'tpts': tpts.reshape(1, -1, 3), 'tocc': tocc.reshape(1, -1, 1)}
         if cfg.use_pair_reg and noise_dense is not None:
             reg = ((tocc.reshape(-1) - 0.5).abs() < 0.02).nonzero(as_tuple=True)[0]
@@ -198,26 +218,8 @@ class Renderer:
             # differentiable recomputation on the pair lists (autograd.py): HIP encoder / compositing
             # forward+backward kernels, torch for the tiny MLPs
             from . import autograd as ag
-            return ag.render_train(net, batch, out, v, stats, n, S, self._pair_noise)
-        resd = torch.zeros(Na + 1, P, 3, device=dev)
-        tpts = torch.zeros(Na + 1, P, 3, device=dev)
-        tocc = torch.zeros(Na + 1, P, device=dev)
-        occp = v['occp']
-        far = v['farflags'][:Na].to(torch.int32)
-        for p in range(P):
-            cnt = int(stats[1 + p])
-            slots = v['l_slot'][p][:cnt].long()
-            rows = torch.where(slots == cap, torch.full_like(slots, Na), slots)       # const pair -> extra row
-            r = v['l_r'][p][:, :cnt].t()
-            resd[rows, p] = r
-            tpts[rows, p] = v['l_x'][p][:, :cnt].t() - r                                 # init_bigpose
-            tocc[rows, p] = occp[p][:cnt]
-            fr = ((far >> p) & 1).nonzero(as_tuple=True)[0]                              # far pairs take the constant
-            if fr.numel():
-                resd[fr, p] = resd[Na, p]
-                tpts[fr, p] = tpts[Na, p]
-                tocc[fr, p] = tocc[Na, p]
-        resd, tpts, tocc = resd[:Na], tpts[:Na], tocc[:Na]
+            return ag.render_train(net, batch, out, v, stats, n, S, self._pair_noise, ctx=ctx, rays=(ray_o, ray_d, near, far), jitter=jitter)
+        resd, tpts, tocc = dense_train_rows(v, stats, ctx, (ray_o, ray_d, near, far), S, jitter)
         ret = {'rgb_map': out['rgb_map'][None], 'acc_map': out['acc_map'][None], 'raw': out['raw'][None],
                'occ': out['occ'][None, :, None], 'resd': resd.reshape(1, -1, 3), 'tpts': tpts.reshape(1, -1, 3),
                'tocc': tocc.reshape(1, -1, 1)}

@@ -221,7 +221,7 @@ def main():
         torch.rand, torch.rand_like = _rand, _rand_like
     out['train_jitter'] = tnp(jit)
     out['train_pair_u'] = tnp(pair['u']) if 'u' in pair else np.zeros((1, 0, 3), np.float32)
-    for k in ['rgb_map', 'acc_map', 'resd', 'tocc', 'oresd', 'reg_distortion_loss']:
+    for k in ['rgb_map', 'acc_map', 'resd', 'tpts', 'tocc', 'oresd', 'reg_distortion_loss']:
         out['train_' + k] = tnp(tret[k])
     loss = ((tret['rgb_map'] - tb_['rgb']) ** 2).mean() + 0.1 * tret['reg_distortion_loss'].mean() \
         + 0.1 * torch.norm(tret['resd'], dim=2).mean()

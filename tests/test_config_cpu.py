@@ -1,0 +1,42 @@
+"""Reference switches this build does not implement must RAISE, not silently render the default behaviour
+(VERDICT r2 'what's missing' #3): cfg.aggr in {mean, dist, mindist} (inb_part_network_multiassign.py:237-251), knn_k != 4,
+random_bg, part_deform, tpose_viewdir False, use_knn False — in make/adopt and in Network.__init__."""
+import pytest
+
+from invr import config
+from invr.network import Network
+
+
+BAD = [('aggr', 'mean'), ('aggr', 'dist'), ('aggr', 'mindist'), ('knn_k', 3), ('knn_k', 8), ('random_bg', True),
+       ('part_deform', True), ('tpose_viewdir', False), ('use_knn', False)]
+
+
+@pytest.mark.parametrize('key,val', BAD)
+def test_network_rejects_unsupported_switch(key, val):
+    cfg = config.make_cfg(table_log2=8, **{key: val})
+    with pytest.raises(ValueError, match=key):
+        Network(cfg=cfg)
+
+
+@pytest.mark.parametrize('key,val', BAD)
+def test_adopt_rejects_unsupported_switch(key, val):
+    saved = dict(config.cfg)
+    host = dict(config.DEFAULTS)
+    host[key] = val
+    try:
+        with pytest.raises(ValueError, match=key):
+            config.adopt(host)
+    finally:
+        config.set_cfg(config._node(saved))
+
+
+def test_defaults_and_ignored_keys_pass():
+    saved = dict(config.cfg)
+    host = dict(config.DEFAULTS)
+    host['N_importance'] = 128          # set by inb_377.yaml, read by nothing in the reference's lib/: ignored as there
+    try:
+        c = config.adopt(host)
+        assert c.aggr == '' and c.knn_k == 4
+        Network(cfg=config.make_cfg(table_log2=8))
+    finally:
+        config.set_cfg(config._node(saved))

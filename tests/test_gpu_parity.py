@@ -307,6 +307,8 @@ def test_train_mode_forward_vs_reference_golden(gpu_setup, golden):
     assert maxerr(ret['acc_map'], golden['train_acc_map']) < 1e-4
     assert ret['resd'].shape == golden['train_resd'].shape and ret['tocc'].shape == golden['train_tocc'].shape
     assert maxerr(ret['resd'], golden['train_resd']) < 5e-6
+    # tpts = init_bigpose of ALL Na x P rows (inb_part_network_multiassign.py:96-120,162-166), unflagged pairs included
+    assert ret['tpts'].shape == golden['train_tpts'].shape and maxerr(ret['tpts'], golden['train_tpts']) < 1e-5
     assert maxerr(ret['tocc'], golden['train_tocc']) < 1e-3        # far pairs are extrapolated (see test_part_fields)
     assert ret['oresd'].shape == golden['train_oresd'].shape
     assert maxerr(ret['oresd'], golden['train_oresd']) < 5e-6
@@ -863,3 +865,47 @@ def test_render_other_scenes_vs_oracle(scene_kw):
     err_ref = (ref['rgb_map'][0].double() - exact).abs().max(1)[0]
     assert bool((err_gpu <= 1e-4 + 4 * err_ref).all()), (float(err_gpu.max()), float(err_ref.max()))
     assert float(err_gpu.median()) < 5e-6
+
+
+@pytest.mark.parametrize('scale', [1.0, 40.0, float('nan')], ids=['as-is', 'x40', 'nan'])
+def test_far_fold_distance_follows_the_frame_matrices(gpu_setup, scale):
+    """Far-constant folding (k_knn.hip header) rests on |A_bw| <= s * max|A| being below fp32 resolution; the distance beyond
+    which a (survivor, part) pair is folded is derived per frame from the largest |entry| of A / big_A (k_part_prepare ->
+    ix.dfar2): (0.68 m)^2 while that is <= 2, larger beyond, +inf (no folding) for non-finite matrices.  What the fold claims is
+    then checked directly: the dense warp (invr_knn_blend + invr_warp_deform, the reference's arithmetic for every pair) puts
+    every folded pair's canonical point within 1.5e-8 m of the origin with a view direction below 1e-15."""
+    from invr import stages
+    cfg, sd, batch, gb, net = gpu_setup
+    b = dict(gb)
+    b['A'] = gb['A'] * scale
+    b['big_A'] = gb['big_A'] * scale
+    ctx = net.prepare(b)
+    ro, rd, nr, fa = (b[k][0] for k in ('ray_o', 'ray_d', 'near', 'far'))
+    S = int(cfg.N_samples)
+    net._ws = None
+    out = net.render_rays(ctx, ro, rd, nr, fa, S, want_raw=False)
+    torch.cuda.synchronize()
+    net._ws = None
+    v = _abi.ws_views(*out['_ws'])
+    st = out['stats'].cpu().numpy()
+    dfar2 = float(v['knn_dfar2'][0])
+    if scale != scale:
+        assert dfar2 == float('inf') and int(st[7:12].sum()) == 0 and int(v['farflags'][:int(st[0])].max()) == 0
+        return
+    M = max(float(b['A'].abs().max()), float(b['big_A'].abs().max()))
+    if M <= 2.0:
+        assert dfar2 == float(np.float32(0.4624)), (M, dfar2)
+    else:
+        assert dfar2 > 0.4624 and abs(dfar2 - 0.01125 * np.log(4.0 * M / 1.12e-17)) < 1e-4, (M, dfar2)
+    Na = int(st[0])
+    assert st[6] == 0 and Na > 1000 and int(st[7:12].sum()) > 100
+    act = v['active_idx'][:Na]
+    pts, dirs = stages.pose_points(ctx.scene, ro, rd, nr, fa, S, act)
+    far = ((v['farflags'][:Na, None].to(torch.int32) >> torch.arange(5, device=DEV)[None]) & 1).bool()
+    nn, d2, w, dist = stages.knn_neighbors(ctx.scene, pts)
+    assert bool((d2[..., 0][far] > dfar2 * 0.9999).all())                      # folded = nearest vertex beyond the far distance
+    bw, _ = stages.knn_blend(ctx.scene, pts)
+    tp, td, rs = stages.warp_deform(ctx.scene, ctx.model, pts, dirs, bw, far)
+    x0 = (tp - rs)[far]                                                          # init_bigpose of the folded pairs
+    assert float(x0.abs().max()) <= 1.5e-8, float(x0.abs().max())
+    assert float(td[far].abs().max()) <= 1e-15, float(td[far].abs().max())
