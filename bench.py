@@ -135,6 +135,125 @@ def train_probe(net, dev, S, iters):
             'parameters_updated': int(sum(p.numel() for p in net.parameters() if p.requires_grad)), 'final_loss': float(loss)}
 
 
+OCC_FLOPS = 2 * (19 * 64 + 64 * 17)                    # occupancy MLP 19 -> 64 -> 17 per evaluated pair
+RGB_FLOPS = {3: 2 * (70 * 64 + 64 * 64 + 64 * 3),      # colour MLP 70 -> 64 -> 64 -> 3 (body, head) per WINNING pair
+             2: 2 * (70 * 64 + 64 * 3)}                # 70 -> 64 -> 3 (leg, arms)           (sum = SURVEY 8d's 22.1 k / 14.0 k)
+
+
+def winner_counts(out, stats):
+    """Listed pairs that won their survivor's max-occupancy merge, per part (= the pairs the colour MLP evaluated, without the
+    one far-constant pair per part), from the segment counts k_winner_lists left in the workspace."""
+    v = _abi.ws_views(*out['_ws'])
+    g_last = (max(int(stats[0]), 1) - 1) // 4096
+    return [int(x) - 1 for x in v['wcnt'][:g_last + 1].sum(0).cpu().tolist()]
+
+
+def graph_of(render):
+    """Capture one frame (the kernels of invr_render_fwd, enqueued on torch's capture stream) as a hipGraph -> (replay, outputs)."""
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        render()
+    torch.cuda.current_stream().wait_stream(side)
+    with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+        res = render()
+    return graph, res
+
+
+def time_frames(fn, frames, min_time=0.0, max_regions=200):
+    """ms per call of fn(): regions of exactly `frames` calls between two synchronisations, repeated until min_time seconds."""
+    fn()
+    torch.cuda.synchronize()
+    tot, n = 0.0, 0
+    while True:
+        t0 = time.perf_counter()
+        for _ in range(frames):
+            fn()
+        torch.cuda.synchronize()
+        tot += time.perf_counter() - t0
+        n += frames
+        if tot >= min_time or n >= frames * max_regions:
+            return tot / n * 1e3
+
+
+def variant_lines(net, cfg, batch, dev, S, n_rays):
+    """Driver-visible variants of the headline frame (SURVEY 8d asks for them): the yaml-default 64 samples/ray,
+    the dense stress frame (smpl_thresh = +inf: every ray-sample survives), the trainable 64-byte rows instead of the row-sum
+    tables, the 8-way strong-scaling projection from rank 0's shard of a W-way split on this one GPU, and the wall clock of the
+    drop-in call Renderer.render(batch) itself."""
+    import copy
+    from invr.renderer import Renderer
+    ro, rd, nr, fr = (batch[k][0].contiguous() for k in ('ray_o', 'ray_d', 'near', 'far'))
+    out = {}
+
+    def frame_ms(ctx, s, frames, idx=None, graph=True, min_time=0.25):
+        a = (ro, rd, nr, fr) if idx is None else tuple(t[idx].contiguous() for t in (ro, rd, nr, fr))
+        render = lambda: net.render_rays(ctx, a[0], a[1], a[2], a[3], s, want_raw=True)
+        if graph:
+            try:
+                g, _ = graph_of(render)
+                return time_frames(g.replay, frames, min_time)
+            except Exception as e:
+                sys.stderr.write('variant: hipGraph capture failed (%s), eager launches\n' % e)
+        return time_frames(render, frames, min_time)
+
+    ctx = net.prepare(batch)
+    # (1) strong-scaling projection: rank 0's tile-cyclic shard of a W-way split, one GPU, hipGraph replay as in the headline
+    shard = {}
+    for W in (1, 2, 4, 8):
+        shard[str(W)] = frame_ms(ctx, S, 20, idx=idist.tile_indices(n_rays, 0, W, device=dev))
+    out['shard_projection'] = {
+        'ms_per_frame_of_rank0_shard': shard, 'projected_speedup': {w: shard['1'] / shard[w] for w in shard},
+        'note': 'rank 0 of a W-way tile-cyclic split rendered on ONE GPU (full per-frame scene work included, the 4 MB all-gather is '
+                'not): the single-GPU evidence for strong scaling; the measured multi-GPU curve is the driver\'s SCALE record'}
+    # (2) 64 samples per ray (configs/inb/inb_377.yaml default)
+    ms = frame_ms(ctx, 64, 20)
+    out['samples_64'] = {'ms_per_frame': ms, 'ray_samples_per_sec': n_rays * 64 / (ms * 1e-3), 'samples_per_ray': 64}
+    # (3) the 64-byte trainable rows (what a training-mode forward reads) instead of the derived row-sum tables
+    old = cfg.get('eval_row_sums', True)
+    cfg['eval_row_sums'] = False
+    try:
+        ms = frame_ms(net.prepare(batch), S, 10)
+    finally:
+        cfg['eval_row_sums'] = old
+    out['full_rows'] = {'ms_per_frame': ms, 'ray_samples_per_sec': n_rays * S / (ms * 1e-3),
+                        'table_bytes_per_pair': PAIR_TABLE_BYTES, 'note': 'k_part_encode: 16 levels x 8 corners x 64-byte rows per pair'}
+    # (4) dense stress: every ray-sample survives the cull (113 M evaluated pairs, 28 GB workspace), 3 frames
+    dcfg = copy.deepcopy(cfg)
+    dcfg['smpl_thresh'] = 1e9
+    net.cfg = dcfg
+    try:
+        dctx = net.prepare(batch)
+        ms = frame_ms(dctx, S, 3, graph=False, min_time=0.0)
+        st = net.render_rays(dctx, ro, rd, nr, fr, S, want_raw=True)['stats'].cpu().numpy().astype('int64')
+    finally:
+        net.cfg = cfg
+        net._ws = None                                       # give the 28 GB back
+    out['dense_stress'] = {'ms_per_frame': ms, 'ray_samples_per_sec': n_rays * S / (ms * 1e-3), 'frames': 3,
+                           'active_samples': int(st[0]), 'evaluated_pairs': int(st[1:6].sum())}
+    # (5) the drop-in call: Renderer.render(batch) as run.py / the evaluator call it (wall clock, host side included)
+    api = {}
+    for to_cpu in (False, True):
+        r = Renderer(net)
+        r.eval_to_cpu = to_cpu
+        b = dict(batch)
+        r.render(b)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            ret = r.render(b)
+        torch.cuda.synchronize()
+        api['eval_to_cpu_%s_ms' % str(to_cpu).lower()] = (time.perf_counter() - t0) / 3 * 1e3
+    api['outputs'] = sorted(ret.keys())
+    api['note'] = ('Renderer.render(batch): eager launches + statistics read-back; eval_to_cpu=True is the reference contract '
+                   '(inb_renderer.py:199-200 moves every output to the host: raw + occ = %.0f MB through pageable memory)'
+                   % (n_rays * S * 20 / 1e6))
+    out['api_frame'] = api
+    torch.cuda.empty_cache()
+    return out
+
+
 def main_train(args):
     """--train: the training iteration of the path as the bench step (BASELINE configs[4]: 1024 rays x 128 samples per rank,
     inb_377 defaults, forward + backward fused HIP + dense Adam over all 286 M parameters; --train-config lan = configs[3]:
@@ -234,15 +353,11 @@ def main_train(args):
         ms = dt / args.steps * 1e3
         total_rs = rays * S * world
         # bytes the timed Adam launch moved: p, m, v read+write (24 B) + gradient (dense 4 B, row-scalar tables 0.25 B) for every
-        # tensor that was updated (a part without a flagged pair in the batch is skipped, as torch skips tensors without gradient)
-        act = opt.arena.part_active.cpu().numpy()
+        # trainable tensor (all of them take every step, as in the reference: zero gradients, not None, for an absent part)
         table_ids = {id(t) for t in opt.arena.tables}
         adam_bytes = 0
         for p_ in net.parameters():
             if not p_.requires_grad:
-                continue
-            flag = opt.arena.active_flag_of(p_)
-            if flag is not None and float(flag) == 0.0:
                 continue
             adam_bytes += p_.numel() * 24 + (p_.numel() // 4 if id(p_) in table_ids else p_.numel() * 4)
         line = {
@@ -254,7 +369,7 @@ def main_train(args):
                              'configs[4]: inb_377 training, %d rays x %d samples per rank per iteration' % (round(rays), S)) +
                             ', full-size model, forward + backward fused HIP + dense Adam',
                 'rays_per_rank': float(rays), 'samples_per_ray': S, 'ray_samples_per_step': int(total_rs), 'parameters_updated': int(n_params),
-                'active_samples_rank0': int(stats[0]), 'pairs_per_part_rank0': [int(v) for v in stats[1:6]], 'parts_updated_last_step': [bool(a) for a in act],
+                'active_samples_rank0': int(stats[0]), 'pairs_per_part_rank0': [int(v) for v in stats[1:6]],
                 'optimizer': type(opt).__name__, 'iterations_timed': args.steps * len(region),
                 'parallelism': 'dp%d: full replicas, row-scalar table gradients (%.0f MB) + %.1f MB small tensors averaged per iteration, '
                                'all-reduce overlapped with the backward' % (world, 4e-6 * sum(e.row_grad().numel() for e in opt.arena.embedders),
@@ -295,6 +410,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--train-iters', type=int, default=10, help='iterations of the informational training-step probe (0 = skip; N=1 only)')
     ap.add_argument('--no-graph', action='store_true', help='launch the ~25 kernels of a frame eagerly instead of replaying one captured hipGraph')
+    ap.add_argument('--no-variants', action='store_true', help='skip the S=64 / dense / full-row / shard-projection / API-frame variants of the default line')
     ap.add_argument('--shard-of', type=int, default=0, help='debug (1 GPU): render only rank 0\'s ray shard of a W-way split')
     args = ap.parse_args()
     if args.train:
@@ -431,25 +547,37 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         value = total_samples * args.steps / dt          # dt = mean duration of one K-step region
         pairs_local = int(stats[1:6].sum())
+        winners = winner_counts(out, stats)              # rank 0's shard
+        n_rgb = [len(pn.rgb.linears) for pn in net.tpose_human.part_networks]
         per = max(n_prof, 1)
         enc_ms = sum(stage_ms['encode_%d' % p] for p in range(5)) / per
         mlp_ms = sum(stage_ms['mlp_%d' % p] for p in range(5)) / per
         knn_ms = stage_ms['knn'] / per
         enc_bytes = pairs_local * (PAIR_TABLE_BYTES if args.full_rows else PAIR_TABLE_BYTES // 16)   # 16 levels x 8 corners x 64 B | 4 B
-        mlp_flops = sum(int(stats[1 + p]) * (22144 if p in (0, 2) else 13952) for p in range(5))          # 2 x MACs, SURVEY 8(d)
+        # part MLPs: occupancy MLP for every listed pair + colour MLP for the winning pair of every survivor (+ the far constants)
+        mlp_flops = OCC_FLOPS * pairs_local + sum(RGB_FLOPS[n_rgb[p]] * (winners[p] + 1) for p in range(5))
+        mlp_flops_ref = sum(int(stats[1 + p]) * (OCC_FLOPS + RGB_FLOPS[n_rgb[p]]) for p in range(5))      # what evaluating every pair costs
         knn_flops = int(stats[0]) * 62000                                                                # brute-force 4-NN of the reference, SURVEY 8(d)
-        # HBM bytes per launch from the PMC passes (profiles/, FETCH_SIZE+WRITE_SIZE with the guide's gfx950 correction)
-        traffic = {}
-        tf = os.path.join(ROOT, 'profiles', 'hbm_traffic_per_launch.json')
-        if os.path.exists(tf) and world == 1 and not args.dense and args.table_log2 is None and args.res == 512 and S == 128 \
-                and not args.full_rows and not args.shard_of:
+        # per-kernel counters of the same command from the PMC passes (tools/prof_all.sh -> tools/prof_summary.py -> profiles/):
+        # HBM / Infinity-Cache bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, the guide's gfx950 correction), busy and wait fractions
+        traffic, counters = {}, {}
+        headline = world == 1 and not args.dense and args.table_log2 is None and args.res == 512 and S == 128 and not args.full_rows \
+            and not args.shard_of
+        tf, cf = os.path.join(ROOT, 'profiles', 'hbm_traffic_per_launch.json'), os.path.join(ROOT, 'profiles', 'kernel_counters.json')
+        if headline and os.path.exists(tf):
             traffic = json.load(open(tf))
-        traffic_src = ('profiles/hbm_traffic_per_launch.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE passes of this command, '
-                       'tools/prof_all.sh; not measured in this run)') if traffic else None
-        # path-level roofline of SURVEY 8(d) / BASELINE.md §4: algorithmic bytes of one frame over its wall time
+        if headline and os.path.exists(cf):
+            counters = json.load(open(cf))
+        src = ('profiles/ (rocprofv3 --pmc passes of this command, tools/prof_all.sh; counters cannot be collected inside the timed run)'
+               if traffic else None)
+        mlp_kernels = ('k_part_occ_all', 'k_winner_lists', 'k_part_rgb_all')
+        mlp_traffic = sum(traffic.get(k, 0) for k in mlp_kernels) if all(k in traffic for k in mlp_kernels) else None
+        # the byte model of SURVEY 8(d) / BASELINE.md §4 for the whole frame (a MODEL, not a bound: see path_roofline.note)
         tab_b = PAIR_TABLE_BYTES if args.full_rows else PAIR_TABLE_BYTES // 16
         path_bytes = (tab_b + 512 + 64) * pairs_local + 1920 * int(stats[0]) + (32 + (20 if want_raw else 0)) * int(ro.shape[0]) * S + 48 * int(ro.shape[0])
+        path_traffic = (sum(v for k, v in traffic.items() if k != 'k_row_sums') if traffic else None)      # (row sums: once per weight version)
         tfl = lambda fl, ms: fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        binding = lambda k: counters.get(k)
         line = {
             'metric': 'ray-samples/sec', 'value': value, 'unit': 'ray-samples/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step, 'repeats': repeats, 'timed_region_s': sum(region), 'higher_is_better': True,
@@ -459,50 +587,71 @@ def main():
                             '%dx%d, %d samples/ray%s' % (args.res, args.res, S, ', DENSE stress (smpl_thresh=inf)' if args.dense else ''),
                 'rays': int(n_rays), 'samples_per_ray': S, 'ray_samples_per_step': int(total_samples),
                 'active_samples': int(stats_all[0]), 'active_fraction': float(stats_all[0]) / total_samples,
+                'survivors_per_sec': float(stats_all[0]) * args.steps / dt,
                 'pairs_per_part': [int(v) for v in stats_all[1:6]],
                 'pairs_per_active_sample': float(stats_all[1:6].sum()) / max(int(stats_all[0]), 1),
+                'colour_mlp_pairs_per_part_rank0': winners,
                 'parameters': int(n_params), 'raw_occ_materialised': want_raw, 'hip_graph': use_graph,
                 'parallelism': 'tile-cyclic ray shards x%d, full replicas, 1 all-gather/frame' % world,
                 'rays_per_sec': n_rays * args.steps / dt,
+                'note': 'value counts every ray-sample of the frame; %.1f %% of them survive the near-surface cull (the camera sits at %.1f m so '
+                        'that the body fills the frame) — survivors_per_sec is the rate of the samples that reach the networks'
+                        % (100.0 * float(stats_all[0]) / total_samples, args.cam_dist),
             },
-            # dominant roofline-bound kernel: the two tiny MLPs of all five parts on the fp32 matrix cores (one launch)
+            # dominant roofline-bound stage: the tiny MLPs of all five parts on the fp32 matrix cores
             'roofline': {
-                'kernel': 'k_part_mlp_all (1 launch/step: occ + rgb MLPs of the 5 parts, v_mfma_f32_16x16x4_f32)', 'bound': 'mfma',
+                'kernel': 'part MLPs = k_part_occ_all (19-64-17 for every listed pair) + k_winner_lists + k_part_rgb_all (70-64(-64)-3 for the '
+                          'pair that wins each survivor\'s max-occupancy merge), v_mfma_f32_16x16x4_f32', 'bound': 'mfma',
                 'achieved': tfl(mlp_flops, mlp_ms), 'peak': 157.3, 'unit': 'TFLOP/s', 'frac': tfl(mlp_flops, mlp_ms) / 157.3,
-                'traffic': traffic.get('k_part_mlp_all'), 'traffic_source': traffic_src,
+                'traffic': mlp_traffic, 'traffic_source': src,
                 'algorithmic_flops_per_launch': int(mlp_flops), 'kernel_ms_per_launch': mlp_ms,
-                'note': 'algorithmic = 22.1 kFLOP (body, head) / 14.0 kFLOP (leg, arms) per evaluated (point,part) pair on rank 0 '
-                        '(SURVEY 8d); fp32-in MFMA peak = fp32 vector peak on gfx950; HIP events on the launch stream',
+                'flops_if_every_pair_ran_both_mlps': int(mlp_flops_ref),
+                'counters': {k: binding(k) for k in mlp_kernels} if counters else None,
+                'note': 'algorithmic = 4.6 kFLOP x listed pairs + 17.5 k (body, head) / 9.3 kFLOP (leg, arms) x winning pairs on rank 0 '
+                        '(SURVEY 8d\'s 22.1 k / 14.0 k split into its two MLPs; the reference evaluates both for every pair and discards the '
+                        'colour of all but the arg-max part, inb_part_network_multiassign.py:253-256); fp32-in MFMA peak = fp32 vector peak on '
+                        'gfx950; time = HIP events on the launch stream around the three launches of the stage',
             },
             'roofline_other': [
-                {'kernel': 'k_knn_pairs (largest single kernel; exact per-part 4-NN, VALU + LDS, no HBM/MFMA roofline)',
-                 'bound': 'valu-fp32', 'achieved': tfl(knn_flops, knn_ms), 'peak': 157.3, 'unit': 'TFLOP/s',
-                 'frac': None, 'traffic': traffic.get('k_knn_pairs'), 'kernel_ms_per_launch': knn_ms,
+                {'kernel': 'k_knn_pairs (largest single kernel; exact per-part 4-NN)', 'bound': 'valu-issue (no HBM / MFMA roofline applies)',
+                 'achieved': tfl(knn_flops, knn_ms), 'peak': 157.3, 'unit': 'TFLOP/s (brute-force-equivalent)',
+                 'frac': None, 'traffic': traffic.get('k_knn_pairs'), 'kernel_ms_per_launch': knn_ms, 'counters': binding('k_knn_pairs'),
                  'note': 'achieved = brute-force-EQUIVALENT rate: the search the reference runs costs 6890 vertices x ~9 FLOP = 62 kFLOP per '
                          'survivor (SURVEY 8d); the cluster-pruned exact search executes roughly a tenth of it, so the figure can exceed the '
-                         'vector peak and no fraction is quoted — the kernel is VALU-issue bound (72 % busy, profiles/)'},
+                         'vector peak and no fraction is quoted; the binding resource is VALU issue (counters.valu_busy)'},
                 {'kernel': 'k_part_encode_rs_xcd (hash-grid gathers through the eval-mode row-sum tables)' if not args.full_rows
                            else 'k_part_encode (64-byte table rows)',
-                 'bound': 'hbm', 'achieved': enc_bytes / (enc_ms * 1e-3) / 1e9 if enc_ms > 0 else 0.0, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
-                 'frac': (enc_bytes / (enc_ms * 1e-3) / HBM_PEAK) if enc_ms > 0 else 0.0,
-                 'traffic': traffic.get('k_part_encode_rs_xcd') if not args.full_rows else None, 'algorithmic_bytes_per_launch': int(enc_bytes),
-                 'kernel_ms_per_launch': enc_ms,
-                 'note': '512 B (16 levels x 8 corners x 4 B row sums) per pair; the 68 MB of row-sum tables are L2 / Infinity-Cache '
-                         'resident, the kernel is bound by index math + L1 line rate, not by HBM' if not args.full_rows
-                         else '8192 B (16 levels x 8 corners x 64 B rows) per pair'},
+                 'bound': 'valu-issue + L2-miss latency (tables are L2 / Infinity-Cache resident)' if not args.full_rows else 'hbm',
+                 'measured_bytes_per_launch': traffic.get('k_part_encode_rs_xcd') if not args.full_rows else None,
+                 'measured_GBps': (traffic['k_part_encode_rs_xcd'] / (enc_ms * 1e-3) / 1e9) if (not args.full_rows and enc_ms > 0 and 'k_part_encode_rs_xcd' in traffic) else None,
+                 'kernel_ms_per_launch': enc_ms, 'counters': binding('k_part_encode_rs_xcd') if not args.full_rows else None,
+                 'nominal_model': {'bytes_per_launch': int(enc_bytes), 'GBps': enc_bytes / (enc_ms * 1e-3) / 1e9 if enc_ms > 0 else 0.0,
+                                   'frac_of_hbm_peak': (enc_bytes / (enc_ms * 1e-3) / HBM_PEAK) if enc_ms > 0 else 0.0,
+                                   'note': 'SECONDARY figure: SURVEY 8d\'s per-pair bytes (16 levels x 8 corners x %d B) x pairs — gathers that hit '
+                                           'L1 / L2 are counted, so this is not HBM traffic and can exceed 1 (64-byte rows: 1.96 in round 1)'
+                                           % (64 if args.full_rows else 4)}},
             ],
             'path_roofline': {
-                'bound': 'hbm', 'bytes_per_step': int(path_bytes), 'achieved': path_bytes / (ms_per_step * 1e-3) / 1e9, 'unit': 'GB/s',
-                'peak': HBM_PEAK / 1e9, 'frac': path_bytes / (ms_per_step * 1e-3) / HBM_PEAK, 'frac_of_measured_copy_rate': path_bytes / (ms_per_step * 1e-3) / 6.29e12,
-                'table_variant': '64-byte trainable rows (8192 B/pair)' if args.full_rows else 'inference row-sum tables (512 B/pair instead of 8192)',
-                'formula': '(%d + 512 + 64) B x evaluated pairs + 1920 B x survivors + (32%s) B x ray-samples + 48 B x rays (SURVEY 8d, rank 0 shard)'
-                           % (tab_b, ' + 20' if want_raw else ''),
-                'traffic': (sum(v for k, v in traffic.items() if k != 'k_row_sums') if traffic else None),      # (the row-sum build runs once per weight version, not per frame)
-                'traffic_source': traffic_src,
-                'note': 'no kernel of the frame is HBM-bound any more (tables are L2 / Infinity-Cache resident through the row sums); the three large '
-                        'kernels are VALU / MFMA issue bound — see roofline and roofline_other'},
+                'bound': 'issue (VALU / MFMA) — no kernel of the frame is HBM-bound',
+                'measured_bytes_per_step': path_traffic, 'measured_GBps': (path_traffic / (ms_per_step * 1e-3) / 1e9) if path_traffic else None,
+                'measured_frac_of_hbm_peak': (path_traffic / (ms_per_step * 1e-3) / HBM_PEAK) if path_traffic else None,
+                'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'traffic_source': src,
+                'nominal_model': {
+                    'bytes_per_step': int(path_bytes), 'GBps': path_bytes / (ms_per_step * 1e-3) / 1e9, 'frac_of_hbm_peak': path_bytes / (ms_per_step * 1e-3) / HBM_PEAK,
+                    'formula': '(%d + 512 + 64) B x evaluated pairs + 1920 B x survivors + (32%s) B x ray-samples + 48 B x rays (SURVEY 8d, rank 0 shard)'
+                               % (tab_b, ' + 20' if want_raw else ''),
+                    'note': 'SECONDARY figure, not a bound: the byte model counts every gather as memory traffic; the measured HBM / Infinity-Cache '
+                            'bytes are about a third of it (rows are reused from L1 / L2), and with the 64-byte rows the model prices the encoder '
+                            'above the HBM peak'},
+                'note': 'the frame is issue-bound: KNN = VALU, part MLPs = MFMA + transcendental issue, encoder = VALU index math + L2-miss '
+                        'latency; see roofline / roofline_other counters'},
             'stage_ms_per_step': {k: v / per for k, v in stage_ms.items()},
         }
+        if world == 1 and not args.no_variants and headline:
+            try:
+                line.update(variant_lines(net, cfg, batch, dev, S, n_rays))
+            except Exception as e:          # informational: never lose the bench line over a variant
+                line['variants_error'] = repr(e)
         if world == 1 and args.train_iters > 0 and not args.shard_of:
             try:
                 line['train_step'] = train_probe(net, dev, S, args.train_iters)

@@ -383,10 +383,7 @@ class GradArena:
         tab_ids = {id(t) for t in self.tables}
         self.small = [p for p in net.parameters() if p.requires_grad and id(p) not in tab_ids]
         n = sum(p.numel() for p in self.small)
-        # + NUM_PARTS activity flags at the tail (they ride along with the data-parallel all-reduce of this buffer: a part is
-        # active if it had a flagged pair on ANY rank)
-        self.flat = torch.zeros(n + NUM_PARTS, device=dev, dtype=torch.float32)
-        self.part_active = self.flat[n:]
+        self.flat = torch.zeros(n, device=dev, dtype=torch.float32)
         self.views, o = {}, 0
         for p in self.small:
             self.views[id(p)] = self.flat[o:o + p.numel()].view_as(p)
@@ -417,16 +414,9 @@ class GradArena:
             G.deform_dense = g(e.dense)
         for k, idx in enumerate((0, 2, 4)):
             G.deform_w[k], G.deform_b[k] = g(net.tpose_deformer.mlp[idx].weight), g(net.tpose_deformer.mlp[idx].bias)
-        G.part_active = self.part_active.data_ptr()
+        G.part_active = None      # every tensor takes every Adam step: the reference runs all five part networks even on zero points
+                                  # (inb_part_network_multiassign.py:223-229), so their gradients are zeros, never None
         return G
-
-    def active_flag_of(self, p):
-        """Device float[1] that reads 0 when parameter `p` belongs to a body part without any flagged pair in the accumulated
-        backward passes (the reference's optimiser skips such tensors: they have no gradient), or None (always active)."""
-        for i, pn in enumerate(self.net.tpose_human.part_networks):
-            if any(p is q for q in pn.parameters()):
-                return self.part_active[i:i + 1]
-        return None
 
     def publish(self):
         """p.grad of every small parameter = its arena view (aliases, no copy); table parameters keep grad None."""

@@ -3,7 +3,10 @@
 `FusedAdam` is torch.optim.Adam (lib/train/optimizer.py:13-31 builds it with one parameter group per tensor,
 `eps=cfg.train.eps`) with the update of every tensor done by `invr_adam_step`; hyper-parameters, per-group `lr`
 (the reference's schedulers write `group['lr']`), `state_dict()` layout (`step`, `exp_avg`, `exp_avg_sq`) and the
-skip-tensors-without-gradient rule are torch's, so optimiser checkpoints interchange with the reference's.
+skip-tensors-without-gradient rule (`p.grad is None`) are torch's, so optimiser checkpoints interchange with the reference's.
+On the fused path every tensor takes every step — also the tensors of a body part without a flagged pair in the batch: the
+reference calls all five part networks even on zero points (inb_part_network_multiassign.py:223-229), their gradients are
+zeros, not None, and its Adam advances `step`, decays the moments and moves the parameters by momentum.
 
 `attach(net)` switches the network's training path to a persistent gradient arena (autograd.GradArena): the fused
 backward (invr_train_bwd) accumulates into fixed addresses — the five part grids as compact ROW-SCALAR gradients, 68 MB
@@ -50,8 +53,7 @@ class FusedAdam(torch.optim.Optimizer):
             self.arena.zero()
 
     def _flush_steps(self):
-        """Write the device-side step counts back into the host `step` tensors (state_dict layout of torch.optim.Adam).  The
-        device is authoritative: a tensor skipped through its activity flag did not count the step."""
+        """Write the device-side step counts back into the host `step` tensors (state_dict layout of torch.optim.Adam)."""
         if self._pending:
             tab = (_abi.InvrAdamTensor * len(self._plan_params)).from_buffer_copy(bytes(self._table.cpu().numpy()))
             for p, e in zip(self._plan_params, tab):
@@ -117,8 +119,7 @@ class FusedAdam(torch.optim.Optimizer):
                 e.param, e.grad, e.exp_avg, e.exp_avg_sq = p.data_ptr(), g.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr()
                 e.numel, e.lr, e.weight_decay = p.numel(), group['lr'], group['weight_decay']
                 e.grad_shift, e.step = sh, int(st['step'])
-                act = self.arena.active_flag_of(p) if self.arena is not None else None
-                e.active = act.data_ptr() if act is not None else None
+                e.active = None
                 n = (p.numel() + E - 1) // E
                 ct.append(np.full(n, t, np.int32))
                 ci.append(np.arange(n, dtype=np.int32))

@@ -78,12 +78,11 @@ def test_configs4_full_size_iteration_vs_oracle_autograd(full_net):
             if id(p) in table_ids:
                 continue
             got = arena.grad_of(p).cpu()
-            if rg is None:                           # a part without any flagged pair: untouched by the reference's backward
-                pid = int(k.split('.')[2])
-                assert float(got.abs().max()) == 0.0 and float(arena.part_active[pid]) == 0.0, k
+            assert rg is not None, k                 # every part network runs, also on zero points: zero gradients, never None
+            if float(rg.abs().max()) == 0.0:         # (a part without any flagged pair)
+                assert float(got.abs().max()) == 0.0, k
+                checked += 1
                 continue
-            if k.startswith('tpose_human'):
-                assert float(arena.part_active[int(k.split('.')[2])]) >= 1.0
             scale = max(float(rg.abs().max()), 1e-6)
             tol = 5e-3 if k.startswith('tpose_deformer') else 2e-4           # pair term: arbitrated in float64 by test_pair_term_gradient_float64_arbitration
             assert float((got - rg).abs().max()) <= tol * scale + 2e-7, (k, float((got - rg).abs().max()), scale)
@@ -91,7 +90,7 @@ def test_configs4_full_size_iteration_vs_oracle_autograd(full_net):
         for i, pn in enumerate(net.tpose_human.part_networks):
             e = pn.embedder
             q = 'tpose_human.part_networks.%d.embedder.' % i
-            if leaves[q + 'hash'].grad is None:
+            if float(leaves[q + 'hash'].grad.abs().max()) == 0.0 and float(leaves[q + 'dense'].grad.abs().max()) == 0.0:
                 assert float(e.row_grad().abs().max()) == 0.0
                 continue
             rows = torch.cat([leaves[q + 'dense'].grad.reshape(-1, 16), leaves[q + 'hash'].grad.reshape(-1, 16)], 0)

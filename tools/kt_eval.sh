@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; T=$1; shift; OUT=$R/gpurun_out/$T; mkdir -p $OUT
 for W in "$@"; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt$W -o tr -- python $R/bench.py --no-cpu-baseline --no-graph --train-iters 0 --steps 20 --warmup 5 --shard-of $W > $OUT/kt$W.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt$W -o tr -- python $R/bench.py --no-cpu-baseline --no-variants --no-graph --train-iters 0 --steps 20 --warmup 5 --shard-of $W > $OUT/kt$W.log 2>&1
   echo "== shard-of $W"
   python - <<PY
 import csv

@@ -4,7 +4,7 @@ R=$GRAFT_REPO_ROOT; T=$1
 OUT=$R/gpurun_out/$T; mkdir -p $OUT
 python $R/bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
 tail -c 400 $OUT/bench.json
-B="python $R/bench.py --no-cpu-baseline --no-graph --train-iters 0"
+B="python $R/bench.py --no-cpu-baseline --no-variants --no-graph --train-iters 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $B --steps 10 --warmup 3 > $OUT/trace.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o fetch -- $B --steps 2 --warmup 1 > $OUT/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/write -o write -- $B --steps 2 --warmup 1 > $OUT/write.log 2>&1

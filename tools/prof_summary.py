@@ -36,7 +36,7 @@ avg = lambda k, c: sum(agg[k][c]) / len(agg[k][c]) if c in agg[k] else float('na
 dur = {short(r['Name']): float(r['AverageNs']) / 1e3 for r in rows}
 out.append('\n## Derived (per launch)\nVALU busy = SQ_ACTIVE_INST_VALU x 4 (quad-cycles) / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8); MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / 1024 / (GRBM_GUI_ACTIVE / 8).\n\n'
            '| kernel | avg_us | HBM/Infinity-Cache read GB (FETCH_SIZE x2, guide gfx950 correction) | write GB | L2 hit % | VALU busy % | MFMA busy % | WAIT_INST_ANY % of wave cycles | VALU instr. per wave |\n|---|---|---|---|---|---|---|---|---|')
-traffic = {}
+traffic, counters = {}, {}
 for k in sel:
     fetch = avg(k, 'FETCH_SIZE') * 1024 * 2 / 1e9
     wr = avg(k, 'WRITE_SIZE') * 1024 / 1e9
@@ -50,6 +50,11 @@ for k in sel:
     t = (avg(k, 'FETCH_SIZE') * 2 + avg(k, 'WRITE_SIZE')) * 1024
     if t == t:
         traffic[k] = int(t)
+    rnd = lambda x, n=3: round(x, n) if x == x else None
+    counters[k] = {'avg_us': rnd(dur.get(k, float('nan')), 1), 'read_GB': rnd(fetch), 'write_GB': rnd(wr),
+                   'l2_hit': rnd(hit / (hit + miss)) if hit + miss > 0 else None, 'valu_busy': rnd(valu / 100), 'mfma_busy': rnd(mfma / 100),
+                   'wait_inst_any_of_wave_cycles': rnd(wait / 100), 'valu_instr_per_wave': rnd(avg(k, 'SQ_INSTS_VALU') / avg(k, 'SQ_WAVES'), 0)}
 open(dst, 'w').write('\n'.join(out) + '\n')
 json.dump(traffic, open(os.path.join(os.path.dirname(dst), 'hbm_traffic_per_launch.json'), 'w'), indent=1)
+json.dump(counters, open(os.path.join(os.path.dirname(dst), 'kernel_counters.json'), 'w'), indent=1)
 print('\n'.join(out[-20:]))
