@@ -161,6 +161,27 @@ def graph_of(render):
     return graph, res
 
 
+def pipelined(net, render, depth):
+    """`depth` captured graphs of render() (own workspace / outputs each), replayed round-robin on `depth` streams -> fn()."""
+    slots = []
+    for _ in range(max(1, depth)):
+        net._ws = None
+        g, _ = graph_of(render)
+        slots.append((g, torch.cuda.Stream()))
+    torch.cuda.synchronize()
+    cnt = [0]
+
+    def fn():
+        g, strm = slots[cnt[0] % len(slots)]
+        cnt[0] += 1
+        if len(slots) == 1:
+            return g.replay()
+        strm.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(strm):
+            g.replay()
+    return fn
+
+
 def time_frames(fn, frames, min_time=0.0, max_regions=200):
     """ms per call of fn(): regions of exactly `frames` calls between two synchronisations, repeated until min_time seconds."""
     fn()
@@ -177,7 +198,7 @@ def time_frames(fn, frames, min_time=0.0, max_regions=200):
             return tot / n * 1e3
 
 
-def variant_lines(net, cfg, batch, dev, S, n_rays):
+def variant_lines(net, cfg, batch, dev, S, n_rays, in_flight=1):
     """Driver-visible variants of the headline frame (SURVEY 8d asks for them): the yaml-default 64 samples/ray,
     the dense stress frame (smpl_thresh = +inf: every ray-sample survives), the trainable 64-byte rows instead of the row-sum
     tables, the 8-way strong-scaling projection from rank 0's shard of a W-way split on this one GPU, and the wall clock of the
@@ -192,8 +213,7 @@ def variant_lines(net, cfg, batch, dev, S, n_rays):
         render = lambda: net.render_rays(ctx, a[0], a[1], a[2], a[3], s, want_raw=True)
         if graph:
             try:
-                g, _ = graph_of(render)
-                return time_frames(g.replay, frames, min_time)
+                return time_frames(pipelined(net, render, in_flight), frames, min_time)
             except Exception as e:
                 sys.stderr.write('variant: hipGraph capture failed (%s), eager launches\n' % e)
         return time_frames(render, frames, min_time)
@@ -205,8 +225,10 @@ def variant_lines(net, cfg, batch, dev, S, n_rays):
         shard[str(W)] = frame_ms(ctx, S, 20, idx=idist.tile_indices(n_rays, 0, W, device=dev))
     out['shard_projection'] = {
         'ms_per_frame_of_rank0_shard': shard, 'projected_speedup': {w: shard['1'] / shard[w] for w in shard},
+        'frames_in_flight': in_flight,
         'note': 'rank 0 of a W-way tile-cyclic split rendered on ONE GPU (full per-frame scene work included, the 4 MB all-gather is '
-                'not): the single-GPU evidence for strong scaling; the measured multi-GPU curve is the driver\'s SCALE record'}
+                'not), frames pipelined as in the headline: the single-GPU evidence for strong scaling; the measured multi-GPU curve is '
+                'the driver\'s SCALE record'}
     # (2) 64 samples per ray (configs/inb/inb_377.yaml default)
     ms = frame_ms(ctx, 64, 20)
     out['samples_64'] = {'ms_per_frame': ms, 'ray_samples_per_sec': n_rays * 64 / (ms * 1e-3), 'samples_per_ray': 64}
@@ -410,6 +432,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--train-iters', type=int, default=10, help='iterations of the informational training-step probe (0 = skip; N=1 only)')
     ap.add_argument('--no-graph', action='store_true', help='launch the ~25 kernels of a frame eagerly instead of replaying one captured hipGraph')
+    ap.add_argument('--in-flight', type=int, default=1, help='frames in flight (captured graphs replayed round-robin on as many streams); 1 = strictly one frame at a time')
     ap.add_argument('--no-variants', action='store_true', help='skip the S=64 / dense / full-row / shard-projection / API-frame variants of the default line')
     ap.add_argument('--shard-of', type=int, default=0, help='debug (1 GPU): render only rank 0\'s ray shard of a W-way split')
     args = ap.parse_args()
@@ -478,18 +501,27 @@ def main():
         # (the library never synchronises or allocates), so a frame replays with one launch.  thread_local capture
         # mode: the RCCL watchdog thread of a multi-rank run may query events while this thread captures.
         try:
-            graph = torch.cuda.CUDAGraph()
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                render()
-            torch.cuda.current_stream().wait_stream(side)
-            with torch.cuda.graph(graph, capture_error_mode='thread_local'):
-                g_out, g_rgba = render()
+            # --in-flight D frames at a time: D captured graphs with their own workspace / output buffers, replayed round-robin
+            # on D streams — frame f+1's kernels start while frame f's short, latency-bound launches (a 1/8 ray shard keeps a
+            # fraction of the 256 CUs busy) are still running.  Frames are independent; every frame still does all its work.
+            slots = []
+            for k in range(max(1, args.in_flight)):
+                net._ws = None                                       # a workspace of its own (allocated in the graph's pool)
+                g, (g_out, g_rgba) = graph_of(render)
+                slots.append((g, torch.cuda.Stream(), g_out, g_rgba))
+            torch.cuda.synchronize()
+            cnt = [0]
 
             def step():
-                graph.replay()
-                return g_out, idist.gather_maps(g_rgba, n_rays, rank, world)
+                g, strm, g_out, g_rgba = slots[cnt[0] % len(slots)]
+                cnt[0] += 1
+                if len(slots) == 1:
+                    g.replay()
+                    return g_out, idist.gather_maps(g_rgba, n_rays, rank, world)
+                strm.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(strm):
+                    g.replay()
+                    return g_out, idist.gather_maps(g_rgba, n_rays, rank, world)
             out, full = step()
         except Exception as e:                       # keep the bench alive: eager launches measure the same work
             sys.stderr.write('hipGraph capture failed (%s); falling back to eager launches\n' % e)
@@ -591,7 +623,7 @@ def main():
                 'pairs_per_part': [int(v) for v in stats_all[1:6]],
                 'pairs_per_active_sample': float(stats_all[1:6].sum()) / max(int(stats_all[0]), 1),
                 'colour_mlp_pairs_per_part_rank0': winners,
-                'parameters': int(n_params), 'raw_occ_materialised': want_raw, 'hip_graph': use_graph,
+                'parameters': int(n_params), 'raw_occ_materialised': want_raw, 'hip_graph': use_graph, 'frames_in_flight': (max(1, args.in_flight) if use_graph else 1),
                 'parallelism': 'tile-cyclic ray shards x%d, full replicas, 1 all-gather/frame' % world,
                 'rays_per_sec': n_rays * args.steps / dt,
                 'note': 'value counts every ray-sample of the frame; %.1f %% of them survive the near-surface cull (the camera sits at %.1f m so '
@@ -649,7 +681,7 @@ def main():
         }
         if world == 1 and not args.no_variants and headline:
             try:
-                line.update(variant_lines(net, cfg, batch, dev, S, n_rays))
+                line.update(variant_lines(net, cfg, batch, dev, S, n_rays, max(1, args.in_flight)))
             except Exception as e:          # informational: never lose the bench line over a variant
                 line['variants_error'] = repr(e)
         if world == 1 and args.train_iters > 0 and not args.shard_of:

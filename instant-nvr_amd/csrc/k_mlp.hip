@@ -557,7 +557,10 @@ __device__ __forceinline__ void rgb_part(float* lds, const MlpAllArgs& a, const 
     }
 }
 
-__global__ __launch_bounds__(MLP_BLOCK, 3) void k_part_rgb_all(MlpAllArgs a) {
+#ifndef RGB_WPS
+#define RGB_WPS 3          // workgroups per CU the colour kernel is compiled / launched for
+#endif
+__global__ __launch_bounds__(MLP_BLOCK, RGB_WPS) void k_part_rgb_all(MlpAllArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     __shared__ int s_tot[INVR_NUM_PARTS];
     const int G = (int)gridDim.x, b = (int)blockIdx.x, lane = threadIdx.x & 63;
@@ -610,7 +613,7 @@ int launch_part_mlp_all(const MlpAllArgs& a, const Workspace& w, hipStream_t st)
     const int64_t per_block = (MLP_BLOCK / 64) * MLP_CB * 16;
     int64_t tiles = cdiv(a.cap, per_block);
     unsigned grid_occ = (unsigned)(tiles < 256 * 4 ? (tiles > 0 ? tiles : 1) : 256 * 4);
-    unsigned grid_rgb = (unsigned)(tiles < 256 * 3 ? (tiles > 0 ? tiles : 1) : 256 * 3);
+    unsigned grid_rgb = (unsigned)(tiles < 256 * RGB_WPS ? (tiles > 0 ? tiles : 1) : 256 * RGB_WPS);
     hipLaunchKernelGGL(k_part_occ_all, dim3(grid_occ), dim3(MLP_BLOCK), 0, st, a);
     INVR_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_winner_lists, dim3((unsigned)w.n_groups), dim3(WL_BLOCK), 0, st, w);
