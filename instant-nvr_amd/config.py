@@ -71,6 +71,7 @@ DEFAULTS = {
     'knn_k': 4,
     'use_knn': True,
     'part_deform': False,
+    'use_amp': False,
     'use_batch_bounds': True,
     'bbox_overlap': 0.2,
     'pair_loss_weight': 10.0,
@@ -127,6 +128,7 @@ UNSUPPORTED = {
     'part_deform': (False, 'cfg.part_deform (inb_part_network_multiassign.py:72,110): the reference itself asserts it off on this path'),
     'tpose_viewdir': (True, 'cfg.tpose_viewdir = False: TPoseHuman.forward indexes the (Na,P,3) view directions per part; the reference cannot run it either'),
     'use_knn': (True, 'cfg.use_knn = False: Network.__init__ of the reference asserts it'),
+    'use_amp': (False, 'cfg.use_amp: the HIP path computes in fp32 (the reference\'s 1e-4 parity bar); half-precision autocast is not built'),
 }
 
 

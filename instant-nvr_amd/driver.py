@@ -45,15 +45,28 @@ def run_evaluate(net, batches, device='cuda'):
     return out
 
 
-def train_step(wrapper, optimizer, batch, iter_step, epoch=0):
-    """trainer.py:108-149 without AMP: add_iter_step, wrapper forward, loss.mean(), zero_grad(set_to_none),
-    backward, step.  Returns (loss value, scalar_stats)."""
+_SCALER = None
+
+
+def train_step(wrapper, optimizer, batch, iter_step, epoch=0, scaler=None):
+    """One optimisation step in the reference's own form (lib/train/trainers/trainer.py:108-149): add_iter_step, the wrapper
+    forward under autocast(enabled=cfg.use_amp), loss.mean(), zero_grad(set_to_none), scaler.scale(loss).backward(),
+    scaler.step(optimizer), scaler.update() with GradScaler(enabled=cfg.use_amp) — use_amp is False in every INB config and
+    rejected by invr.config.validate, so autocast and the scaler are the disabled pass-throughs the reference runs with.
+    Returns (loss value, scalar_stats)."""
+    global _SCALER
+    if scaler is None:
+        if _SCALER is None:
+            _SCALER = torch.amp.GradScaler('cuda', enabled=False)
+        scaler = _SCALER
     batch['iter_step'] = iter_step
-    ret, loss, stats, _ = wrapper(batch, epoch, split='train')
+    with torch.amp.autocast('cuda', enabled=False):
+        ret, loss, stats, _ = wrapper(batch, epoch, split='train')
     loss = loss.mean()
     optimizer.zero_grad(set_to_none=True)
-    loss.backward()
-    optimizer.step()
+    scaler.scale(loss).backward()
+    scaler.step(optimizer)
+    scaler.update()
     return loss.detach(), stats          # a device scalar: reading it (float()) is the caller's synchronisation point
 
 

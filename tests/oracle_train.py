@@ -13,12 +13,12 @@ def reg_raw_crit(x):
     return (v[:, n:] - v[:, :n]).norm(dim=-1).mean()
 
 
-def train_loss(sd, cfg, batch, jitter, noise_dense):
+def train_loss(sd, cfg, batch, jitter, noise_dense, chunk=64):
     """sd: reference-keyed dict of CPU tensors (leaves that require grad get gradients); batch: collated CPU batch;
     jitter (n_rays,S) uniform; noise_dense (N*5,3) uniform per dense (survivor slot, part) row -> (loss, stats dict)."""
     model = O.Model(sd, cfg)
     S = cfg.N_samples
-    ret = O.render(model, batch, n_samples=S, jitter=None if jitter is None else jitter[None], want_train=True, chunk=64)
+    ret = O.render(model, batch, n_samples=S, jitter=None if jitter is None else jitter[None], want_train=True, chunk=chunk)
     img = ((ret['rgb_map'] - batch['rgb']) ** 2).mean()
     loss = img
     stats = {'img_loss': img}

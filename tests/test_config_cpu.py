@@ -8,7 +8,7 @@ from invr.network import Network
 
 
 BAD = [('aggr', 'mean'), ('aggr', 'dist'), ('aggr', 'mindist'), ('knn_k', 3), ('knn_k', 8), ('random_bg', True),
-       ('part_deform', True), ('tpose_viewdir', False), ('use_knn', False)]
+       ('part_deform', True), ('tpose_viewdir', False), ('use_knn', False), ('use_amp', True)]
 
 
 @pytest.mark.parametrize('key,val', BAD)

@@ -29,6 +29,8 @@ from invr import _abi, scene, stages        # noqa: E402
 
 DEV = 'cuda:0'
 S = 128
+WELL_FLOOR = 0.95        # least fraction of the 256 sampled pixels per pose that must be well conditioned and meet the plain 1e-4 bar
+                         # (measured: 254-256 of 256 at the four poses; printed by the test)
 POSES = [dict(seed=0, pose_scale=0.5, frame=3, cam_dist=1.8, thresh=0.05),
          dict(seed=1, pose_scale=1.0, frame=17, cam_dist=1.8, thresh=0.05),
          dict(seed=2, pose_scale=1.2, frame=60, cam_dist=2.2, thresh=0.1),          # inb_lan.yaml smpl_thresh
@@ -272,7 +274,9 @@ def test_render_strict_1e4_on_well_conditioned_pixels(fr):
     sens = (ref64p['rgb_map'][0] - exact).abs().max(1)[0]
     noise = torch.maximum(err_ref, sens)
     well = noise < 2e-6
-    assert int(well.sum()) >= 64, int(well.sum())
+    print('pose %d: well-conditioned pixels %d / %d; max err on them %.2e; worst pixel err %.2e (noise %.2e)'
+          % (k, int(well.sum()), well.numel(), float(err_gpu[well].max()) if bool(well.any()) else 0.0, float(err_gpu.max()), float(noise.max())))
+    assert int(well.sum()) >= WELL_FLOOR * well.numel(), int(well.sum())
     assert float(err_gpu[well].max()) <= 1e-4, ('strict', float(err_gpu[well].max()))           # strict, no allowance
     worst = (err_gpu - (1e-4 + 4 * noise)).argmax()
     assert bool((err_gpu <= 1e-4 + 4 * noise).all()), ('ill-conditioned', float(err_gpu[worst]), float(err_ref[worst]), float(sens[worst]))

@@ -228,3 +228,149 @@ def test_lan_config_training_loop_vs_oracle():
     # the adopted bounds are part of the checkpoint
     b0 = net.state_dict()['tpose_human.part_networks.0.embedder.bounds'].cpu()
     assert torch.equal(b0, sd['tpose_human.part_networks.0.embedder.bounds'])
+
+
+def test_reference_step_form_with_disabled_grad_scaler(small_setup):
+    """The reference's optimisation step, literally (lib/train/trainers/trainer.py:116-149): forward under
+    autocast(enabled=cfg.use_amp), `scaler.scale(loss).backward(); scaler.step(optimizer); scaler.update()` with
+    GradScaler(enabled=cfg.use_amp), use_amp False — on the fused training node + gradient arena + FusedAdam.  The disabled scaler
+    must be a pure pass-through: after 3 steps the parameters equal those of the plain `loss.backward(); optimizer.step()`
+    sequence from the same start (up to the run-to-run rounding of the atomically accumulated gradients, see below)."""
+    cfg, sd, batch, _ = small_setup
+    g = torch.Generator().manual_seed(31)
+    n = 256
+    sel = torch.randperm(batch['ray_o'].shape[1], generator=g)[:n].sort()[0]
+    b = dict(batch)
+    for k in ('ray_o', 'ray_d', 'near', 'far', 'rgb', 'occupancy'):
+        b[k] = batch[k][:, sel]
+    jit = torch.rand(n, cfg.N_samples, generator=g)
+    noi = torch.rand(n * cfg.N_samples * 5, 3, generator=g)
+    finals = []
+    for mode in ('scaler', 'plain'):
+        net = Network(cfg=copy.deepcopy(cfg))
+        net.load_state_dict(sd, strict=True)
+        net = net.to(DEV).train()
+        wrap = NetworkWrapper(net)
+        wrap.renderer._jitter = lambda shape, device: jit.to(device)
+        wrap.renderer._pair_noise_dense = lambda rows, device: noi.to(device)[:rows]
+        opt = driver.make_optimizer(net, lr=5e-4, eps=1e-15)
+        assert isinstance(opt, FusedAdam) and opt.arena is not None
+        scaler = torch.amp.GradScaler('cuda', enabled=False)
+        for it in range(3):
+            gb = {k: v.to(DEV) for k, v in b.items()}
+            gb['iter_step'] = it + 2
+            if mode == 'scaler':
+                with torch.amp.autocast('cuda', enabled=False):
+                    output, loss, loss_stats, image_stats = wrap(gb, 0, split='train')
+                loss = loss.mean()
+                opt.zero_grad(set_to_none=True)
+                scaler.scale(loss).backward()
+                scaler.step(opt)
+                scaler.update()
+            else:
+                output, loss, loss_stats, image_stats = wrap(gb, 0, split='train')
+                loss = loss.mean()
+                opt.zero_grad(set_to_none=True)
+                loss.backward()
+                opt.step()
+        assert np.isfinite(float(loss))
+        finals.append({k: v.detach().cpu().clone() for k, v in net.state_dict().items()})
+        steps = {int(st['step']) for st in opt.state_dict()['state'].values()}
+        assert steps == {3}, steps                            # every tensor took every step (no part is skipped)
+    # (not bit for bit: the backward accumulates weight / table gradients with float atomics, whose order differs from run to
+    # run, and Adam with eps = 1e-15 turns a rounding-level gradient difference into a different step of the few elements whose
+    # gradient IS rounding noise — so: no element further apart than the steps could move it, all but a sliver identical to 1e-6)
+    moved = 0
+    for k in finals[0]:
+        a, b = finals[0][k].double(), finals[1][k].double()
+        if not finals[0][k].is_floating_point():
+            assert torch.equal(finals[0][k], finals[1][k]), k
+            continue
+        d = (a - b).abs()
+        assert float(d.max()) <= 2 * 3 * 5e-4 * 1.01, (k, float(d.max()))
+        assert float((d <= 1e-6 + 1e-5 * b.abs()).double().mean()) >= 0.99, (k, float((d <= 1e-6 + 1e-5 * b.abs()).double().mean()))
+        moved += int(not torch.equal(finals[0][k], sd[k]))
+    assert moved >= 60
+
+
+def test_configs3_real_shape_three_steps_vs_oracle_autograd(full_net):
+    """BASELINE configs[3] at its REAL shape: inb_lan.yaml over inb_377.yaml — smpl_thresh 0.1, pair_loss_weight 1e-4, lr 1e-3,
+    eps 1e-15 — one 64 x 64 patch x 64 samples per iteration on the full-size model (285,993,711 parameters, 1.09 GB of tables),
+    three optimiser steps through driver.train_step (the reference's step form) + FusedAdam, against the same three steps of CPU
+    torch autograd of the oracle + torch.optim.Adam: the loss of every step, and after the third step every small tensor and the
+    table rows the steps touched."""
+    cfg0, net = full_net
+    cfg = copy.deepcopy(cfg0)
+    cfg.update(N_samples=64, smpl_thresh=0.1, pair_loss_weight=1e-4)
+    sd0 = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    old_cfg, was_training = net.cfg, net.training
+    net.cfg = cfg
+    net.train()
+    LR, STEPS = 1e-3, 3
+    try:
+        bc = patch_batch(64, frame=11, centre=(250, 262))
+        n, S = bc['ray_o'].shape[1], 64
+        assert n == 4096
+        g = torch.Generator().manual_seed(41)
+        jit = [torch.rand(n, S, generator=g) for _ in range(STEPS)]
+        noi = [torch.rand(n * S * 5, 3, generator=g) for _ in range(STEPS)]
+        wrap = NetworkWrapper(net)
+        cur = {'k': 0}
+        wrap.renderer._jitter = lambda shape, device: jit[cur['k']].to(device)
+        wrap.renderer._pair_noise_dense = lambda rows, device: noi[cur['k']].to(device)[:rows]
+        opt = driver.make_optimizer(net, lr=LR, eps=1e-15)
+        gb = {k: v.to(DEV) for k, v in bc.items()}
+        mine = []
+        for k in range(STEPS):
+            cur['k'] = k
+            loss, _ = driver.train_step(wrap, opt, dict(gb), k + 2)
+            mine.append(float(loss))
+        torch.cuda.synchronize()
+        got = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+        # ---- the oracle's three steps on the CPU
+        train_keys = [k for k, p in net.named_parameters() if p.requires_grad]
+        sd = {k: v.clone() for k, v in sd0.items()}
+        for k in train_keys:
+            sd[k].requires_grad_()
+        ref_opt = torch.optim.Adam([{'params': [sd[k]], 'lr': LR} for k in train_keys], LR, eps=1e-15)
+        ref = []
+        for k in range(STEPS):
+            loss, _ = OT.train_loss(sd, cfg, bc, jit[k], noi[k], chunk=1024)
+            ref_opt.zero_grad(set_to_none=True)
+            loss.backward()
+            ref_opt.step()
+            ref.append(float(loss))
+        print('configs[3] real shape: losses', mine, 'oracle', ref)
+        assert abs(mine[0] - ref[0]) < 2e-5 * max(1.0, abs(ref[0]))            # identical parameters: fp32 agreement of the objective
+        for a, b in zip(mine, ref):
+            assert abs(a - b) < 5e-3 * max(1e-3, abs(b)), (mine, ref)
+        # parameters after three steps.  Adam with eps 1e-15 moves every element with a gradient by ~lr per step whatever the
+        # gradient's size (sign-like), so elements whose gradient is rounding noise may differ by a few lr; everything else agrees.
+        checked = 0
+        for k in train_keys:
+            a, b, o = got[k].double(), sd[k].detach().double(), sd0[k].double()
+            moved_ref = (b - o).abs()
+            if a.numel() > (1 << 22):                                           # part tables: the rows the three steps touched
+                rows = (moved_ref.reshape(-1, a.shape[-1]).sum(1) > 0).nonzero(as_tuple=True)[0]
+                if rows.numel() == 0:
+                    assert torch.equal(got[k], sd0[k]), k
+                    continue
+                a, b = a.reshape(-1, a.shape[-1])[rows], b.reshape(-1, b.shape[-1])[rows]
+                untouched = (moved_ref.reshape(-1, moved_ref.shape[-1]).sum(1) == 0)
+                assert float((got[k].double() - o).abs().reshape(-1, o.shape[-1])[untouched].max()) <= 3.5 * LR, k   # noise-level rows at most
+            d = (a - b).abs()
+            frac_close = float((d <= 1e-5 + 1e-3 * b.abs()).double().mean())
+            assert float(d.max()) <= 2 * STEPS * LR * 1.01, (k, float(d.max()))  # never more than the steps can move an element
+            assert frac_close >= 0.97, (k, frac_close)
+            checked += 1
+        assert checked >= 60
+    finally:
+        net.cfg = old_cfg
+        net.train(was_training)
+        if hasattr(net, '_grad_arena'):
+            del net._grad_arena
+        with torch.no_grad():
+            for k, p in net.state_dict().items():
+                p.copy_(sd0[k])
+        for p in net.parameters():
+            p.grad = None
