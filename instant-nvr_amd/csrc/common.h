@@ -49,10 +49,12 @@ struct GridDev {
     // T = 2^mod_k + mod_c with a small mod_c (nextprime(2^k)): 32-bit reduction is valid (host-checked)
     int32_t mod_k, mod32;
     uint32_t mod_c;
+    int32_t xdelta;             // mod24 and T > 2^14: the c1x corners' rows follow from the c0x corners' by a +-delta fold (k_encode.hip)
     int32_t mod24;              // mod32 and every multiplicand of its folding rounds < 2^24: v_mul_u32_u24 (full rate) instead of
                                 // v_mul_lo_u32 (quarter rate)
     int32_t res[INVR_MAX_LEVELS];
     float cell[INVR_MAX_LEVELS];
+    float rcell[INVR_MAX_LEVELS];   // RN(1 / cell[l]) when the level qualifies for the reciprocal form of x / cell (level_corners), else 0
     int64_t dense_off[INVR_MAX_LEVELS];
     int32_t sum, sum_over_features, include_input;
     const float* row_sums;      // optional inference-only (rows,) table of per-row feature sums
@@ -221,6 +223,28 @@ __device__ __forceinline__ uint32_t hash_mod(uint32_t cx, uint32_t cy, uint32_t 
 // Normalised coordinate -> per-axis clipped corners and fractional offsets of one level
 // (part_base_embedder.py:115-118): f = x / cell; c0 = clip(trunc(f)), c1 = clip(trunc(f + 1));
 // t = f - c0 (may leave [0,1] outside the box -> extrapolation).
+// x / b through the correctly rounded reciprocal y = RN(1 / b) (host-computed): q0 = RN(x y); two Markstein steps
+// r = fma(-q, b, x), q = fma(r, y, q).  The first makes q faithful, the second then yields RN(x / b) — the IEEE quotient, bit for
+// bit (Markstein 1990; excluded on the host: a divisor whose mantissa is all ones; no over/underflow: |x / b| < 2^40 here and an
+// |x| below 2^-60 takes the hardware division) — in 5 full-rate instructions instead of the ~11 of the v_div_scale / v_rcp /
+// v_div_fmas / v_div_fixup sequence.  The encoders spend 3 divisions per level and pair on it.
+__device__ __forceinline__ float div_by_rcp(float x, float b, float y) {
+    float q = x * y;
+    float r = fmaf(-q, b, x);
+    q = fmaf(r, y, q);
+    r = fmaf(-q, b, x);
+    return fmaf(r, y, q);
+}
+
+__device__ __forceinline__ void level_corners(float x, float cell, float rcell, int res, int& c0, int& c1, float& t) {
+    float f = (rcell != 0.0f && fabsf(x) > 8.7e-19f && fabsf(x) < 1.0e6f) ? div_by_rcp(x, cell, rcell) : x / cell;
+    int a = (int)f;              // v_cvt_i32_f32: truncates toward zero (torch .long())
+    int b = (int)(f + 1.0f);
+    c0 = min(max(a, 0), res - 1);
+    c1 = min(max(b, 0), res - 1);
+    t = f - (float)c0;
+}
+
 __device__ __forceinline__ void level_corners(float x, float cell, int res, int& c0, int& c1, float& t) {
     float f = x / cell;
     int a = (int)f;              // v_cvt_i32_f32: truncates toward zero (torch .long())

@@ -56,9 +56,29 @@ GridDev make_grid_dev(const InvrGrid* g) {
                 d.mod32 = 1;
             // 24-bit multiplies: c and the multiplicands h0 <= 2^41 >> k, h1 <= y1 >> k, h2 <= y2 >> k below 2^24
             d.mod24 = d.mod32 && c < (1u << 24) && ((1ull << 41) >> k) < (1ull << 24) && (y1 >> k) < (1ull << 24) && (y2 >> k) < (1ull << 24);
+            d.xdelta = d.mod24 && d.T > (1ll << 14);         // (resolutions are <= 8192: |delta| < 2^13 < T / 2)
         }
     }
-    for (int l = 0; l < INVR_MAX_LEVELS; ++l) { d.res[l] = g->res[l]; d.cell[l] = g->cell[l]; d.dense_off[l] = g->dense_off[l]; }
+    for (int l = 0; l < INVR_MAX_LEVELS; ++l) {
+        d.res[l] = g->res[l]; d.cell[l] = g->cell[l]; d.dense_off[l] = g->dense_off[l];
+        // reciprocal form of x / cell (common.h:div_by_rcp): y = RN(1 / cell), the float nearest to the exact reciprocal — chosen
+        // among the double-rounded candidate and its neighbours by the exact residual |1 - cell * y| (a product of two floats is
+        // exact in double); not for a divisor whose mantissa is all ones (Markstein's exception) or outside [2^-20, 2^20]
+        d.rcell[l] = 0.0f;
+        const float b = g->cell[l];
+        uint32_t bits;
+        memcpy(&bits, &b, 4);
+        if (l < g->n_levels && b > 9.6e-7f && b < 1.0e6f && (bits & 0x7fffffu) != 0x7fffffu) {
+            const float y0 = (float)(1.0 / (double)b);
+            float best = y0;
+            double err = fabs(1.0 - (double)b * (double)y0);
+            for (float c : {nextafterf(y0, 0.0f), nextafterf(y0, INFINITY)}) {
+                const double e = fabs(1.0 - (double)b * (double)c);
+                if (e < err) { err = e; best = c; }
+            }
+            d.rcell[l] = best;
+        }
+    }
     d.sum = g->sum; d.sum_over_features = g->sum_over_features; d.include_input = g->include_input;
     d.row_sums = (g->sum && g->sum_over_features) ? g->row_sums : nullptr;
     d.dense_rows = 0;

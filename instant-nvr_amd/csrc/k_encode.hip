@@ -581,9 +581,10 @@ __device__ __forceinline__ float level_rowsum(const GridDev& g, const float* __r
     const float cell = g.cell[l];
     int c0x, c1x, c0y, c1y, c0z, c1z;
     float tx, ty, tz;
-    level_corners(x, cell, res, c0x, c1x, tx);
-    level_corners(y, cell, res, c0y, c1y, ty);
-    level_corners(z, cell, res, c0z, c1z, tz);
+    const float rcell = g.rcell[l];
+    level_corners(x, cell, rcell, res, c0x, c1x, tx);
+    level_corners(y, cell, rcell, res, c0y, c1y, ty);
+    level_corners(z, cell, rcell, res, c0z, c1z, tz);
     unsigned row[8];
     const float* tab;
     if (l >= g.start_hash) {
@@ -597,7 +598,23 @@ __device__ __forceinline__ float level_rowsum(const GridDev& g, const float* __r
         const uint64_t hx[2] = {(uint64_t)(uint32_t)c0x, (uint64_t)(uint32_t)c1x};
         const uint64_t hy[2] = {hy0, hy0 + (dy > 0 ? HASH_P1 : 0ull) + (dy > 1 ? HASH_P1 : 0ull)};
         const uint64_t hz[2] = {hz0, hz0 + (dz > 0 ? HASH_P2 : 0ull) + (dz > 1 ? HASH_P2 : 0ull)};
-        if (g.mod24) {
+        if (g.xdelta) {
+            // x's hash prime is 1, so the four corners at c1x are the corners at c0x with the low bits m = c0x ^ c1x flipped:
+            // X ^ m = X + m - 2 (X & m), a shift of |delta| <= m < 4096 — their reduction mod T is the c0x corner's + delta, folded
+            // back into [0, T) (T > 2^14 > 2 |delta|: host-checked, GridDev.xdelta), instead of four
+            // more 3-round reductions
+            const uint32_t m = (uint32_t)c0x ^ (uint32_t)c1x;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint64_t X = hx[0] ^ hy[(k >> 1) & 1] ^ hz[k & 1];
+                const uint32_t r0 = hash_mod24(X, g.mod_k, g.mod_c, (uint32_t)g.T);
+                row[k] = r0;
+                int32_t r1 = (int32_t)r0 + (int32_t)m - 2 * (int32_t)((uint32_t)X & m);
+                r1 += (r1 < 0) ? (int32_t)g.T : 0;
+                r1 -= (r1 >= (int32_t)g.T) ? (int32_t)g.T : 0;
+                row[4 + k] = (uint32_t)r1;
+            }
+        } else if (g.mod24) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) row[k] = hash_mod24(hx[k >> 2] ^ hy[(k >> 1) & 1] ^ hz[k & 1], g.mod_k, g.mod_c, (uint32_t)g.T);
         } else {
