@@ -440,6 +440,17 @@ class GradArena:
             e.expand_row_grad()
 
 
+def check_workspace(net, ws, gen, what):
+    """The fused training forward leaves its pair lists and activations in the network's shared workspace; the backward and the
+    lazily materialised tensors read them again.  Any library call on the same network in between (a second training forward
+    — gradient accumulation, summed losses —, an eval render, Network.forward, geometry_pass) overwrites them: raise instead of
+    differentiating someone else's pair lists."""
+    if net._ws is not ws or getattr(net, '_ws_gen', None) != gen:
+        raise RuntimeError('invr: the training %s needs the workspace of ITS forward, but another call on this network has used the '
+                           'workspace since (a second forward before the backward, an eval render, Network.forward ...).  Run '
+                           'backward() / read resd, tpts, tocc, oresd before the next call on the network.' % what)
+
+
 class TrainRenderFn(torch.autograd.Function):
     """Renderer.render in train mode + the regulariser reductions as ONE differentiable node: forward = invr_train_fwd,
     backward = invr_train_bwd.  `params` are the network's parameters (listed so that autograd connects the node to them).
@@ -462,6 +473,7 @@ class TrainRenderFn(torch.autograd.Function):
         stats = torch.zeros(_abi.STATS_LEN, dtype=torch.int32, device=dev)
         nbytes = L.invr_train_workspace_bytes(n, S, max_active)
         ws = net.workspace(nbytes, dev)
+        ctx.ws_gen = net._ws_gen
         jit = None if jitter is None else f(jitter)
         noise = None if pair_noise is None else f(pair_noise)
         _abi.check(L.invr_train_fwd(C.byref(rctx.scene), C.byref(rctx.model), _abi.ptr(ray_o), _abi.ptr(ray_d), _abi.ptr(near), _abi.ptr(far),
@@ -480,6 +492,7 @@ class TrainRenderFn(torch.autograd.Function):
         L = _abi.lib()
         raw, weights, z = ctx.saved_tensors
         net, rctx, arena = ctx.net, ctx.rctx, ctx.arena
+        check_workspace(net, ctx.ws, ctx.ws_gen, 'backward')
         n, S, max_active, nbytes = ctx.dims
         dev = raw.device
         c = lambda t: None if t is None else t.to(torch.float32).contiguous()

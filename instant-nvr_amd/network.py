@@ -214,7 +214,7 @@ class Network(nn.Module):
         self.tpose_human = TPoseHuman(self.cfg)
         self._ws = None
 
-    _TRANSIENT = ('_model_key', '_model_base', '_model_keep', '_ws', '_grad_arena')
+    _TRANSIENT = ('_model_key', '_model_base', '_model_keep', '_ws', '_ws_gen', '_grad_arena')
 
     def __getstate__(self):
         # derived ctypes views / scratch buffers are not part of the module's state (copy.deepcopy, pickling)
@@ -250,8 +250,12 @@ class Network(nn.Module):
         return m
 
     def workspace(self, nbytes, device):
+        """The shared scratch buffer of this network's library calls.  Every hand-out bumps `_ws_gen`: a caller that reads the
+        buffer again later (the training backward, the lazily materialised train-mode tensors) remembers the generation of its
+        own call and refuses to run on a buffer some other call has overwritten since."""
         if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self._ws_gen = getattr(self, '_ws_gen', 0) + 1
         return self._ws
 
     def adopt_batch_bounds(self, batch):

@@ -64,6 +64,13 @@ class FusedAdam(torch.optim.Optimizer):
         self._flush_steps()
         return super().state_dict()
 
+    def __getstate__(self):
+        # copy.deepcopy / pickle read `state` directly: make the host-side step counts current first.  (Reading
+        # optimizer.state[p]['step'] by hand between steps sees the value of the last flush; a scheduler that changes a learning
+        # rate EVERY iteration rebuilds the device table each time — one small device-to-host read per step.)
+        self._flush_steps()
+        return super().__getstate__()
+
     def load_state_dict(self, sd):
         self._flush_steps()
         super().load_state_dict(sd)

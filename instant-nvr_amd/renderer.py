@@ -163,9 +163,10 @@ class Renderer:
         if cfg.use_pair_reg:
             base['pair_loss'] = terms[ag.TERM_PAIR_SUM] / terms[ag.TERM_PAIR_ROWS].clamp(min=1.0)
             lazy.append('oresd')
-        ws = net._ws
+        ws, ws_gen = net._ws, net._ws_gen
 
         def materialise():
+            ag.check_workspace(net, ws, ws_gen, "forward's resd / tpts / tocc / oresd read-back")
             with torch.no_grad():
                 return self._train_extras(net, ctx, ws, stats, n, S, max_active, noise, (ray_o, ray_d, near, far), jitter)
         return ag.LazyTrainRet(base, lazy, materialise)

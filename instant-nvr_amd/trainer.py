@@ -72,6 +72,11 @@ class NetworkWrapper(nn.Module):
                     raise RuntimeError('cfg.use_lpips is set (configs/inb/inb_377.yaml:196) but no perceptual loss is available: pass '
                                        'NetworkWrapper(net, perceptual_loss=module), set cfg.vgg19_weights to a torchvision VGG19 '
                                        'state_dict, run inside the reference (torchvision), or set use_lpips False for the plain MSE')
+            # the reference's PerceptualLoss moves its VGG to the GPU in its constructor (perceptual_loss.py:50); here the module
+            # follows the network's device — the wrapper is normally built after net.to(device) and not moved again
+            dev = next(net.parameters()).device
+            if isinstance(perceptual_loss, torch.nn.Module):
+                perceptual_loss = perceptual_loss.to(dev)
             self.perceptual_loss = perceptual_loss
         for flag, mod, cls, attr in (('use_ssim', 'lib.utils.loss_utils', 'SSIM', 'ssim_loss'),
                                      ('use_fourier', 'lib.train.trainers.loss.fourier_loss', 'FourierLoss', 'fourier_loss'),

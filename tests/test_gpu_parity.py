@@ -504,8 +504,9 @@ def test_network_wrapper_lpips_patch_branch(gpu_setup, golden):
     net.cfg = copy.deepcopy(cfg)
     net.cfg.use_lpips = True
     torch.manual_seed(3)
-    pl = PerceptualLoss(allow_random=True).to(DEV)
+    pl = PerceptualLoss(allow_random=True)                 # built on the CPU: the wrapper moves it to the network's device
     wrap = NetworkWrapper(net, perceptual_loss=pl)
+    assert next(wrap.perceptual_loss.parameters()).device.type == 'cuda'
     seen = {}
 
     class Spy(torch.nn.Module):
@@ -909,3 +910,26 @@ def test_far_fold_distance_follows_the_frame_matrices(gpu_setup, scale):
     x0 = (tp - rs)[far]                                                          # init_bigpose of the folded pairs
     assert float(x0.abs().max()) <= 1.5e-8, float(x0.abs().max())
     assert float(td[far].abs().max()) <= 1e-15, float(td[far].abs().max())
+
+
+def test_training_backward_refuses_an_overwritten_workspace(gpu_setup, golden):
+    """The fused training forward keeps its pair lists / activations in the network's shared workspace.  A second library call
+    on the network before the backward (gradient accumulation over two forwards, an eval render) overwrites them: the backward
+    and the lazy train-mode tensors must raise instead of differentiating the other call's lists."""
+    import copy
+    from invr.trainer import NetworkWrapper
+    cfg, sd, batch, gb, net0 = gpu_setup
+    net = copy.deepcopy(net0).train()
+    net.cfg = copy.deepcopy(cfg)
+    wrap = NetworkWrapper(net)
+    tb = _train_batch(gb, golden)
+    tb['iter_step'] = 2
+    ret1, loss1, _, _ = wrap(dict(tb), split='train')
+    ret2, loss2, _, _ = wrap(dict(tb), split='train')           # second forward: takes over the workspace
+    with pytest.raises(RuntimeError, match='workspace'):
+        loss1.backward()
+    with pytest.raises(RuntimeError, match='workspace'):
+        ret1['tocc']
+    assert ret2['tocc'].shape[1] == ret2['resd'].shape[1]         # the latest forward is fine
+    loss2.backward()
+    assert sum(float(p.grad.abs().sum()) for p in net.parameters() if p.grad is not None) > 0
