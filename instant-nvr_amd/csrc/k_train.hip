@@ -461,6 +461,8 @@ int launch_deform_bwd(const RenderArgs& a, const Workspace& w, const TrainWs& t,
     jobs.j[2] = WgradJob{t.d_gz3, t.d_a2, G.w[2], G.b[2], 0, 4, 32, 3, 32, 32};
     if (launch_wgrad(jobs, w.counters + CNT_DTOT, t.DM, st)) return 1;
     // grid^T: table gradients of the deformer's 8 x 2 grid (the (u,v,t) input carries no gradient)
+    const int rc = launch_deform_slice_bwd(dg, a.scene.frame_dim, t.d_uvt, t.d_gfeat, t.DM, w.counters + CNT_DTOT, G.dense, G.hash, st);
+    if (rc >= 0) return rc;
     return launch_grid_encode_bwd_generic(dg, t.d_uvt, t.d_gfeat, t.DM, G.dense, G.hash, nullptr, st, w.counters + CNT_DTOT);
 }
 

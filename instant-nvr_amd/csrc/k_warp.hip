@@ -604,6 +604,94 @@ int launch_deform_slice(const RenderArgs& a, const Workspace& w, const GridDev& 
     return 0;
 }
 
+// ---- backward of the deformer's grid through the same t-slices -------------------------------------------------------------
+// feature (l, f) of a point = sum over its four (u, v) corners of w_uv * S_l[corner][f],  S_l = (1-tz) row(., ., c0z) + tz row(., ., c1z)
+// with ONE tz per call.  So the table gradient is the transposed two-step: every workgroup scatter-adds w_uv * g into a 24 KB LDS
+// image of the slices (2959 float2 entries for the reference's 8 levels) over its share of the points, then sends each non-zero
+// entry to its two table rows with the weights (1-tz, tz).  The generic level-outer backward (k_grid_encode_bwd_rt) zeroed and
+// flushed a 132 KB LDS image of a whole 3-D level slice per level and workgroup: 242 us per iteration for ~1e5 points; this one
+// 125 us with one workgroup per CU — bound by the LDS atomics of the coarse levels (all points of a workgroup on 16..50 entries;
+// reducing wave-uniform cells with shuffles first did not help: the UV coordinates of neighbouring points are unrelated).
+#define DSB_BLOCK 1024
+__global__ __launch_bounds__(DSB_BLOCK) void k_deform_slice_bwd(GridDev dg, DfSliceInfo si, const float* __restrict__ frame_dim,
+                                                                const float* __restrict__ uvt, const float* __restrict__ gfeat,
+                                                                int64_t n_host, const int32_t* __restrict__ count, int feat_dim,
+                                                                float* __restrict__ g_dense, float* __restrict__ g_hash) {
+    extern __shared__ __attribute__((aligned(16))) float2 gS[];
+    const int64_t n = count ? (int64_t)*count : n_host;
+    const int total = si.off[dg.L];
+    for (int e = threadIdx.x; e < total; e += DSB_BLOCK) gS[e] = make_float2(0.f, 0.f);
+    __syncthreads();
+    const float gb0 = dg.bounds[0], gb1 = dg.bounds[1];
+    const float ge0 = dg.bounds[3] - gb0, ge1 = dg.bounds[4] - gb1;
+    const int off = dg.include_input ? 3 : 0;
+    for (int64_t i = (int64_t)blockIdx.x * DSB_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * DSB_BLOCK) {
+        const float un = (uvt[i * 3] - gb0) / ge0, vn = (uvt[i * 3 + 1] - gb1) / ge1;          // :112
+        const float* go = gfeat + i * feat_dim + off;
+#pragma unroll 2
+        for (int l = 0; l < 8; ++l) {
+            const float g0 = go[2 * l], g1 = go[2 * l + 1];
+            const int res = dg.res[l];
+            int c0x, c1x, c0y, c1y;
+            float tx, ty;
+            level_corners(un, dg.cell[l], res, c0x, c1x, tx);
+            level_corners(vn, dg.cell[l], res, c0y, c1y, ty);
+            const float ux = 1.0f - tx, uy = 1.0f - ty;
+            float* r0 = reinterpret_cast<float*>(gS + si.off[l] + c0x * res);
+            float* r1 = reinterpret_cast<float*>(gS + si.off[l] + c1x * res);
+            const float w00 = ux * uy, w01 = ux * ty, w10 = tx * uy, w11 = tx * ty;
+            atomicAdd(r0 + 2 * c0y, w00 * g0); atomicAdd(r0 + 2 * c0y + 1, w00 * g1);
+            atomicAdd(r0 + 2 * c1y, w01 * g0); atomicAdd(r0 + 2 * c1y + 1, w01 * g1);
+            atomicAdd(r1 + 2 * c0y, w10 * g0); atomicAdd(r1 + 2 * c0y + 1, w10 * g1);
+            atomicAdd(r1 + 2 * c1y, w11 * g0); atomicAdd(r1 + 2 * c1y + 1, w11 * g1);
+        }
+    }
+    __syncthreads();
+    const float tn = (frame_dim[0] - dg.bounds[2]) / (dg.bounds[5] - dg.bounds[2]);
+    for (int e = threadIdx.x; e < total; e += DSB_BLOCK) {
+        const float2 g = gS[e];
+        if (g.x == 0.0f && g.y == 0.0f) continue;
+        int l = 0;
+        while (e >= si.off[l + 1]) ++l;
+        const int res = dg.res[l];
+        int c0z, c1z;
+        float tz;
+        level_corners(tn, dg.cell[l], res, c0z, c1z, tz);
+        const int idx = e - si.off[l], cx = idx / res, cy = idx - cx * res;
+        const bool hashed = l >= dg.start_hash;
+        float* tb = dg.separate_dense ? (hashed ? g_hash + (int64_t)(l - dg.start_hash) * dg.T * 2 : g_dense + dg.dense_off[l] * 2)
+                                      : g_hash + (int64_t)l * dg.T * 2;
+        unsigned r0, r1;
+        if (hashed) {
+            const uint64_t hxy = (uint64_t)(uint32_t)cx ^ ((uint64_t)(uint32_t)cy * HASH_P1);
+            r0 = grid_hash_mod(hxy ^ ((uint64_t)(uint32_t)c0z * HASH_P2), dg);
+            r1 = grid_hash_mod(hxy ^ ((uint64_t)(uint32_t)c1z * HASH_P2), dg);
+        } else {
+            r0 = ((unsigned)cx * (unsigned)res + (unsigned)cy) * (unsigned)res + (unsigned)c0z;
+            r1 = ((unsigned)cx * (unsigned)res + (unsigned)cy) * (unsigned)res + (unsigned)c1z;
+        }
+        const float uz = 1.0f - tz;
+        unsafeAtomicAdd(tb + (int64_t)r0 * 2, uz * g.x); unsafeAtomicAdd(tb + (int64_t)r0 * 2 + 1, uz * g.y);
+        unsafeAtomicAdd(tb + (int64_t)r1 * 2, tz * g.x); unsafeAtomicAdd(tb + (int64_t)r1 * 2 + 1, tz * g.y);
+    }
+}
+
+// -> 0 launched, 1 error, -1 not applicable (the slices do not fit / not the 8 x 2 concat grid): use the generic backward
+int launch_deform_slice_bwd(const GridDev& dg, const float* frame_dim, const float* uvt, const float* gfeat, int64_t n_max,
+                            const int32_t* count, float* g_dense, float* g_hash, hipStream_t st) {
+    DfSliceInfo si;
+    if (!deform_slices_fit(dg, si, deform_cb()) || dg.F != 2 || dg.sum || !dg.include_input) return -1;
+    if (n_max == 0) return 0;
+    const size_t lds_bytes = (size_t)si.off[8] * sizeof(float2);
+    const int64_t tiles = cdiv(n_max, DSB_BLOCK);
+    static const int gmax = getenv("INVR_DSB_GRID") ? atoi(getenv("INVR_DSB_GRID")) : 256;
+    const unsigned grid = (unsigned)(tiles < gmax ? (tiles > 0 ? tiles : 1) : gmax);
+    hipLaunchKernelGGL(k_deform_slice_bwd, dim3(grid), dim3(DSB_BLOCK), lds_bytes, st, dg, si, frame_dim, uvt, gfeat, n_max, count,
+                       3 + 16, g_dense, g_hash);
+    INVR_LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_warp_pairs(const RenderArgs& a, const Workspace& w, const GridDev& dg, const MlpDev& dm, hipStream_t st) {
     int64_t tiles = cdiv(w.lcap, WARP_BLOCK);
     unsigned gx = (unsigned)(tiles < 1024 ? (tiles > 0 ? tiles : 1) : 1024);

@@ -35,3 +35,5 @@ struct WgradJob;
 struct WgradJobs;
 int launch_part_wgrad(const float* gz, const float* a, int64_t lcap, int n_rgb, float* const* dW, float* const* db,
                       const int32_t* count, hipStream_t st);
+int launch_deform_slice_bwd(const GridDev& dg, const float* frame_dim, const float* uvt, const float* gfeat, int64_t n_max,
+                            const int32_t* count, float* g_dense, float* g_hash, hipStream_t st);
