@@ -71,6 +71,7 @@ class Renderer:
         self.eval_to_cpu = True        # reference moves every eval output to the CPU (:199-200)
         self.want_raw = True           # reference always returns raw/occ
         self.adaptive_cap = True       # size the workspace from the previous frame's survivor count (eval_to_cpu only)
+        self.pin_host = True           # eval_to_cpu: page-locked host tensors for the outputs (False: ordinary pageable tensors)
         self._cap_hint = None
 
     def render(self, batch, test=False, epoch=-1):
@@ -122,7 +123,18 @@ class Renderer:
             ret['occ'] = cat('occ')[None, :, None]
         self.last_stats = outs[-1]['stats']
         if self.eval_to_cpu:
-            ret = {k: v.detach().cpu() for k, v in ret.items()}
+            # the reference moves every eval output to the host (:199-200).  raw + occ of a 512x512x128 frame are 656 MB: through
+            # pageable memory that copy takes ~25x the render; page-locked destinations (torch's caching host allocator: fresh
+            # tensors per call, no aliasing between frames) and one stream synchronisation bring it to the PCIe rate
+            host = {}
+            for k, v in ret.items():
+                v = v.detach()
+                h = torch.empty(v.shape, dtype=v.dtype, device='cpu', pin_memory=self.pin_host and v.is_cuda)
+                h.copy_(v, non_blocking=True)
+                host[k] = h
+            if any(v.is_cuda for v in ret.values()):
+                torch.cuda.current_stream().synchronize()
+            ret = host
         return ret
 
     def _jitter(self, shape, device):
