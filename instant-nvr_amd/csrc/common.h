@@ -236,8 +236,24 @@ __device__ __forceinline__ float div_by_rcp(float x, float b, float y) {
     return fmaf(r, y, q);
 }
 
+// x / b, bit for bit: the reciprocal form where it is proven (y = RN(1 / b) != 0 handed in, x in the safe range), else the hardware
+// division
+__device__ __forceinline__ float div_exact(float x, float b, float y) {
+    const bool ok = y != 0.0f && fabsf(x) > 8.7e-19f && fabsf(x) < 1.0e6f;
+    // a WAVE-uniform branch: written as a select the compiler evaluates both forms for every lane (measured: slower than the
+    // plain division); the hardware division only runs when some lane of the wave needs it
+    if (__ballot(!ok) == 0ull) return div_by_rcp(x, b, y);
+    return ok ? div_by_rcp(x, b, y) : x / b;
+}
+// y for div_exact from a divisor only known on the device: 1.0f / b is the correctly rounded reciprocal (IEEE division); 0 = do not
+// use the reciprocal form (Markstein's exception: a mantissa of all ones; divisors outside [2^-20, 2^20])
+__device__ __forceinline__ float rcp_for_div(float b) {
+    const bool ok = fabsf(b) > 9.6e-7f && fabsf(b) < 1.0e6f && (__float_as_uint(b) & 0x7fffffu) != 0x7fffffu;
+    return ok ? 1.0f / b : 0.0f;
+}
+
 __device__ __forceinline__ void level_corners(float x, float cell, float rcell, int res, int& c0, int& c1, float& t) {
-    float f = (rcell != 0.0f && fabsf(x) > 8.7e-19f && fabsf(x) < 1.0e6f) ? div_by_rcp(x, cell, rcell) : x / cell;
+    float f = div_exact(x, cell, rcell);
     int a = (int)f;              // v_cvt_i32_f32: truncates toward zero (torch .long())
     int b = (int)(f + 1.0f);
     c0 = min(max(a, 0), res - 1);

@@ -61,12 +61,13 @@ __global__ void k_cull_cells(VolDev v, float thresh_hi, uint8_t* __restrict__ ma
 // distance channel of the pose-space volume at (px,py,pz): sample_volume_dev<1> (same arithmetic, bit for bit)
 // with the cell-mask early-out; returns +inf for samples in masked-out cells (they fail pn < thresh either way)
 template <typename IDX>        // IDX = uint32_t when dx*dy*dz*c < 2^31 (host-checked): 64-bit index multiplies are quarter rate
-__device__ __forceinline__ float cull_distance(const VolDev& v, const uint8_t* __restrict__ mask, float px, float py, float pz) {
+__device__ __forceinline__ float cull_distance(const VolDev& v, const uint8_t* __restrict__ mask, float px, float py, float pz, const float* rext) {
     const float b0x = v.bounds[0], b0y = v.bounds[1], b0z = v.bounds[2];
     const float b1x = v.bounds[3], b1y = v.bounds[4], b1z = v.bounds[5];
-    float gx = (px - b0x) / (b1x - b0x) * 2.0f - 1.0f;
-    float gy = (py - b0y) / (b1y - b0y) * 2.0f - 1.0f;
-    float gz = (pz - b0z) / (b1z - b0z) * 2.0f - 1.0f;
+    // (p - b0) / (b1 - b0): the IEEE quotients through the per-thread reciprocals of the three extents (common.h:div_exact)
+    float gx = div_exact(px - b0x, b1x - b0x, rext[0]) * 2.0f - 1.0f;
+    float gy = div_exact(py - b0y, b1y - b0y, rext[1]) * 2.0f - 1.0f;
+    float gz = div_exact(pz - b0z, b1z - b0z, rext[2]) * 2.0f - 1.0f;
     float ix = ((gx + 1.0f) * 0.5f) * (float)(v.dx - 1);
     float iy = ((gy + 1.0f) * 0.5f) * (float)(v.dy - 1);
     float iz = ((gz + 1.0f) * 0.5f) * (float)(v.dz - 1);
@@ -97,6 +98,12 @@ template <bool MASKED, bool FAST>
 __global__ __launch_bounds__(CULL_BLOCK) void k_cull_flag(RenderArgs a, Workspace w, double inv_S, float lin_step) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     __shared__ int cnt[CULL_PER * (CULL_BLOCK / 64)];
+    float rext[3] = {0.f, 0.f, 0.f};
+    if (MASKED) {
+        const float* pb = a.scene.pbw.bounds;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rext[c] = rcp_for_div(pb[3 + c] - pb[c]);
+    }
 #pragma unroll
     for (int k = 0; k < CULL_PER; ++k) {
         const int64_t i = (int64_t)blockIdx.x * CULL_TILE + k * CULL_BLOCK + threadIdx.x;
@@ -125,7 +132,7 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_cull_flag(RenderArgs a, Workspac
             }
             if (a.z_vals) a.z_vals[i] = z;
             float pn;
-            if (MASKED) pn = FAST ? cull_distance<uint32_t>(a.scene.pbw, w.cullmask, px, py, pz) : cull_distance<int64_t>(a.scene.pbw, w.cullmask, px, py, pz);
+            if (MASKED) pn = FAST ? cull_distance<uint32_t>(a.scene.pbw, w.cullmask, px, py, pz, rext) : cull_distance<int64_t>(a.scene.pbw, w.cullmask, px, py, pz, rext);
             else sample_volume_dev<1>(a.scene.pbw, a.scene.pbw.c - 1, px, py, pz, &pn);   // distance channel
             keep = pn < a.scene.thresh;                                               // :135
         }
