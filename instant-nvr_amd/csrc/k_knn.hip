@@ -25,10 +25,14 @@
 // pairs.  Exactness: near/band pairs are bit-faithful brute-force results; far pairs differ from
 // the reference by <= 1.1e-9 m in the canonical point (see above).
 //
-// Data layout: a per-frame prepare kernel Morton-sorts each part's vertices (bitonic sort in LDS),
-// writes them as float4 {x,y,z,original row} and builds 64-vertex clusters {AABB, representative}.
-// The query kernel is one thread per point; cluster records and vertices are wave-uniform reads
-// (scalar path / broadcast), pruned per wave with lb(cluster) < current 4th-best.
+// Data layout: a per-frame prepare kernel (k_part_prepare, side stream) Morton-sorts each part's vertices — a counting sort on
+// the 12 leading Morton bits in LDS, every element ranking itself inside its bucket — and writes them pair-interleaved,
+// {x0,x1,y0,y1}{z0,z1,row0,row1} per two vertices, with one {AABB, first vertex} record per 64-vertex cluster and four AABBs of its
+// 16-vertex sub-clusters; k_knn_voxel_class classifies the live lattice cells of the distance volume per part (far / provably
+// unflagged / undecided + candidate-cluster mask + 4th-nearest bound).  The query kernel (k_knn_pairs) holds the WHOLE index in
+// LDS (persistent 1024-thread workgroups, one per CU); a wave draws tickets of 64 survivors, one thread per point: every vertex /
+// record read is a wave-uniform (broadcast) ds_read_b128, clusters and sub-clusters are pruned per wave with
+// lb(box) <= current 4th-best, distances of two vertices per packed-fp32 instruction, top-4 kept as 64-bit (distance, row) keys.
 #include <stdlib.h>
 #include "pipeline.h"
 
