@@ -12,6 +12,13 @@ import torch.distributed as dist
 DEFAULT_TILE = 512       # rays per tile (one image-row-sized strip of the compacted ray list)
 
 
+def FORCE_COLLECTIVES():
+    """INVR_FORCE_COLLECTIVES=1: issue the collectives even in a group of one rank — lets a 1-GPU box execute the very RCCL calls
+    (device all_gather_into_tensor, ReduceOp.AVG all-reduce, async handles) the multi-GPU runs make (tests/test_gpu_rccl_world1.py)."""
+    import os
+    return os.environ.get('INVR_FORCE_COLLECTIVES', '0') == '1'
+
+
 def tile_indices(n_rays, rank, world, tile=DEFAULT_TILE, device='cpu'):
     """Ray indices owned by `rank`: tiles rank, rank+world, rank+2*world, ... of `tile` rays."""
     n_tiles = (n_rays + tile - 1) // tile
@@ -45,7 +52,7 @@ def gather_plan(n_rays, world, tile, device):
 def gather_maps(local_rgba, n_rays, rank, world, tile=DEFAULT_TILE, group=None):
     """All-gather the per-rank [r,g,b,acc] rows (n_local,4) into the full (n_rays,4) map:
     one padded all_gather_into_tensor + one index_select."""
-    if world == 1:
+    if world == 1 and not FORCE_COLLECTIVES():
         return local_rgba
     dev = local_rgba.device
     mx, src = gather_plan(n_rays, world, tile, dev)

@@ -17,6 +17,8 @@ beside the remaining backward stages; `wait()` (FusedAdam.step via optimizer hoo
 import torch
 import torch.distributed as dist
 
+from .dist import FORCE_COLLECTIVES
+
 
 class GradReducer:
     def __init__(self, arena, group=None):
@@ -30,7 +32,7 @@ class GradReducer:
         arena.reducer = self
 
     def _all_reduce_mean(self, t):
-        if self.world == 1:
+        if self.world == 1 and not (dist.is_initialized() and FORCE_COLLECTIVES()):
             return
         if self.backend == 'nccl':
             self.pending.append(dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=True))
