@@ -281,3 +281,106 @@ def test_render_strict_1e4_on_well_conditioned_pixels(fr):
     worst = (err_gpu - (1e-4 + 4 * noise)).argmax()
     assert bool((err_gpu <= 1e-4 + 4 * noise).all()), ('ill-conditioned', float(err_gpu[worst]), float(err_ref[worst]), float(sens[worst]))
     assert float(err_gpu.median()) < 2e-6
+
+
+def test_two_phase_mlp_and_winner_lists_vs_whole_field(fr):
+    """The part MLPs run in two phases since round 3 (k_part_occ_all -> k_winner_lists -> k_part_rgb_all: colour only for the pair
+    that wins its survivor's max-occupancy merge).  For the WHOLE frame (2.4 M survivors, 584 slot groups: the colour kernel's
+    segment cursor crosses several 64-group windows) at every pose:
+      * occp of every listed pair = the occupancy of the one-kernel field evaluation (invr_part_field_fwd: encoder + both MLPs for
+        every pair) of the same canonical points,
+      * wsel of every survivor = the reference's merge rule (inb_part_network_multiassign.py:229-256: zeros for unflagged parts,
+        the part constant for far pairs, FIRST maximum) applied to those occupancies,
+      * the winner lists hold exactly the winning listed pairs (+ the far-constant pair of every part), segment by segment,
+      * rgbw at every survivor with a listed winner = the field's [rgb, occ] of the winning pair."""
+    import ctypes as C
+    f = fr
+    v, st, Na, net, cfg = f['v'], f['st'], f['Na'], f['net'], f['cfg']
+    L = _abi.lib()
+    keep = []
+    old = net.cfg
+    net.cfg = cfg
+    try:
+        model = net.model_struct(keep)
+    finally:
+        net.cfg = old
+    li = f['gb']['latent_index'].reshape(-1)[:1].to(torch.int64).contiguous()
+    cap, lc = v['cap'], v['lcap']
+    cnt = [int(st[1 + p]) for p in range(5)]
+    fields = []
+    cand = torch.zeros(Na, 5, device=DEV)
+    kind = torch.full((Na, 5), 255, dtype=torch.int64, device=DEV)          # what wsel would say if part p won
+    pair_of = torch.full((Na, 5), -1, dtype=torch.int64, device=DEV)
+    fl = v['pflags'][:Na].to(torch.int64)
+    ff = v['farflags'][:Na].to(torch.int64)
+    worst_occ = 0.0
+    for p in range(5):
+        n = cnt[p]
+        x = v['l_x'][p][:, :n].t().contiguous()
+        d = v['l_d'][p][:, :n].t().contiguous()
+        raw = torch.empty(n, 4, device=DEV)
+        nb = L.invr_part_field_workspace(n)
+        ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+        _abi.check(L.invr_part_field_fwd(C.byref(model), p, _abi.ptr(li, torch.int64), _abi.ptr(x), _abi.ptr(d), n,
+                                         _abi.ptr(raw), C.c_void_p(ws.data_ptr()), nb, _abi.stream_ptr()))
+        fields.append(raw)
+        occp = v['occp'][p][:n]
+        worst_occ = max(worst_occ, float((raw[:, 3] - occp).abs().max()))
+        slots = v['l_slot'][p][:n].long()
+        assert int(slots[-1]) == cap                                         # the far-constant pair closes the list
+        real = slots[:-1]
+        cand[real, p] = occp[:-1]
+        kind[real, p] = p
+        pair_of[real, p] = torch.arange(n - 1, device=DEV)
+        far = ((ff >> p) & 1).bool()
+        assert not bool((far & ((fl >> p) & 1).bool()).any())
+        cand[far, p] = occp[-1]
+        kind[far, p] = 8 + p
+    assert worst_occ <= 1e-6, worst_occ
+    # the merge rule: start from part 0 whatever it is, a later part only takes over with a strictly larger occupancy
+    best = cand[:, 0].clone()
+    bsel = kind[:, 0].clone()
+    bpair = pair_of[:, 0].clone()
+    bpart = torch.zeros(Na, dtype=torch.int64, device=DEV)
+    for p in range(1, 5):
+        take = cand[:, p] > best
+        best = torch.where(take, cand[:, p], best)
+        bsel = torch.where(take, kind[:, p], bsel)
+        bpair = torch.where(take, pair_of[:, p], bpair)
+        bpart = torch.where(take, torch.full_like(bpart, p), bpart)
+    wsel = v['wsel'][:Na].to(torch.int64)
+    assert torch.equal(wsel, bsel), int((wsel != bsel).sum())
+    listed = bsel < 5
+    assert int(listed.sum()) > Na // 2
+    # winner lists, segment by segment
+    g_last = (max(Na, 1) - 1) // 4096
+    wcnt = v['wcnt'][:g_last + 1].to(torch.int64)
+    worst_rgb = 0.0
+    for p in range(5):
+        slots = v['l_slot'][p][:cnt[p]].long()
+        real = slots[:-1]
+        # list offset of every group = pairs of the groups before it
+        per_group = torch.bincount(real // 4096, minlength=g_last + 1)
+        off = torch.cumsum(per_group, 0) - per_group
+        want = (listed & (bpart == p)).nonzero(as_tuple=True)[0]             # winning survivors of part p, ascending
+        want_pairs = bpair[want]
+        want_per_group = torch.bincount(want // 4096, minlength=g_last + 1)
+        exp_cnt = want_per_group.clone()
+        exp_cnt[g_last] += 1                                                 # + the far-constant pair
+        assert torch.equal(wcnt[:, p], exp_cnt), p
+        # gather the lists' entries: positions off[g] + [0, wcnt[g][p])
+        gidx = torch.repeat_interleave(torch.arange(g_last + 1, device=DEV), wcnt[:, p])
+        start = torch.cumsum(wcnt[:, p], 0) - wcnt[:, p]
+        pos = off[gidx] + (torch.arange(gidx.numel(), device=DEV) - start[gidx])
+        got = v['wl'][p][pos].long()
+        assert int(got[-1]) == cnt[p] - 1                                    # the constant pair, last entry of the last segment
+        assert torch.equal(got[:-1], want_pairs), p
+        # colour of the winners
+        rw = v['rgbw'][want]
+        ref = fields[p][want_pairs]
+        if want.numel():
+            worst_rgb = max(worst_rgb, float((rw - ref).abs().max()))
+        worst_rgb = max(worst_rgb, float((v['rgbw'][lc + p] - fields[p][-1]).abs().max()))     # far constant of the part
+    print('pose %d: %d survivors, %d listed winners; max |occp - field occ| %.1e, max |rgbw - field raw| %.1e'
+          % (f['k'], Na, int(listed.sum()), worst_occ, worst_rgb))
+    assert worst_rgb <= 1e-6, worst_rgb
