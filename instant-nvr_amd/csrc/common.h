@@ -287,6 +287,25 @@ __device__ __forceinline__ uint32_t hash_mod24(uint64_t x, int k, uint32_t c, ui
     return (uint32_t)v;
 }
 
+// ---- wave scans on the DPP network ------------------------------------------------------------------------------------------
+// Inclusive prefix sum over the 64 lanes: row_shr 1 / 2 / 4 / 8 inside the 16-lane rows, then row_bcast:15 / row_bcast:31 across
+// rows (the sequence LLVM's own wave scans use on gfx9) — six full-rate VALU instructions.  __shfl_up compiles to ds_bpermute_b32:
+// an LDS round trip per step, which is what the short list kernels (dependent chains of a few dozen steps) spent their time on.
+// ALL 64 lanes must be active.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i(int identity, int x) {
+    return __builtin_amdgcn_update_dpp(identity, x, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ int wave_incl_sum_i(int x) {
+    x += dpp_i<0x111, 0xF>(0, x);
+    x += dpp_i<0x112, 0xF>(0, x);
+    x += dpp_i<0x114, 0xF>(0, x);
+    x += dpp_i<0x118, 0xF>(0, x);
+    x += dpp_i<0x142, 0xA>(0, x);
+    x += dpp_i<0x143, 0xC>(0, x);
+    return x;
+}
+
 // ---- kernel launchers (defined in the .hip files) ---------------------------------------------
 int launch_grid_encode_generic(const GridDev& g, const float* xyz, int64_t n, float* out, hipStream_t st);
 int launch_grid_encode_bwd_generic(const GridDev& g, const float* xyz, const float* gout, int64_t n, float* g_dense,

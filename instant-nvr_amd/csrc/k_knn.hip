@@ -770,9 +770,7 @@ __global__ __launch_bounds__(PL_BLOCK) void k_pair_lists(Workspace w, int32_t* _
 #pragma unroll
         for (int p = 0; p < INVR_NUM_PARTS; ++p) {
             const int mine = __popcll(fb & (0x0101010101010101ull << p));
-            int x = mine;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d); if (lane >= d) x += y; }
+            const int x = wave_incl_sum_i(mine);
             pre[p] = x - mine;
             if (lane == 63) s_cnt[wv][p] = x;
         }

@@ -341,9 +341,7 @@ __global__ __launch_bounds__(WL_BLOCK) void k_winner_lists(Workspace w) {
 #pragma unroll
         for (int p = 0; p < INVR_NUM_PARTS; ++p) {
             const int mine = __popcll(fb & (0x0101010101010101ull << p));
-            int x = mine;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d); if (lane >= d) x += y; }
+            const int x = wave_incl_sum_i(mine);
             pos[p] = x - mine;
             if (lane == 63) s_cnt[wv][p] = x;
         }
@@ -396,9 +394,7 @@ __global__ __launch_bounds__(WL_BLOCK) void k_winner_lists(Workspace w) {
 #pragma unroll
         for (int p = 0; p < INVR_NUM_PARTS; ++p) {
             const int mine = __popcll(wb & (0x0101010101010101ull << p));
-            int x = mine;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d); if (lane >= d) x += y; }
+            const int x = wave_incl_sum_i(mine);
             wpos[p] = x - mine;
             if (lane == 63) s_cnt[wv][p] = x;
         }
@@ -438,12 +434,7 @@ __device__ __forceinline__ void seg_window(SegCursor& c, const int32_t* __restri
     c.wc = ok ? wcnt[(int64_t)gi * INVR_NUM_PARTS + part] : 0;
     const int gc = ok ? gcount[(int64_t)gi * INVR_NUM_PARTS + part] : 0;
     c.tl = (c.wc + 31) >> 5;
-    int x = c.tl, y = gc;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int x2 = __shfl_up(x, d), y2 = __shfl_up(y, d);
-        if (lane >= d) { x += x2; y += y2; }
-    }
+    const int x = wave_incl_sum_i(c.tl), y = wave_incl_sum_i(gc);
     c.ti = x; c.pe = y - gc;
     c.win_tiles = __shfl(x, 63); c.win_pairs = __shfl(y, 63);
 }
