@@ -750,7 +750,7 @@ __global__ __launch_bounds__(PL_BLOCK) void k_pair_lists(Workspace w, int32_t* _
             for (int p = 0; p < INVR_NUM_PARTS; ++p) acc[p] += w.gcount[q * INVR_NUM_PARTS + p];
 #pragma unroll
         for (int p = 0; p < INVR_NUM_PARTS; ++p) {
-            for (int d = 32; d >= 1; d >>= 1) acc[p] += __shfl_xor(acc[p], d);
+            acc[p] = __builtin_amdgcn_readlane(wave_incl_sum_i(acc[p]), 63);
             if (lane == 0) s_red[wv][p] = acc[p];
         }
         __syncthreads();

@@ -315,7 +315,7 @@ __global__ __launch_bounds__(WL_BLOCK) void k_winner_lists(Workspace w) {
             for (int p = 0; p < INVR_NUM_PARTS; ++p) acc[p] += w.gcount[q * INVR_NUM_PARTS + p];
 #pragma unroll
         for (int p = 0; p < INVR_NUM_PARTS; ++p) {
-            for (int d = 32; d >= 1; d >>= 1) acc[p] += __shfl_xor(acc[p], d);
+            acc[p] = __builtin_amdgcn_readlane(wave_incl_sum_i(acc[p]), 63);
             if (lane == 0) s_red[wv][p] = acc[p];
         }
         __syncthreads();
@@ -565,7 +565,7 @@ __global__ __launch_bounds__(MLP_BLOCK, RGB_WPS) void k_part_rgb_all(MlpAllArgs 
             for (int p = 0; p < INVR_NUM_PARTS; ++p) acc[p] += (a.wcnt[(int64_t)q * INVR_NUM_PARTS + p] + 31) >> 5;
 #pragma unroll
         for (int p = 0; p < INVR_NUM_PARTS; ++p) {
-            for (int d = 32; d >= 1; d >>= 1) acc[p] += __shfl_xor(acc[p], d);
+            acc[p] = __builtin_amdgcn_readlane(wave_incl_sum_i(acc[p]), 63);
             if (lane == 0 && acc[p]) atomicAdd(&s_tot[p], acc[p]);
         }
     }
