@@ -74,3 +74,56 @@ def test_pair_list_offsets_give_ascending_dense_lists():
         for p in range(P):
             want = np.nonzero((flags >> p) & 1)[0]
             assert np.array_equal(lists[p][:-1], want)            # dense, ascending, every flagged slot once
+
+
+# ---- round 3: the colour kernel's segment cursor (csrc/k_mlp.hip: seg_window / seg_locate / rgb_part) ----------------------------
+def rgb_tiles_by_cursor(wcnt, gcount, n_waves):
+    """Mirror of k_part_rgb_all for ONE part: the winners of slot group g sit at list positions [pairs before g, + wcnt[g]); a
+    wave's unit is a tile of 32 winners of one segment; tile T -> (segment, offset) through a cursor over windows of 64
+    segments with inclusive tile / exclusive pair prefix sums.  -> [(list position, valid) x 32] per tile, in tile order, as the
+    waves (T = wave, wave + n_waves, ...) produce them."""
+    g_last = len(wcnt) - 1
+    total = sum((c + 31) >> 5 for c in wcnt)
+    out = {}
+    for w in range(n_waves):
+        g0, tiles_before, pairs_before = 0, 0, 0
+
+        def window(g0):
+            wc = [wcnt[g] if g <= g_last else 0 for g in range(g0, g0 + 64)]
+            gc = [gcount[g] if g <= g_last else 0 for g in range(g0, g0 + 64)]
+            tl = [(c + 31) >> 5 for c in wc]
+            ti = list(np.cumsum(tl))
+            pe = list(np.cumsum(gc) - np.array(gc))
+            return wc, tl, ti, pe, int(ti[-1]), int(sum(gc))
+        wc, tl, ti, pe, win_tiles, win_pairs = window(g0)
+        for T in range(w, total, n_waves):
+            while T >= tiles_before + win_tiles and g0 + 64 <= g_last:
+                tiles_before += win_tiles
+                pairs_before += win_pairs
+                g0 += 64
+                wc, tl, ti, pe, win_tiles, win_pairs = window(g0)
+            L = next(l for l in range(64) if tiles_before + ti[l] > T)
+            t0, sb, sn = tiles_before + ti[L] - tl[L], pairs_before + pe[L], wc[L]
+            cols = []
+            for j in range((T - t0) * 32, (T - t0) * 32 + 32):
+                cols.append((sb + min(j, sn - 1), j < sn))
+            out[T] = cols
+    return [out[T] for T in range(total)]
+
+
+def test_colour_kernel_segment_cursor_visits_every_winner_once():
+    rng = np.random.default_rng(3)
+    for n_groups, n_waves in ((1, 4), (3, 7), (64, 12), (65, 5), (130, 3072), (584, 3072), (700, 33)):
+        gcount = rng.integers(0, 4097, n_groups)
+        wcnt = np.array([int(rng.integers(0, g + 1)) if rng.random() > 0.15 else 0 for g in gcount])
+        wcnt[-1] += 1                                            # the far-constant pair rides in the last segment
+        off = np.cumsum(gcount) - gcount
+        want = [int(off[g]) + r for g in range(n_groups) for r in range(int(wcnt[g]))]
+        tiles = rgb_tiles_by_cursor([int(x) for x in wcnt], [int(x) for x in gcount], n_waves)
+        got = [pos for cols in tiles for pos, valid in cols if valid]
+        assert got == want, (n_groups, n_waves)
+        # invalid columns re-read a winner of the SAME segment (a valid address, its result is not stored)
+        for cols in tiles:
+            seg_lo = min(pos for pos, _ in cols)
+            assert all(seg_lo <= pos <= seg_lo + 31 for pos, _ in cols)
+        assert len(tiles) == sum((int(c) + 31) >> 5 for c in wcnt)
