@@ -221,6 +221,7 @@ static size_t carve(Workspace& w, void* base, int64_t N, int64_t cap) {
     w.mask = c.take<unsigned long long>(nb * 16);
     w.block_cnt = c.take<int32_t>(nb);
     w.block_off = c.take<int32_t>(nb);
+    w.super_tot = c.take<int32_t>(cdiv(nb, 1024) + 1);
     w.active_idx = c.take<int32_t>(lc);
     w.word_off = c.take<int32_t>(nb * 16);
     w.pflags = c.take<uint8_t>(lc);

@@ -152,57 +152,39 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_cull_flag(RenderArgs a, Workspac
 }
 
 #define SCAN_T 1024
-#define SCAN_PER 8
-__global__ __launch_bounds__(SCAN_T) void k_scan_blocks(Workspace w, int64_t nb, int64_t max_active) {
+// Exclusive scan of the per-tile survivor counts in two levels WITHOUT a second pass or any inter-workgroup hand-shake: one workgroup
+// per SCAN_T tiles writes the prefix inside its super-block (block_off) and the super-block's total (super_tot); k_compact adds the
+// totals of the super-blocks before its own (<= 32 wave-uniform scalar loads for the 32 k tiles of a 512x512x128 frame) and its
+// first workgroup publishes the survivor count.  (One workgroup scanning all counts in passes of 8192 took 31 us per frame.)
+__global__ __launch_bounds__(SCAN_T) void k_scan_blocks(Workspace w, int64_t nb) {
     __shared__ int wsum[SCAN_T / 64];
-    __shared__ int carry_s;
-    if (threadIdx.x == 0) carry_s = 0;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * SCAN_T + threadIdx.x;
+    const int v = i < nb ? w.block_cnt[i] : 0;
+    const int x = wave_incl_sum_i(v);
+    if (lane == 63) wsum[wv] = x;
     __syncthreads();
-    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int64_t base = 0; base < nb; base += SCAN_T * SCAN_PER) {
-        int64_t i0 = base + (int64_t)threadIdx.x * SCAN_PER;
-        int v[SCAN_PER];
-        int tot = 0;
-#pragma unroll
-        for (int k = 0; k < SCAN_PER; ++k) {
-            v[k] = (i0 + k < nb) ? w.block_cnt[i0 + k] : 0;
-            tot += v[k];
-        }
-        int x = tot;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            int y = __shfl_up(x, d);
-            if (lane >= d) x += y;
-        }
-        if (lane == 63) wsum[wv] = x;
-        __syncthreads();
-        int woff = 0;
-        for (int k = 0; k < wv; ++k) woff += wsum[k];
-        int carry = carry_s;
-        int run = carry + woff + x - tot;
-#pragma unroll
-        for (int k = 0; k < SCAN_PER; ++k) {
-            if (i0 + k < nb) w.block_off[i0 + k] = run;
-            run += v[k];
-        }
-        __syncthreads();
-        if (threadIdx.x == SCAN_T - 1) carry_s = run;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        int na = carry_s;
-        if ((int64_t)na > max_active) {
-            w.counters[CNT_OVERFLOW] = 1;
-            na = (int)max_active;
-        }
-        w.counters[CNT_ACTIVE] = na;
-    }
+    int woff = 0;
+    for (int k = 0; k < wv; ++k) woff += wsum[k];
+    if (i < nb) w.block_off[i] = woff + x - v;
+    if (threadIdx.x == SCAN_T - 1) w.super_tot[blockIdx.x] = woff + x;
 }
 
 __global__ __launch_bounds__(CULL_BLOCK) void k_compact(RenderArgs a, Workspace w, int64_t max_active) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const unsigned long long* mk = w.mask + (int64_t)blockIdx.x * (CULL_TILE / 64);
     int off = w.block_off[blockIdx.x];
+    for (int64_t j = 0; j < (int64_t)(blockIdx.x / SCAN_T); ++j) off += w.super_tot[j];          // (wave-uniform: scalar loads)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // the survivor count = the total over all super-blocks; clamped to the workspace capacity (overflow is reported, never written)
+        int64_t na = 0;
+        for (int64_t j = 0; j < ((int64_t)gridDim.x + SCAN_T - 1) / SCAN_T; ++j) na += w.super_tot[j];
+        if (na > max_active) {
+            w.counters[CNT_OVERFLOW] = 1;
+            na = max_active;
+        }
+        w.counters[CNT_ACTIVE] = (int)na;
+    }
 #pragma unroll
     for (int k = 0; k < CULL_PER; ++k) {
         const int64_t i = (int64_t)blockIdx.x * CULL_TILE + k * CULL_BLOCK + threadIdx.x;
@@ -243,7 +225,7 @@ int launch_cull(const RenderArgs& a, const Workspace& w, int64_t max_active, boo
         hipLaunchKernelGGL((k_cull_flag<false, false>), dim3((unsigned)nb), dim3(CULL_BLOCK), 0, st, a, w, inv_S, lin_step);
     }
     INVR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(SCAN_T), 0, st, w, nb, max_active);
+    hipLaunchKernelGGL(k_scan_blocks, dim3((unsigned)cdiv(nb, SCAN_T)), dim3(SCAN_T), 0, st, w, nb);
     INVR_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_compact, dim3((unsigned)nb), dim3(CULL_BLOCK), 0, st, a, w, max_active);
     INVR_LAUNCH_CHECK();
