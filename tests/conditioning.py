@@ -3,12 +3,12 @@
 Band / far pairs land far outside a part's box and are EXTRAPOLATED by the encoder with trilinear weights of 1e3..1e9 (DESIGN.md
 §3): a one-ulp difference anywhere upstream moves such a pixel by 1e-4 and more — in the reference's own fp32 run as much as in the
 kernels.  One fp32 run of the oracle is a single noisy sample of that (and changes with the host's thread count); so the noise scale of
-a pixel is estimated as the largest move of the FLOAT64 result under several independent fp32-ulp-sized random perturbations of the
+a pixel is estimated as the largest move of the FLOAT64 result under several (default 4) independent fp32-ulp-sized random perturbations of the
 rays, together with the deviation of the oracle's fp32 run.  Checker only."""
 import torch
 
 
-def pixel_noise(O, model64, b64, exact, n_samples, chunk=64, ref32=None, trials=6, seed=0):
+def pixel_noise(O, model64, b64, exact, n_samples, chunk=64, ref32=None, trials=4, seed=0):
     """exact: (n,3) float64 rgb_map of the unperturbed float64 run -> (n,) noise scale per pixel."""
     g = torch.Generator().manual_seed(1000 + seed)
     noise = torch.zeros(exact.shape[0], dtype=torch.float64)

@@ -30,7 +30,7 @@ from invr import _abi, scene, stages        # noqa: E402
 DEV = 'cuda:0'
 S = 128
 WELL_FLOOR = 0.90        # least fraction of the 256 sampled pixels per pose that must be well conditioned and meet the plain 1e-4 bar
-                         # (measured: 240-256 of 256 at the four poses with the 6-trial noise estimate of tests/conditioning.py; printed)
+                         # (measured: 240-256 of 256 at the four poses with the multi-trial noise estimate of tests/conditioning.py; printed)
 POSES = [dict(seed=0, pose_scale=0.5, frame=3, cam_dist=1.8, thresh=0.05),
          dict(seed=1, pose_scale=1.0, frame=17, cam_dist=1.8, thresh=0.05),
          dict(seed=2, pose_scale=1.2, frame=60, cam_dist=2.2, thresh=0.1),          # inb_lan.yaml smpl_thresh
