@@ -174,16 +174,27 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_compact(RenderArgs a, Workspace 
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const unsigned long long* mk = w.mask + (int64_t)blockIdx.x * (CULL_TILE / 64);
     int off = w.block_off[blockIdx.x];
-    for (int64_t j = 0; j < (int64_t)(blockIdx.x / SCAN_T); ++j) off += w.super_tot[j];          // (wave-uniform: scalar loads)
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    {   // + the totals of the super-blocks before this tile's: one load per lane, summed over the wave on the DPP network
+        const int64_t sb = (int64_t)(blockIdx.x / SCAN_T);
+        int add = 0;
+        for (int64_t j0 = 0; j0 < sb; j0 += 64) add += (j0 + lane < sb) ? w.super_tot[j0 + lane] : 0;
+        off += __builtin_amdgcn_readlane(wave_incl_sum_i(add), 63);
+    }
+    if (blockIdx.x == 0 && wv == 0) {
         // the survivor count = the total over all super-blocks; clamped to the workspace capacity (overflow is reported, never written)
+        const int64_t ns = ((int64_t)gridDim.x + SCAN_T - 1) / SCAN_T;
         int64_t na = 0;
-        for (int64_t j = 0; j < ((int64_t)gridDim.x + SCAN_T - 1) / SCAN_T; ++j) na += w.super_tot[j];
-        if (na > max_active) {
-            w.counters[CNT_OVERFLOW] = 1;
-            na = max_active;
+        for (int64_t j0 = 0; j0 < ns; j0 += 64) {
+            const int t = (j0 + lane < ns) ? w.super_tot[j0 + lane] : 0;
+            na += __builtin_amdgcn_readlane(wave_incl_sum_i(t), 63);
         }
-        w.counters[CNT_ACTIVE] = (int)na;
+        if (lane == 0) {
+            if (na > max_active) {
+                w.counters[CNT_OVERFLOW] = 1;
+                na = max_active;
+            }
+            w.counters[CNT_ACTIVE] = (int)na;
+        }
     }
 #pragma unroll
     for (int k = 0; k < CULL_PER; ++k) {
