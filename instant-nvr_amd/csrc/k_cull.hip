@@ -3,8 +3,8 @@
 // inb_part_network_multiassign.py:128-140 (world->pose, pnorm < smpl_thresh, nonzero, gathers)
 // without the host-syncing nonzero: three stream-ordered launches
 //   k_cull_flag   : one thread per ray-sample -> 64-bit survivor mask per wave + per-block count
-//   k_scan_blocks : exclusive scan of the block counts (one workgroup, 8192 counts per pass)
-//   k_compact     : rank = block offset + wave prefix + popcount(mask below lane) -> active list
+//   k_scan_blocks : exclusive scan of the tile counts inside super-blocks of 1024 tiles + the super-blocks' totals
+//   k_compact     : rank = totals of the super-blocks before + tile offset + wave prefix + popcount(mask below lane) -> active list
 // The active list is in ray-major / sample-minor order, exactly the order torch.nonzero gives,
 // so the train-time (Na*P, .) layouts of resd/tpts/tocc keep the reference's row order.
 #include <stdlib.h>
