@@ -12,9 +12,16 @@ ranks tile-cyclically, every rank renders its tiles with a full model replica an
 all-gather assembles [r,g,b,acc]; total work is fixed -> "scaling": "strong".
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with these extra objects:
-  roofline      — the dominant roofline-bound kernel (k_part_mlp_all, fp32 MFMA): algorithmic FLOPs
-                  (SURVEY.md §8d per pair) / its HIP-event time, vs 157.3 TFLOP/s; roofline_other: KNN, encoder
-  path_roofline — the WHOLE frame against SURVEY §8d's byte model (HBM), with the PMC-measured traffic per frame
+  roofline      — the dominant roofline-bound stage: the part MLPs on the fp32 matrix cores (k_part_occ_all + k_winner_lists +
+                  k_part_rgb_all): algorithmic FLOPs = 4.6 k x listed pairs + 17.5 k / 9.3 k x winning pairs (SURVEY.md §8d's 22.1 k /
+                  14.0 k per pair split into its two MLPs) / the stage's HIP-event time, vs 157.3 TFLOP/s; measured HBM bytes and
+                  busy counters of the same command from profiles/ (PMC passes cannot run inside the timed region)
+  roofline_other— the KNN (VALU-issue bound, no roofline fraction) and the encoder (measured bytes primary, the byte model secondary)
+  path_roofline — the WHOLE frame: measured HBM / Infinity-Cache bytes per frame primary, SURVEY §8d's byte model labelled secondary
+  shard_projection, samples_64, full_rows, dense_stress, api_frame — variants of the headline frame (N=1 only): rank 0's shard of a
+                  W-way split (W = 1, 2, 4, 8) on this one GPU, the yaml-default 64 samples/ray, the 64-byte-row encoder, the dense
+                  stress frame (every sample survives), and the wall clock of Renderer.render(batch) with and without the reference's
+                  move-everything-to-the-host contract
   cpu_baseline  — the oracle (CPU PyTorch port of the reference path) timed on the host cores on a
                   bounded sample of the same workload (N=1 only): one 4096-ray chunk + BASELINE configs[0]
   train_step    — informational: a few configs[4]-shaped training iterations (N=1 only)
