@@ -127,3 +127,50 @@ def test_colour_kernel_segment_cursor_visits_every_winner_once():
             seg_lo = min(pos for pos, _ in cols)
             assert all(seg_lo <= pos <= seg_lo + 31 for pos, _ in cols)
         assert len(tiles) == sum((int(c) + 31) >> 5 for c in wcnt)
+
+
+# ---- round 3: the merge rule of k_winner_lists against the oracle's merge (inb_part_network_multiassign.py:229-256) --------------
+def wsel_mirror(occ, listed, far, occ_const):
+    """csrc/k_mlp.hip:k_winner_lists per survivor: candidates = listed occupancy / the part's far constant / 0 for an unflagged part;
+    start from part 0 whatever it is, a later part takes over only with a strictly larger occupancy.
+    -> sel: p (listed pair of part p), 8 + p (far constant of part p), 255 (zeros)."""
+    n = occ.shape[0]
+    sel = np.full(n, 255, np.int64)
+    best = np.zeros(n, np.float32)
+    for p in range(5):
+        c = np.where(listed[:, p], occ[:, p], np.where(far[:, p], occ_const[p], np.float32(0.0))).astype(np.float32)
+        s = np.where(listed[:, p], p, np.where(far[:, p], 8 + p, 255))
+        take = np.ones(n, bool) if p == 0 else c > best
+        best = np.where(take, c, best)
+        sel = np.where(take, s, sel)
+    return sel
+
+
+def test_winner_rule_equals_the_oracles_merge():
+    import torch
+    from oracle import nvr_oracle as O          # checker only
+    rng = np.random.default_rng(11)
+    n = 20000
+    occ = rng.random((n, 5)).astype(np.float32)
+    occ[rng.random((n, 5)) < 0.15] = 0.0                                     # exact zeros and
+    occ[:, 3] = np.where(rng.random(n) < 0.3, occ[:, 1], occ[:, 3])          # exact ties between parts
+    rgb = rng.random((n, 5, 3)).astype(np.float32)
+    kind = rng.integers(0, 3, (n, 5))                                         # 0 unflagged, 1 listed, 2 far
+    listed, far = kind == 1, kind == 2
+    occ_const = rng.random(5).astype(np.float32)
+    rgb_const = rng.random((5, 3)).astype(np.float32)
+    # the dense (N, 5, 4) tensor the reference merges: zeros for unflagged parts (:199-200,229-233), the part constant for far pairs
+    raws = np.zeros((n, 5, 4), np.float32)
+    raws[..., :3] = np.where(listed[..., None], rgb, np.where(far[..., None], rgb_const[None], 0.0))
+    raws[..., 3] = np.where(listed, occ, np.where(far, occ_const[None], 0.0))
+    want_raw, want_occ = O.merge_parts(torch.from_numpy(raws))
+    sel = wsel_mirror(occ, listed, far, occ_const)
+    got = np.zeros((n, 4), np.float32)
+    for p in range(5):
+        m = sel == p
+        got[m, :3], got[m, 3] = rgb[m, p], occ[m, p]
+        m = sel == 8 + p
+        got[m, :3], got[m, 3] = rgb_const[p], occ_const[p]
+    assert np.array_equal(got, want_raw.numpy())
+    assert np.array_equal(got[:, 3], want_occ.numpy().reshape(-1))
+    assert (sel == 255).sum() > 100 and (sel < 5).sum() > 1000 and ((sel >= 8) & (sel < 16)).sum() > 1000
