@@ -174,3 +174,28 @@ def test_winner_rule_equals_the_oracles_merge():
     assert np.array_equal(got, want_raw.numpy())
     assert np.array_equal(got[:, 3], want_occ.numpy().reshape(-1))
     assert (sel == 255).sum() > 100 and (sel < 5).sum() > 1000 and ((sel >= 8) & (sel < 16)).sum() > 1000
+
+
+# ---- round 3: the x-corner rows of a hashed level by a +-delta fold (csrc/k_encode.hip: level_rowsum, GridDev.xdelta) -------------
+def test_hashed_x_corner_delta_fold_equals_the_direct_hash():
+    """hash(cx, cy, cz) = (cx * 1) ^ (cy * 19349663) ^ (cz * 83492791) mod T (part_base_embedder.py:132-136).  x's prime is 1, so the
+    key of the c1x corner is the c0x corner's key X with the bits m = c0x ^ c1x flipped: X ^ m = X + m - 2 (X & m); its residue is
+    the c0x corner's + that delta, folded once into [0, T) — for every cell a level can have (res <= 8192) and every table size in
+    use (T = nextprime(2^k) > 2^14)."""
+    P1, P2 = 19349663, 83492791
+    rng = np.random.default_rng(21)
+    for T in (32771, 262147, 1048583):
+        for res in (23, 250, 1291, 2004, 8192):
+            c0x = rng.integers(0, res, 4000)
+            d = rng.choice([0, 1, 1, 1, 2], 4000)                      # clipped / regular / the f + 1 rounding case (:116)
+            c1x = np.minimum(c0x + d, res - 1)
+            cy, cz = rng.integers(0, res, 4000), rng.integers(0, res, 4000)
+            X = c0x.astype(object) ^ (cy.astype(object) * P1) ^ (cz.astype(object) * P2)
+            r0 = np.array([int(v) % T for v in X], dtype=np.int64)
+            want = np.array([int((int(a) ^ (int(b) * P1) ^ (int(c) * P2)) % T) for a, b, c in zip(c1x, cy, cz)], dtype=np.int64)
+            m = (c0x ^ c1x).astype(np.int64)
+            xlo = np.array([int(v) & 0xFFFFFFFF for v in X], dtype=np.int64)
+            r1 = r0 + m - 2 * (xlo & m)
+            r1 = np.where(r1 < 0, r1 + T, r1)
+            r1 = np.where(r1 >= T, r1 - T, r1)
+            assert np.array_equal(r1, want), (T, res)
