@@ -83,7 +83,8 @@ def sample_volume(vol, bounds, pts, c0, nc):
     dims = (C.c_int32 * 3)(*vol.shape[:3])
     pts = pts.detach().to(torch.float32).contiguous()
     out = torch.empty(pts.shape[0], nc, device=pts.device)
-    _abi.check(_abi.lib().invr_sample_volume(_abi.ptr(vol), dims, vol.shape[3], c0, nc, _abi.ptr(bounds.contiguous()),
+    bounds = bounds.contiguous()                       # held in a name: the pointer must outlive the call
+    _abi.check(_abi.lib().invr_sample_volume(_abi.ptr(vol), dims, vol.shape[3], c0, nc, _abi.ptr(bounds),
                                              _abi.ptr(pts), pts.shape[0], _abi.ptr(out), _abi.stream_ptr()))
     return out
 

@@ -315,7 +315,9 @@ __device__ __forceinline__ void encode_rows_part(const GridDev& g, const float* 
                 semb[wv][3 + level][j1] = sb;
             }
         }
-        // flush [k][point] rows, coalesced (wave-private LDS region: no workgroup barrier needed)
+        // flush [k][point] rows, coalesced.  The LDS region is private to the wave: no workgroup barrier is needed, the lanes of a
+        // wave run in lockstep — stated to the compiler as a wave barrier (no instruction; orders the stores above before the loads)
+        __builtin_amdgcn_wave_barrier();
         if (lane < m) {
 #pragma unroll
             for (int k = 0; k < EMB_K; ++k) emb[(int64_t)k * cap + base + lane] = semb[wv][k][lane];

@@ -94,7 +94,8 @@ class FusedAdam(torch.optim.Optimizer):
                         assert (1 << shift) == e.f
                 if g is None:
                     continue
-                assert p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and not g.is_sparse
+                _abi.ptr(p)                                               # (the binding's checks: device tensor, float32, contiguous)
+                assert not g.is_sparse
                 out.append((p, group, g if g.is_contiguous() else g.contiguous(), shift))
         return out, betas, eps
 

@@ -26,8 +26,9 @@ def pack_parts(ppts, weights, parts, tpose, bbox_overlap=0.2):
     part_pbw = torch.empty(NUM_PARTS, V, W, device=dev)
     lengths2 = torch.empty(NUM_PARTS, dtype=torch.int64, device=dev)
     bounds = torch.empty(NUM_PARTS, 2, 3, device=dev)
-    _abi.check(_abi.lib().invr_pack_parts(_abi.ptr(f(ppts)), _abi.ptr(f(weights)), _abi.ptr(parts.to(torch.int64).contiguous(), torch.int64),
-                                          _abi.ptr(f(tpose)), V, W, V, float(bbox_overlap), _abi.ptr(part_pts), _abi.ptr(part_pbw),
+    ppts, weights, tpose, parts = f(ppts), f(weights), f(tpose), parts.to(torch.int64).contiguous()      # held: pointers outlive the call
+    _abi.check(_abi.lib().invr_pack_parts(_abi.ptr(ppts), _abi.ptr(weights), _abi.ptr(parts, torch.int64),
+                                          _abi.ptr(tpose), V, W, V, float(bbox_overlap), _abi.ptr(part_pts), _abi.ptr(part_pbw),
                                           _abi.ptr(lengths2, torch.int64), _abi.ptr(bounds), _abi.stream_ptr()))
     M = int(lengths2.max())                                   # max_length trim (:591-593), one host sync as in NumPy
     return part_pts[:, :M].contiguous(), part_pbw[:, :M].contiguous(), lengths2, bounds

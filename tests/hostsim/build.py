@@ -1,0 +1,100 @@
+"""TEST INFRASTRUCTURE — builds tests/hostsim/_build/libinvr_hostsim.so: the kernel sources of instant-nvr_amd/csrc compiled for the
+HOST against tests/hostsim/hip/hip_runtime.h (a wave machine on fibers, see README.md) so that CPU-only tests can run the very
+kernel code of the product at toy sizes.  The sources are used as they are, except for three device-only constructs that have no
+host spelling and are rewritten on the fly (the csrc tree stays free of host-simulation conditionals):
+  * `extern __shared__ T name[];`                 -> a pointer to the simulated dynamic LDS
+  * the v_min_f64 / v_max_f64 inline assembly      -> fmin / fmax (the keys are finite non-negative doubles, k_knn.hip:68-72)
+  * the empty `asm volatile("" : "+v"...)` fences  -> dropped
+Nothing under instant-nvr_amd/ imports this module or loads its output."""
+import concurrent.futures as cf
+import hashlib
+import os
+import re
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, 'instant-nvr_amd', 'csrc')
+OUT = os.path.join(HERE, '_build')
+LIB = os.path.join(OUT, 'libinvr_hostsim.so')
+CXX = os.environ.get('HOSTSIM_CXX') or '/opt/rocm/lib/llvm/bin/clang++'
+FLAGS = ['-x', 'c++', '-std=c++17', '-O1', '-g0', '-fPIC', '-fno-strict-aliasing', '-ffp-contract=off', '-mfma', '-mavx2',
+         '-Wno-unused-function', '-Wno-unused-value', '-Wno-unknown-pragmas', '-Wno-pass-failed',
+         '-I', HERE, '-I', CSRC]
+
+REWRITES = [
+    (re.compile(r'extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?(\w+)\s+(\w+)\[\];'),
+     r'\1* \2 = reinterpret_cast<\1*>(hostsim::dyn_lds());'),
+    (re.compile(r'asm\("v_min_f64 %0, %1, %2" : "=v"\((\w+)\) : "v"\((\w+)\), "v"\((\w+)\)\);'), r'\1 = fmin(\2, \3);'),
+    (re.compile(r'asm\("v_max_f64 %0, %1, %2" : "=v"\((\w+)\) : "v"\((\w+)\), "v"\((\w+)\)\);'), r'\1 = fmax(\2, \3);'),
+    (re.compile(r'asm volatile\("" : [^;]*\);'), r''),
+]
+
+
+def transform(text, name):
+    for rx, rep in REWRITES:
+        text = rx.sub(rep, text)
+    code = re.sub(r'//[^\n]*', '', text)
+    if re.search(r'\basm\b', code) or 'extern __shared__' in code:
+        raise RuntimeError('hostsim/build.py: %s holds a device-only construct without a rewrite rule' % name)
+    return text
+
+
+def sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith('.hip'))
+
+
+def digest():
+    h = hashlib.sha256()
+    for d, names in ((CSRC, sorted(os.listdir(CSRC))), (HERE, ['build.py', 'hostsim_rt.cpp', os.path.join('hip', 'hip_runtime.h')]),
+                     (os.path.join(ROOT, 'include'), ['invr.h'])):
+        for n in names:
+            p = os.path.join(d, n)
+            if os.path.isfile(p) and not n.endswith(('.so', '.o')):
+                h.update(n.encode())
+                h.update(open(p, 'rb').read())
+    h.update(' '.join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def _compile(job):
+    src, obj, extra = job
+    r = subprocess.run([CXX] + FLAGS + extra + ['-c', src, '-o', obj], capture_output=True, text=True)
+    return src, r.returncode, r.stderr
+
+
+def build(force=False, verbose=False, extra=()):
+    """-> path of the library (built when the sources changed)."""
+    os.makedirs(OUT, exist_ok=True)
+    stamp = os.path.join(OUT, 'digest.txt')
+    dg = digest() + ' ' + ' '.join(extra)
+    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == dg:
+        return LIB
+    jobs = []
+    for f in sources():
+        cpp = os.path.join(OUT, f[:-4] + '.cpp')
+        text = transform(open(os.path.join(CSRC, f)).read(), f)
+        with open(cpp, 'w') as fh:
+            fh.write('#line 1 "%s"\n' % os.path.join(CSRC, f))
+            fh.write(text)
+        jobs.append((cpp, cpp[:-4] + '.o', list(extra)))
+    jobs.append((os.path.join(HERE, 'hostsim_rt.cpp'), os.path.join(OUT, 'hostsim_rt.o'), list(extra)))
+    failed = False
+    with cf.ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        for src, rc, err in ex.map(_compile, jobs):
+            if rc != 0 or (verbose and err):
+                sys.stderr.write('---- %s\n%s\n' % (src, err[-6000:]))
+            failed |= rc != 0
+    if failed:
+        raise RuntimeError('hostsim build failed')
+    r = subprocess.run([CXX, '-shared', '-o', LIB] + list(extra) + [j[1] for j in jobs] + ['-lm'], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError('hostsim link failed:\n' + r.stderr[-4000:])
+    with open(stamp, 'w') as fh:
+        fh.write(dg)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose=True))

@@ -20,7 +20,7 @@ DEV = 'cuda:0'
 
 
 def cu(x):
-    return (torch.from_numpy(np.ascontiguousarray(x)) if isinstance(x, np.ndarray) else x).to(DEV)
+    return (torch.from_numpy(np.ascontiguousarray(x)) if isinstance(x, np.ndarray) else x).to(DEV, copy=True)
 
 
 @pytest.fixture(scope='module')
@@ -162,7 +162,8 @@ def test_warp_deform(gpu_setup, golden):
     tp = torch.empty(n, 5, 3, device=DEV)
     td = torch.empty(n, 5, 3, device=DEV)
     rs = torch.empty(n, 5, 3, device=DEV)
-    _abi.check(_abi.lib().invr_warp_deform(C.byref(scene), C.byref(model), _abi.ptr(ap), _abi.ptr(cu(pd).contiguous()),
+    pdd = cu(pd).contiguous()                                   # (held: a temporary would be freed before the call reads it)
+    _abi.check(_abi.lib().invr_warp_deform(C.byref(scene), C.byref(model), _abi.ptr(ap), _abi.ptr(pdd),
                                            _abi.ptr(bw), _abi.ptr(flag, torch.uint8), n, _abi.ptr(tp), _abi.ptr(td),
                                            _abi.ptr(rs), _abi.stream_ptr()))
     assert maxerr(tp[None], golden['tpose']) < 1e-5
@@ -507,7 +508,7 @@ def test_network_wrapper_lpips_patch_branch(gpu_setup, golden):
     torch.manual_seed(3)
     pl = PerceptualLoss(allow_random=True)                 # built on the CPU: the wrapper moves it to the network's device
     wrap = NetworkWrapper(net, perceptual_loss=pl)
-    assert next(wrap.perceptual_loss.parameters()).device.type == 'cuda'
+    assert next(wrap.perceptual_loss.parameters()).device.type == torch.device(DEV).type
     seen = {}
 
     class Spy(torch.nn.Module):

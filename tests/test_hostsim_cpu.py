@@ -1,0 +1,34 @@
+"""CPU: the kernel SOURCES of instant-nvr_amd/csrc, compiled for the host and executed wave by wave on a fiber machine
+(tests/hostsim/: ballot / shuffle / DPP / readlane / MFMA as rendezvous of the 64 lanes of a wave), run the parity tests of
+tests/test_gpu_parity.py at the golden sizes — the same test bodies, against the same reference goldens and oracle.  What this
+covers that the other CPU tests cannot: the logic of the kernels themselves (index arithmetic, list building, merge rule, wave
+scans, MFMA operand layouts, LDS carving) on a box without a GPU.  What it does not cover: timing, the hardware's transcendental
+pipes (libm here), real concurrency.  Test infrastructure only — the product never loads the host build."""
+import pytest
+import torch
+
+import tests.test_gpu_parity as T
+from tests.hostsim import harness
+from tests.test_gpu_parity import gpu_setup  # noqa: F401  (fixture)
+
+
+@pytest.fixture(scope='module', autouse=True)
+def hostsim():
+    old = T.DEV
+    T.DEV = 'cpu'
+    try:
+        with harness.activate() as counters:
+            yield counters
+            # no kernel read a lane that was not taking part in the operation (readlane / shuffle from a disabled lane)
+            assert counters.anomalies == 0, counters.anomalies
+    finally:
+        T.DEV = old
+
+
+def _export(name):
+    fn = getattr(T, name)
+    globals()['test_hostsim__' + name[5:]] = fn
+
+
+for _n in [n for n in dir(T) if n.startswith('test_')]:
+    _export(_n)
