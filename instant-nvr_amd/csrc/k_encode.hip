@@ -508,11 +508,13 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_part_encode_bwd(GridDev g, EncBwd
             for (int k = 0; k < 8; ++k)
                 if (prow[k] != 0xFFFFFFFFu) flush(prow[k], pval[k]);
         }
+        __builtin_amdgcn_wave_barrier();              // sgx / sgo are private to the wave: lane 0's stores above before the loads below
         if (io.g_xyz && lane < m) {
             io.g_xyz[(base + lane) * io.gx_ps + 0 * io.gx_cs] = (sgx[wv][lane][0] + sgo[wv][lane][0]) / ex;
             io.g_xyz[(base + lane) * io.gx_ps + 1 * io.gx_cs] = (sgx[wv][lane][1] + sgo[wv][lane][1]) / ey;
             io.g_xyz[(base + lane) * io.gx_ps + 2 * io.gx_cs] = (sgx[wv][lane][2] + sgo[wv][lane][2]) / ez;
         }
+        __builtin_amdgcn_wave_barrier();              // ... and those loads before the next tile's stores
     }
     __syncthreads();
     // flush the write-combining cache: one global atomic per touched (level, row)

@@ -32,8 +32,18 @@ REWRITES = [
 ]
 
 
-def transform(text, name):
-    for rx, rep in REWRITES:
+# sanitizer builds only: a poisoned 256-byte red zone behind every array carved out of a caller's workspace (invr_abi.hip: Carver), so
+# that a kernel running over the end of ITS array trips ASan instead of landing in the neighbouring array of the same allocation
+ASAN_REWRITES = [
+    (re.compile(r'(struct Carver \{.*?off \+= n \* sizeof\(T\);)', re.S),
+     r'\1\n        { const size_t rz = off; off = align_up(off, 256) + 256; if ((uintptr_t)base > (1u << 20) && (uintptr_t)base != (uintptr_t(1) << 40)) __asan_poison_memory_region(base + rz, off - rz); }'),
+    (re.compile(r'(\(3 \+ 3 \+ EMB_K\) \* sizeof\(float\) \+ 3 \* 256), 256\);'), r'\1 + 4096, 256);'),      # invr_part_field_workspace: room for them
+    (re.compile(r'(// ---- workspace carve -+)'), r'\1\nextern "C" void __asan_poison_memory_region(void const volatile*, size_t);'),
+]
+
+
+def transform(text, name, asan=False):
+    for rx, rep in REWRITES + (ASAN_REWRITES if asan else []):
         text = rx.sub(rep, text)
     code = re.sub(r'//[^\n]*', '', text)
     if re.search(r'\basm\b', code) or 'extern __shared__' in code:
@@ -74,7 +84,7 @@ def build(force=False, verbose=False, extra=()):
     jobs = []
     for f in sources():
         cpp = os.path.join(OUT, f[:-4] + '.cpp')
-        text = transform(open(os.path.join(CSRC, f)).read(), f)
+        text = transform(open(os.path.join(CSRC, f)).read(), f, asan='-fsanitize=address' in extra)
         with open(cpp, 'w') as fh:
             fh.write('#line 1 "%s"\n' % os.path.join(CSRC, f))
             fh.write(text)

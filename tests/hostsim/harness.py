@@ -22,7 +22,16 @@ def _workspace(self, nbytes, device):
         off = (-raw.data_ptr()) % 256
         self._ws_raw, self._ws = raw, raw[off:off + nbytes]
     self._ws_gen = getattr(self, '_ws_gen', 0) + 1
+    if _ASAN is not None:                                  # sanitizer runs: forget the red zones of the previous call's layout
+        _ASAN.__asan_unpoison_memory_region(C.c_void_p(self._ws.data_ptr()), C.c_size_t(self._ws.numel()))
     return self._ws
+
+
+try:
+    _ASAN = C.CDLL(None)
+    _ASAN.__asan_unpoison_memory_region
+except (OSError, AttributeError):
+    _ASAN = None
 
 
 class Counters:
@@ -41,6 +50,9 @@ class Counters:
 
 @contextlib.contextmanager
 def activate(extra_flags=()):
+    """HOSTSIM_FLAGS in the environment adds compiler flags (tools/hostsim_asan.sh: the sanitizer builds)."""
+    import os
+    extra_flags = tuple(extra_flags) + tuple(os.environ.get('HOSTSIM_FLAGS', '').split())
     from invr import _abi
     from invr.network import Network
     from . import build

@@ -179,10 +179,37 @@ static void resolve(Fiber* w, uint64_t in) {
     }
 }
 
+// HOSTSIM_LANE_ORDER=reverse | shuffle:<seed> runs the lanes of a wave from 63 down to 0 / in a fresh pseudo-random order between
+// rendezvous; HOSTSIM_WAVE_ORDER=reverse | shuffle:<seed> does the same with the waves of a workgroup between barriers.  Results
+// must not depend on either: a kernel whose lanes hand data to each other through memory without a wave-level operation in
+// between, or whose waves do so without __syncthreads, shows up as a difference.
+struct Order {
+    int mode = 0;                                       // 0 ascending, 1 reverse, 2 shuffle
+    uint64_t state = 0;
+    explicit Order(const char* env) {
+        const char* v = getenv(env);
+        if (!v) return;
+        if (!strcmp(v, "reverse")) mode = 1;
+        else if (!strncmp(v, "shuffle:", 8)) { mode = 2; state = 0x9E3779B97F4A7C15ull ^ strtoull(v + 8, nullptr, 10); }
+    }
+    void fill(int* idx, int n) {
+        for (int k = 0; k < n; ++k) idx[k] = mode == 1 ? n - 1 - k : k;
+        if (mode == 2)
+            for (int k = n - 1; k > 0; --k) {
+                state = state * 6364136223846793005ull + 1442695040888963407ull;
+                const int j = (int)((state >> 33) % (uint64_t)(k + 1));
+                const int t = idx[k]; idx[k] = idx[j]; idx[j] = t;
+            }
+    }
+};
+static Order g_lane_order("HOSTSIM_LANE_ORDER"), g_wave_order("HOSTSIM_WAVE_ORDER");
+
 static void run_wave(Fiber* w, int n_lanes) {
     for (;;) {
-        for (int l = 0; l < n_lanes; ++l)
-            if (w[l].state == RUNNABLE) resume(&w[l]);
+        int idx[64];
+        g_lane_order.fill(idx, n_lanes);
+        for (int k = 0; k < n_lanes; ++k)
+            if (w[idx[k]].state == RUNNABLE) resume(&w[idx[k]]);
         // every lane now waits or is done
         const void* best = nullptr;
         int best_tag = 0, best_op = 0, groups = 0;
@@ -232,7 +259,12 @@ void launch_impl(dim3 grid, dim3 block, size_t shmem, void (*fn)(void*), void* a
                     prepare(f, (int)t);
                 }
                 for (;;) {
-                    for (int w = 0; w < n_waves; ++w) run_wave(&g_fib[w * 64], (int)std::min<size_t>(64, nt - (size_t)w * 64));
+                    int widx[MAX_THREADS / 64];
+                    g_wave_order.fill(widx, n_waves);
+                    for (int k = 0; k < n_waves; ++k) {
+                        const int w = widx[k];
+                        run_wave(&g_fib[w * 64], (int)std::min<size_t>(64, nt - (size_t)w * 64));
+                    }
                     size_t n_bar = 0, n_done = 0;
                     for (size_t t = 0; t < nt; ++t) { n_bar += g_fib[t].state == WAIT_BAR; n_done += g_fib[t].state == DONE; }
                     if (n_done == nt) break;

@@ -32,3 +32,19 @@ def _export(name):
 
 for _n in [n for n in dir(T) if n.startswith('test_')]:
     _export(_n)
+
+
+def test_hostsim_results_do_not_depend_on_lane_or_wave_order():
+    """The wave machine runs the lanes of a wave one after the other between rendezvous, and the waves of a workgroup one after the
+    other between barriers.  On the hardware the lanes run in lockstep and the waves concurrently, so no result may depend on the
+    order the machine happens to use: the golden render and the gradient goldens again with the lanes in a pseudo-random order
+    and the waves reversed (a separate process: the order is fixed when the library loads).  This is what found the two places
+    where lanes hand data to each other through LDS with no wave-level operation in between (k_encode.hip: wave barriers)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, HOSTSIM_LANE_ORDER='shuffle:7', HOSTSIM_WAVE_ORDER='reverse')
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-p', 'no:cacheprovider', '-k',
+                        'render_64x64x32 or train_step_gradients or part_fields or knn_fallback'],
+                       env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
