@@ -57,13 +57,17 @@ def activate(extra_flags=()):
     from invr.network import Network
     from . import build
     path = build.build(extra=tuple(extra_flags))
-    saved = (_abi.LIB_PATH, _abi._lib, _abi.ptr, _abi.stream_ptr, Network.workspace, torch.cuda.synchronize)
+    from invr import driver
+    make_opt = driver.make_optimizer
+    saved = (_abi.LIB_PATH, _abi._lib, _abi.ptr, _abi.stream_ptr, Network.workspace, torch.cuda.synchronize, make_opt)
     _abi.LIB_PATH, _abi._lib = path, None
     _abi.ptr, _abi.stream_ptr = _ptr, (lambda: C.c_void_p(0))
     Network.workspace = _workspace
     torch.cuda.synchronize = lambda *a, **k: None
+    # the driver picks the fused optimiser for device-resident parameters: here the "device" is the host build
+    driver.make_optimizer = lambda net, *a, **k: make_opt(net, *a, **dict(k, fused=k.get('fused') if k.get('fused') is not None else True))
     try:
         _abi.lib()
         yield Counters(path)
     finally:
-        _abi.LIB_PATH, _abi._lib, _abi.ptr, _abi.stream_ptr, Network.workspace, torch.cuda.synchronize = saved
+        _abi.LIB_PATH, _abi._lib, _abi.ptr, _abi.stream_ptr, Network.workspace, torch.cuda.synchronize, driver.make_optimizer = saved

@@ -8,30 +8,33 @@ import pytest
 import torch
 
 import tests.test_gpu_parity as T
+import tests.test_gpu_training as TT
 from tests.hostsim import harness
 from tests.test_gpu_parity import gpu_setup  # noqa: F401  (fixture)
+
+# every test of the parity module; of the training module the ones at the golden's / a toy size (the others need the 1.09 GB model)
+# (test_lan_config_training_loop_vs_oracle passes here too: 14 optimiser steps against the oracle's autograd, 110 s — left to -m gpu)
+BORROWED = [(T, None), (TT, ['test_pair_term_gradient_float64_arbitration', 'test_reference_step_form_with_disabled_grad_scaler'])]
 
 
 @pytest.fixture(scope='module', autouse=True)
 def hostsim():
-    old = T.DEV
-    T.DEV = 'cpu'
+    old = [m.DEV for m, _ in BORROWED]
+    for m, _ in BORROWED:
+        m.DEV = 'cpu'
     try:
         with harness.activate() as counters:
             yield counters
             # no kernel read a lane that was not taking part in the operation (readlane / shuffle from a disabled lane)
             assert counters.anomalies == 0, counters.anomalies
     finally:
-        T.DEV = old
+        for (m, _), d in zip(BORROWED, old):
+            m.DEV = d
 
 
-def _export(name):
-    fn = getattr(T, name)
-    globals()['test_hostsim__' + name[5:]] = fn
-
-
-for _n in [n for n in dir(T) if n.startswith('test_')]:
-    _export(_n)
+for _m, _names in BORROWED:
+    for _n in (_names or [n for n in dir(_m) if n.startswith('test_')]):
+        globals()['test_hostsim__' + _n[5:]] = getattr(_m, _n)
 
 
 def test_hostsim_results_do_not_depend_on_lane_or_wave_order():
