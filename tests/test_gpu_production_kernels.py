@@ -28,7 +28,11 @@ from oracle import nvr_oracle as O          # noqa: E402  (checker only)
 from invr import _abi, scene, stages        # noqa: E402
 
 DEV = 'cuda:0'
-S = 128
+RES, S = 512, 128
+# least counts a frame must reach for the comparisons to mean something, and sample sizes (tests/test_hostsim_cpu.py runs the same
+# test bodies on a reduced frame with smaller numbers)
+MIN = dict(na=500000, listed=500000, oracle_subset=6000, oracle_chunk=2000, enc_take=25000, enc_total=100000, enc_inside=30000,
+           strict_rays=256, occ=300)
 WELL_FLOOR = 0.90        # least fraction of the 256 sampled pixels per pose that must be well conditioned and meet the plain 1e-4 bar
                          # (measured: 240-256 of 256 at the four poses with the multi-trial noise estimate of tests/conditioning.py; printed)
 POSES = [dict(seed=0, pose_scale=0.5, frame=3, cam_dist=1.8, thresh=0.05),
@@ -40,11 +44,13 @@ POSES = [dict(seed=0, pose_scale=0.5, frame=3, cam_dist=1.8, thresh=0.05),
 def fr(request, full_net):
     """One production render of a pose (all rays, 128 samples, full 28 GB workspace) and views of what it left behind;
     module-scoped and parametrised, so pytest runs every test of a pose on one render."""
-    k = request.param
-    cfg0, net = full_net
+    return make_frame(request.param, *full_net)
+
+
+def make_frame(k, cfg0, net):
     kw = dict(POSES[k])
     thresh = kw.pop('thresh')
-    bnp, _ = scene.make_scene(512, 512, **kw)
+    bnp, _ = scene.make_scene(RES, RES, **kw)
     bc = scene.to_torch(bnp)
     gb = {k_: v.to(DEV) for k_, v in bc.items()}
     cfg = copy.deepcopy(cfg0)
@@ -77,7 +83,7 @@ def ulp_diff(a, b):
 def test_knn_pairs_vs_brute_force_whole_frame(fr):
     f, k = fr, fr['k']
     v, st, Na, thresh = f['v'], f['st'], f['Na'], f['thresh']
-    assert Na > 500000
+    assert Na > MIN['na']
     # survivors: exactly the samples whose trilinear distance is below the threshold, in ray-major order
     assert bool((f['act'][1:] > f['act'][:-1]).all())
     nn, d2, w, dist = stages.knn_neighbors(f['ctx'].scene, f['pts'])
@@ -104,14 +110,14 @@ def test_knn_pairs_vs_brute_force_whole_frame(fr):
         wd = ulp_diff(v['l_w'][p][slots], w[slots, p])
         assert int(wd.max()) <= 1, (k, p, int(wd.max()))
         n_listed += cnt
-    assert n_listed > 500000
+    assert n_listed > MIN['listed']
     # brute-force kernel vs the oracle (CPU restatement of pytorch3d knn_points + sample_blend_closest_points) on a subset
-    sel = torch.randperm(Na, generator=torch.Generator().manual_seed(k))[:6000].to(DEV)
+    sel = torch.randperm(Na, generator=torch.Generator().manual_seed(k))[:MIN['oracle_subset']].to(DEV)
     b = f['bc']
     pp = f['pts'][sel].cpu()
     got_nn, got_dist, got_w = nn[sel].cpu(), dist[sel].cpu(), w[sel].cpu()
-    for c0 in range(0, sel.numel(), 2000):
-        sl = slice(c0, c0 + 2000)
+    for c0 in range(0, sel.numel(), MIN['oracle_chunk']):
+        sl = slice(c0, c0 + MIN['oracle_chunk'])
         P, M = b['part_pts'][0].shape[:2]
         dd = ((pp[sl][None, :, None, :] - b['part_pts'][0][:, None, :, :]) ** 2).sum(-1)
         dd = dd.masked_fill(torch.arange(M)[None, None, :] >= b['lengths2'][0][:, None, None], float('inf'))
@@ -213,7 +219,7 @@ def test_row_sum_xcd_encoder_vs_oracle_real_tables(fr):
     # (2) a sample against the oracle on the CPU
     for p in range(5):
         cnt = int(st[1 + p])                                  # incl. the far-constant pair (canonical origin, far outside most boxes)
-        take = min(cnt, 25000)
+        take = min(cnt, MIN['enc_take'])
         sel = torch.randperm(cnt, generator=g)[:take]
         sel[0] = cnt - 1
         sel = sel.to(DEV)
@@ -234,7 +240,7 @@ def test_row_sum_xcd_encoder_vs_oracle_real_tables(fr):
             assert err[inside].max() < 1.3e-5, (k, p, float(err[inside].max()))
         total += take
         inside_total += int(inside.sum())
-    assert total >= 100000 and inside_total >= 30000
+    assert total >= MIN['enc_total'] and inside_total >= MIN['enc_inside']
 
 
 def test_render_strict_1e4_on_well_conditioned_pixels(fr):
@@ -246,7 +252,7 @@ def test_render_strict_1e4_on_well_conditioned_pixels(fr):
     f, k = fr, fr['k']
     net, bc, gb, cfg = f['net'], f['bc'], f['gb'], f['cfg']
     n = gb['ray_o'].shape[1]
-    sel = torch.randperm(n, generator=torch.Generator().manual_seed(100 + k))[:256].sort()[0]
+    sel = torch.randperm(n, generator=torch.Generator().manual_seed(100 + k))[:MIN['strict_rays']].sort()[0]
     out = net.render_rays(f['ctx'], *[gb[k_][0][sel.to(DEV)] for k_ in ('ray_o', 'ray_d', 'near', 'far')], S, want_raw=True)
     torch.cuda.synchronize()
     net._ws = None
@@ -259,7 +265,7 @@ def test_render_strict_1e4_on_well_conditioned_pixels(fr):
         sd64 = {k_: (t.double() if t.is_floating_point() else t) for k_, t in sd.items()}
         b64 = {k_: (t.double() if torch.is_tensor(t) and t.is_floating_point() else t) for k_, t in b.items()}
         ref64 = O.render(O.Model(sd64, cfg), b64, n_samples=S, chunk=64)
-    assert int((ref['occ'][0, :, 0] != 0).sum()) > 300
+    assert int((ref['occ'][0, :, 0] != 0).sum()) > MIN['occ']
     assert bool(((out['raw'].cpu()[:, 3] != 0) == (ref['raw'][0, :, 3] != 0)).all())
     exact = ref64['rgb_map'][0]
     err_gpu = (out['rgb_map'].cpu().double() - exact).abs().max(1)[0]
