@@ -42,7 +42,19 @@ ASAN_REWRITES = [
 ]
 
 
-def transform(text, name, asan=False):
+# -DHOSTSIM_KNN_PERM (tools/knn_order_model.py): k_knn_pairs reads its survivors through a permutation set from outside, to count the
+# sweep's work (the -DKNN_PROF counters) under other survivor orders than the compaction's.  Results of such a run are garbage.
+def knn_perm_rewrite(text, name):
+    if name != 'k_knn.hip':
+        return text
+    text = text.replace('w.active_idx[slot]', 'w.active_idx[hostsim_knn_perm ? hostsim_knn_perm[slot] : slot]')
+    return text.replace('#define KNN_BLOCK 256', 'static const int* hostsim_knn_perm = nullptr;\n'
+                        'extern "C" void hostsim_set_knn_perm(const int* p) { hostsim_knn_perm = p; }\n#define KNN_BLOCK 256', 1)
+
+
+def transform(text, name, asan=False, knn_perm=False):
+    if knn_perm:
+        text = knn_perm_rewrite(text, name)
     for rx, rep in REWRITES + (ASAN_REWRITES if asan else []):
         text = rx.sub(rep, text)
     code = re.sub(r'//[^\n]*', '', text)
@@ -84,7 +96,7 @@ def build(force=False, verbose=False, extra=()):
     jobs = []
     for f in sources():
         cpp = os.path.join(OUT, f[:-4] + '.cpp')
-        text = transform(open(os.path.join(CSRC, f)).read(), f, asan='-fsanitize=address' in extra)
+        text = transform(open(os.path.join(CSRC, f)).read(), f, asan='-fsanitize=address' in extra, knn_perm='-DHOSTSIM_KNN_PERM' in extra)
         with open(cpp, 'w') as fh:
             fh.write('#line 1 "%s"\n' % os.path.join(CSRC, f))
             fh.write(text)
