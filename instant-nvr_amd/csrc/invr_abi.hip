@@ -224,6 +224,8 @@ static size_t carve(Workspace& w, void* base, int64_t N, int64_t cap) {
     w.super_tot = c.take<int32_t>(cdiv(nb, 1024) + 1);
     w.active_idx = c.take<int32_t>(lc);
     w.word_off = c.take<int32_t>(nb * 16);
+    w.byte_off = c.take<int32_t>(nb * 128);
+    w.ord_rows = w.ord_cols = 0;
     w.pflags = c.take<uint8_t>(lc);
     w.farflags = c.take<uint8_t>(lc);
     for (int p = 0; p < INVR_NUM_PARTS; ++p) {
@@ -318,7 +320,7 @@ static int render_impl(const InvrScene* scene, const InvrModel* model,
                        float* rgb_map, float* acc_map, float* raw, float* occ, float* weights,
                        float* z_vals, int32_t* stats,
                        void* workspace, size_t workspace_bytes, int64_t max_active, void* stream,
-                       bool geometry_only = false) {
+                       bool geometry_only = false, bool may_reorder = false) {
     hipStream_t st = (hipStream_t)stream;
     INVR_CHECK(scene && model, "invr_render_fwd: null scene/model");
     INVR_CHECK(n_rays >= 0 && (n_samples >= 2 || (wpts && n_samples == 1)), "invr_render_fwd: need n_rays >= 0 and n_samples >= 2");
@@ -340,6 +342,15 @@ static int render_impl(const InvrScene* scene, const InvrModel* model,
                "TPoseHuman.forward indexes the (Na,3) view directions per part)");
     INVR_CHECK(scene->part_stride <= KNN_MAX_PART, "invr_render_fwd: part_stride %d > %d vertices per part", scene->part_stride, KNN_MAX_PART);
 
+    // survivor order of the frame: ray-major, or (eval frames with a power-of-two sample count, INVR_ORDER=1) depth-windowed inside
+    // blocks of 8192 ray-samples.  Every training forward — invr_train_fwd / invr_geometry_fwd, and the op-by-op path's
+    // invr_render_fwd calls, which carry jitter or ask for the weights — keeps the reference's ray-major row order (its per-row
+    // noise and its (Na*P, .) outputs are defined on it).
+    static const int order_env = getenv("INVR_ORDER") ? atoi(getenv("INVR_ORDER")) : 0;
+    if (order_env && may_reorder && !wpts && !jitter && !weights && n_samples >= 8 && n_samples <= 1024 && (n_samples & (n_samples - 1)) == 0) {
+        w.ord_cols = n_samples / 8;
+        w.ord_rows = 1024 / w.ord_cols;
+    }
     RenderArgs a;
     a.scene = make_scene_dev(scene);
     a.ray_o = ray_o; a.ray_d = ray_d; a.near = near; a.far = far; a.jitter = jitter; a.z_vals = z_vals;
@@ -444,7 +455,7 @@ extern "C" int invr_render_fwd(const InvrScene* scene, const InvrModel* model,
                                float* z_vals, int32_t* stats,
                                void* workspace, size_t workspace_bytes, int64_t max_active, void* stream) {
     return render_impl(scene, model, ray_o, ray_d, near, far, jitter, nullptr, nullptr, n_rays, n_samples, rgb_map, acc_map,
-                       raw, occ, weights, z_vals, stats, workspace, workspace_bytes, max_active, stream);
+                       raw, occ, weights, z_vals, stats, workspace, workspace_bytes, max_active, stream, false, true);
 }
 
 extern "C" int invr_geometry_fwd(const InvrScene* scene, const InvrModel* model,

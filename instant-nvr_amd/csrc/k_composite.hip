@@ -43,14 +43,19 @@ struct DenseRaw {      // raw (R,S,4) given
 };
 struct MergedRaw {     // merge per-part results of the survivor slot of sample i
     const unsigned long long* mask;      // survivor bit of sample i: bit i&63 of word i>>6
-    const int32_t* word_off;             // rank of the first survivor of every word
+    const int32_t* word_off;             // rank of the first survivor of every word (ray-major order)
+    const int32_t* byte_off;             // windowed order (Workspace::ord_rows > 0): rank of the first survivor of every mask byte; else NULL
     const uint8_t* wsel;                 // the merge's choice per survivor (k_winner_lists)
     const float4* rgbw;                  // [rgb, occ] of the winning listed pair at the survivor's slot; far constants at [lcap + p]
     int64_t const_slot;
     __device__ __forceinline__ float4 get(int64_t i) const {
         const unsigned long long m = mask[i >> 6];
         const int bit = (int)(i & 63);
-        int slot = ((m >> bit) & 1ull) ? word_off[i >> 6] + __popcll(m & ((1ull << bit) - 1ull)) : -1;
+        int slot = -1;
+        if ((m >> bit) & 1ull) {
+            if (byte_off) slot = byte_off[i >> 3] + __popc((unsigned)(m >> (bit & ~7)) & ((1u << (bit & 7)) - 1u));
+            else slot = word_off[i >> 6] + __popcll(m & ((1ull << bit) - 1ull));
+        }
         if (slot >= const_slot) slot = -1;                   // survivor beyond max_active (reported in stats[6])
         float4 best = make_float4(0.f, 0.f, 0.f, 0.f);
         if (slot >= 0) {
@@ -107,7 +112,7 @@ int launch_composite(const float* raw, int64_t n_rays, int S, float* weights, fl
 int launch_merge_composite(const RenderArgs& a, const Workspace& w, float* rgb_map, float* acc_map, float* raw,
                            float* occ, float* weights, hipStream_t st) {
     if (a.R == 0) return 0;
-    MergedRaw src{w.mask, w.word_off, w.wsel, w.rgbw, w.cap};
+    MergedRaw src{w.mask, w.word_off, w.ord_rows > 0 ? w.byte_off : nullptr, w.wsel, w.rgbw, w.cap};
     hipLaunchKernelGGL(k_composite<MergedRaw>, dim3((unsigned)cdiv(a.R, CMP_BLOCK / 64)), dim3(CMP_BLOCK), 0, st,
                        src, a.R, a.S, weights, rgb_map, acc_map, reinterpret_cast<float4*>(raw), occ);
     INVR_LAUNCH_CHECK();

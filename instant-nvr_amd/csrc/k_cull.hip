@@ -210,6 +210,96 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_compact(RenderArgs a, Workspace 
     }
 }
 
+// ---- windowed survivor order (Workspace::ord_rows > 0) ----------------------------------------------------------------------
+// A block = ord_rows rays x ord_cols windows of 8 samples = 8192 ray-samples = 8 cull tiles = 128 mask words.  Inside a block the
+// survivors are ranked by (window, ray, sample): the exclusive scan of the 1024 byte popcounts in column-major order.  Same three
+// launches as the ray-major order: the scan sums 8 tile counts per block, the compaction ranks inside the block.
+#define WIN_BLOCK 8192
+#define WIN_BYTES (WIN_BLOCK / 8)
+__global__ __launch_bounds__(SCAN_T) void k_scan_blocks_win(Workspace w, int64_t nb_tiles, int64_t nblk) {
+    __shared__ int wsum[SCAN_T / 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * SCAN_T + threadIdx.x;
+    int v = 0;
+    if (i < nblk)
+        for (int t = 0; t < WIN_BLOCK / CULL_TILE; ++t) v += (i * (WIN_BLOCK / CULL_TILE) + t < nb_tiles) ? w.block_cnt[i * (WIN_BLOCK / CULL_TILE) + t] : 0;
+    const int x = wave_incl_sum_i(v);
+    if (lane == 63) wsum[wv] = x;
+    __syncthreads();
+    int woff = 0;
+    for (int k = 0; k < wv; ++k) woff += wsum[k];
+    if (i < nblk) w.block_off[i] = woff + x - v;
+    if (threadIdx.x == SCAN_T - 1) w.super_tot[blockIdx.x] = woff + x;
+}
+
+__global__ __launch_bounds__(CULL_BLOCK) void k_compact_win(RenderArgs a, Workspace w, int64_t max_active, int64_t n_words) {
+    __shared__ unsigned long long smask[WIN_BLOCK / 64];
+    __shared__ int soff[WIN_BYTES];
+    __shared__ int wsum[CULL_BLOCK / 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int base = w.block_off[blockIdx.x];
+    {
+        const int64_t sb = (int64_t)(blockIdx.x / SCAN_T);
+        int add = 0;
+        for (int64_t j0 = 0; j0 < sb; j0 += 64) add += (j0 + lane < sb) ? w.super_tot[j0 + lane] : 0;
+        base += __builtin_amdgcn_readlane(wave_incl_sum_i(add), 63);
+    }
+    if (blockIdx.x == 0 && wv == 0) {                  // the survivor count, clamped to the workspace capacity (k_compact)
+        const int64_t ns = ((int64_t)gridDim.x + SCAN_T - 1) / SCAN_T;
+        int64_t na = 0;
+        for (int64_t j0 = 0; j0 < ns; j0 += 64) {
+            const int t = (j0 + lane < ns) ? w.super_tot[j0 + lane] : 0;
+            na += __builtin_amdgcn_readlane(wave_incl_sum_i(t), 63);
+        }
+        if (lane == 0) {
+            if (na > max_active) {
+                w.counters[CNT_OVERFLOW] = 1;
+                na = max_active;
+            }
+            w.counters[CNT_ACTIVE] = (int)na;
+        }
+    }
+    const int64_t word0 = (int64_t)blockIdx.x * (WIN_BLOCK / 64);
+    if (threadIdx.x < WIN_BLOCK / 64) smask[threadIdx.x] = word0 + threadIdx.x < n_words ? w.mask[word0 + threadIdx.x] : 0ull;
+    __syncthreads();
+    // thread t ranks the bytes at column-major positions 4 t .. 4 t + 3 (ord_rows is a multiple of 4: one window, four rays)
+    const int rows = w.ord_rows, cols = w.ord_cols;
+    const uint8_t* sbytes = reinterpret_cast<const uint8_t*>(smask);
+    int fb[4], cnt[4], tot = 0;
+    unsigned bits[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int q = threadIdx.x * 4 + e;
+        fb[e] = (q % rows) * cols + q / rows;           // byte of (ray q % rows, window q / rows) in the block's flat sample order
+        bits[e] = sbytes[fb[e]];
+        cnt[e] = __popc(bits[e]);
+        tot += cnt[e];
+    }
+    const int incl = wave_incl_sum_i(tot);
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    int off = base + incl - tot;
+    for (int k = 0; k < wv; ++k) off += wsum[k];
+    const int64_t i0 = (int64_t)blockIdx.x * WIN_BLOCK;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        soff[fb[e]] = off;
+        unsigned b = bits[e];
+        int slot = off;
+        while (b) {
+            const int bit = __ffs((int)b) - 1;
+            b &= b - 1u;
+            if (slot < max_active) w.active_idx[slot] = (int32_t)(i0 + fb[e] * 8 + bit);
+            ++slot;
+        }
+        off += cnt[e];
+    }
+    __syncthreads();
+    const int64_t n_bytes = (a.N + 7) >> 3, byte0 = (int64_t)blockIdx.x * WIN_BYTES;
+    for (int j = threadIdx.x; j < WIN_BYTES; j += CULL_BLOCK)
+        if (byte0 + j < n_bytes) w.byte_off[byte0 + j] = soff[j];
+}
+
 // cell mask of the cull + list of the live cells (for the KNN's lattice classification); 1 = built
 int launch_cull_cells(const RenderArgs& a, const Workspace& w, hipStream_t st) {
     const VolDev& v = a.scene.pbw;
@@ -236,6 +326,14 @@ int launch_cull(const RenderArgs& a, const Workspace& w, int64_t max_active, boo
         hipLaunchKernelGGL((k_cull_flag<false, false>), dim3((unsigned)nb), dim3(CULL_BLOCK), 0, st, a, w, inv_S, lin_step);
     }
     INVR_LAUNCH_CHECK();
+    if (w.ord_rows > 0) {
+        const int64_t nblk = cdiv(a.N, WIN_BLOCK);
+        hipLaunchKernelGGL(k_scan_blocks_win, dim3((unsigned)cdiv(nblk, SCAN_T)), dim3(SCAN_T), 0, st, w, nb, nblk);
+        INVR_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_compact_win, dim3((unsigned)nblk), dim3(CULL_BLOCK), 0, st, a, w, max_active, nb * (CULL_TILE / 64));
+        INVR_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(k_scan_blocks, dim3((unsigned)cdiv(nb, SCAN_T)), dim3(SCAN_T), 0, st, w, nb);
     INVR_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_compact, dim3((unsigned)nb), dim3(CULL_BLOCK), 0, st, a, w, max_active);

@@ -59,6 +59,12 @@ struct Workspace {
     int32_t* active_idx;          // cap: ray-sample index of every survivor (ordered)
     int32_t* word_off;            // ceil(N/64): rank of the first survivor of every 64-sample mask word (slot of sample i =
                                   // word_off[i>>6] + popcount(mask[i>>6] below bit i&63); 2 MB instead of a 131 MB slot-per-sample array)
+    // Windowed survivor order (eval frames, launch_cull): ord_rows > 0 = the survivors of a block of ord_rows rays are ranked by
+    // (8-sample depth window, ray, sample) instead of (ray, sample) — 64 consecutive survivors are then one depth slab of a few
+    // neighbouring rays instead of the front AND back segments of those rays, which is what the KNN's per-wave pruning pays for
+    // (tools/knn_order_model.py).  slot of sample i = byte_off[i>>3] + popcount(bits of its mask byte below bit i&7).
+    int32_t* byte_off;            // ceil(N/8): rank of the first survivor of every 8-sample mask byte (windowed order only)
+    int32_t ord_rows, ord_cols;   // rays per block, 8-sample windows per ray (ord_rows * ord_cols = 1024: blocks of 8192 ray-samples); 0 = ray-major
     uint8_t* pflags;              // cap: bit p set if (slot, part p) is flagged and listed
     uint8_t* farflags;            // cap: bit p set if (slot, part p) is a far pair (takes the part constant)
     KnnIndex knn;

@@ -19,6 +19,7 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STEPS, SIDE, SAMPLES = 4, 20, 32
+DEV = 'cuda:0'                  # (tests/test_hostsim_dist_cpu.py runs the same bodies on the CPU wave machine)
 
 
 def _setup():
@@ -33,14 +34,14 @@ def _setup():
     sd = params.init_state_dict(cfg, seed=31)
     net = Network(cfg=cfg)
     net.load_state_dict(sd, strict=True)
-    net = net.to('cuda:0').train()
+    net = net.to(DEV).train()
     batches = []
     for r, centre in enumerate(((250, 262), (270, 248))):
         bnp, _ = scene.make_scene(512, 512, seed=2, frame=11 + 40 * r, cam_dist=1.8, crop=(centre[0] - SIDE // 2, centre[1] - SIDE // 2, SIDE, SIDE))
-        batches.append({k: v.to('cuda:0') for k, v in scene.to_torch(bnp).items()})
+        batches.append({k: v.to(DEV) for k, v in scene.to_torch(bnp).items()})
     g = torch.Generator().manual_seed(3)
-    jit = [torch.rand(b['ray_o'].shape[1], SAMPLES, generator=g).to('cuda:0') for b in batches]
-    noi = [torch.rand(b['ray_o'].shape[1] * SAMPLES * 5, 3, generator=g).to('cuda:0') for b in batches]
+    jit = [torch.rand(b['ray_o'].shape[1], SAMPLES, generator=g).to(DEV) for b in batches]
+    noi = [torch.rand(b['ray_o'].shape[1] * SAMPLES * 5, 3, generator=g).to(DEV) for b in batches]
     wrap = NetworkWrapper(net)
     opt = driver.make_optimizer(net, lr=1e-3, eps=1e-15)
     return net, wrap, opt, batches, jit, noi, driver
@@ -50,6 +51,10 @@ def _worker(rank, world, port, out_path):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
+    _rank_body(rank, out_path)
+
+
+def _rank_body(rank, out_path):
     try:
         net, wrap, opt, batches, jit, noi, driver = _setup()
         from invr import dist_train
@@ -75,9 +80,9 @@ def _free_port():
     return p
 
 
-def test_two_rank_dp_equals_single_rank_averaged_gradients(tmp_path):
+def test_two_rank_dp_equals_single_rank_averaged_gradients(tmp_path, worker=None):
     out = str(tmp_path / 'dp')
-    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(worker or _worker, args=(2, _free_port(), out), nprocs=2, join=True)
     r0, r1 = torch.load(out + '.0'), torch.load(out + '.1')
     for k in r0['sd']:
         assert torch.equal(r0['sd'][k], r1['sd'][k]), k                     # replicas stay identical (same averaged gradient)

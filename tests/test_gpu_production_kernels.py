@@ -84,8 +84,17 @@ def test_knn_pairs_vs_brute_force_whole_frame(fr):
     f, k = fr, fr['k']
     v, st, Na, thresh = f['v'], f['st'], f['Na'], f['thresh']
     assert Na > MIN['na']
-    # survivors: exactly the samples whose trilinear distance is below the threshold, in ray-major order
-    assert bool((f['act'][1:] > f['act'][:-1]).all())
+    # survivors: every sample once — in ray-major order, or (eval frames with a power-of-two sample count, csrc/k_cull.hip "windowed
+    # survivor order") ranked by (8-sample depth window, ray, sample) inside blocks of 8192 ray-samples
+    act = f['act'].long()
+    asc = act.sort()[0]
+    assert bool((asc[1:] > asc[:-1]).all())
+    if not torch.equal(act, asc):
+        assert S >= 8 and S & (S - 1) == 0
+        rows = 8192 // S
+        ray, smp = act // S, act % S
+        key = ((ray // rows) * (S // 8) + smp // 8) * 8192 + (ray % rows) * 8 + smp % 8
+        assert bool((key[1:] > key[:-1]).all())
     nn, d2, w, dist = stages.knn_neighbors(f['ctx'].scene, f['pts'])
     pf, ff = v['pflags'][:Na].int(), v['farflags'][:Na].int()
     assert int((pf & ff).max()) == 0

@@ -1,6 +1,6 @@
 """CPU: the PRODUCTION kernels of the eval frame (k_knn_pairs, k_warp_pairs + k_deform_pairs_slice, k_part_encode_rs_xcd, k_part_occ_all /
 k_winner_lists / k_part_rgb_all) pinned directly — the test bodies of tests/test_gpu_production_kernels.py on a reduced frame
-(96 x 96 pixels x 48 samples, 2^12-row tables) through the host build of the kernel sources (tests/hostsim).  The frame is large
+(96 x 96 pixels x 64 samples, 2^12-row tables) through the host build of the kernel sources (tests/hostsim).  The frame is large
 enough for several 4096-slot groups (segmented pair / winner lists, the colour kernel's segment cursor) and for every class of the
 KNN's lattice cells; the whole-frame sizes stay with -m gpu."""
 import copy
@@ -12,13 +12,13 @@ import torch
 import tests.test_gpu_production_kernels as P
 from tests.hostsim import harness
 
-SMALL = dict(RES=96, S=48,
-             MIN=dict(na=12000, listed=12000, oracle_subset=1500, oracle_chunk=500, enc_take=4000, enc_total=9000, enc_inside=2000,
+SMALL = dict(RES=96, S=64,
+             MIN=dict(na=16000, listed=16000, oracle_subset=1500, oracle_chunk=500, enc_take=4000, enc_total=9000, enc_inside=2000,
                       strict_rays=48, occ=40))
 if os.environ.get('HOSTSIM_FRAME'):        # e.g. HOSTSIM_FRAME=256,128: a one-off larger frame (> 64 slot groups: the segment cursor's windows)
     SMALL['RES'], SMALL['S'] = (int(x) for x in os.environ['HOSTSIM_FRAME'].split(','))
-    _f = SMALL['RES'] ** 2 * SMALL['S'] / (96 * 96 * 48)
-    SMALL['MIN'].update(na=int(12000 * _f), listed=int(12000 * _f))
+    _f = SMALL['RES'] ** 2 * SMALL['S'] / (96 * 96 * 64)
+    SMALL['MIN'].update(na=int(16000 * _f), listed=int(16000 * _f))
 POSE_IDS = [1, 2]          # pose_scale 1.0 at threshold 0.05, pose_scale 1.2 at the inb_lan threshold 0.1
 
 
@@ -72,7 +72,7 @@ def test_hostsim_edge_cases(small_net):
     ro, rd, nr, fa = (gb[k][0] for k in ('ray_o', 'ray_d', 'near', 'far'))
     n = ro.shape[0]
     e = torch.empty(0, 3)
-    z = net.render_rays(ctx, e, e, torch.empty(0), torch.empty(0), 48)
+    z = net.render_rays(ctx, e, e, torch.empty(0), torch.empty(0), 64)
     assert z['rgb_map'].shape == (0, 3) and z['acc_map'].shape == (0,)
     idx = torch.arange(0, 333) * (n // 333)
     for S in (2, 3, 63, 65, 130):
@@ -81,18 +81,18 @@ def test_hostsim_edge_cases(small_net):
         assert int(o['stats'][6]) == 0
     o = net.render_rays(ctx, ro[:200] + 50.0, rd[:200], nr[:200], fa[:200], 64, want_raw=True)
     assert int(o['stats'][0]) == 0 and float(o['rgb_map'].abs().max()) == 0 and float(o['raw'].abs().max()) == 0
-    full = net.render_rays(ctx, ro, rd, nr, fa, 48, want_raw=True)
+    full = net.render_rays(ctx, ro, rd, nr, fa, 64, want_raw=True)
     na = int(full['stats'][0])
     assert na > 8192 and int(full['stats'][6]) == 0
     rgb, raw = full['rgb_map'].clone(), full['raw'].clone()
     for cap in (1000, 4095, 4096, 4097, na - 1):                       # too small: reported, nothing written out of bounds
-        o = net.render_rays(ctx, ro, rd, nr, fa, 48, max_active=cap)
+        o = net.render_rays(ctx, ro, rd, nr, fa, 64, max_active=cap)
         assert int(o['stats'][6]) == 1, cap
-    o = net.render_rays(ctx, ro, rd, nr, fa, 48, max_active=na, want_raw=True)          # exactly enough
+    o = net.render_rays(ctx, ro, rd, nr, fa, 64, max_active=na, want_raw=True)          # exactly enough
     assert int(o['stats'][6]) == 0 and torch.equal(o['rgb_map'], rgb) and torch.equal(o['raw'], raw)
     perm = torch.randperm(n, generator=torch.Generator().manual_seed(1))
-    o = net.render_rays(ctx, ro[perm], rd[perm], nr[perm], fa[perm], 48)
+    o = net.render_rays(ctx, ro[perm], rd[perm], nr[perm], fa[perm], 64)
     assert torch.equal(o['rgb_map'], rgb[perm])
     for sl in (slice(0, n // 3), slice(n // 3, n)):
-        o = net.render_rays(ctx, ro[sl], rd[sl], nr[sl], fa[sl], 48)
+        o = net.render_rays(ctx, ro[sl], rd[sl], nr[sl], fa[sl], 64)
         assert torch.equal(o['rgb_map'], rgb[sl])
