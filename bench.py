@@ -55,6 +55,10 @@ PAIR_TABLE_BYTES = 16 * 8 * ROW_BYTES      # 16 levels x 8 corners x 64 B = 8192
 
 
 def build_model(cfg, device, seed=0):
+    # the MLPs take torch's default initialisation: seeded, because WHICH part wins a survivor's max-occupancy merge — and with it how
+    # many pairs run the (larger) body / head colour MLP — depends on those weights; unseeded, the colour kernel's time moved between
+    # 0.25 and 0.43 ms from run to run (round 3 first read that as a power-state effect)
+    torch.manual_seed(seed)
     with torch.device(device):
         net = Network(cfg=cfg)
     net = net.to(device).eval()

@@ -342,11 +342,11 @@ static int render_impl(const InvrScene* scene, const InvrModel* model,
                "TPoseHuman.forward indexes the (Na,3) view directions per part)");
     INVR_CHECK(scene->part_stride <= KNN_MAX_PART, "invr_render_fwd: part_stride %d > %d vertices per part", scene->part_stride, KNN_MAX_PART);
 
-    // survivor order of the frame: ray-major, or (eval frames with a power-of-two sample count, INVR_ORDER=1) depth-windowed inside
+    // survivor order of the frame: ray-major, or (eval frames with a power-of-two sample count) depth-windowed inside
     // blocks of 8192 ray-samples.  Every training forward — invr_train_fwd / invr_geometry_fwd, and the op-by-op path's
     // invr_render_fwd calls, which carry jitter or ask for the weights — keeps the reference's ray-major row order (its per-row
     // noise and its (Na*P, .) outputs are defined on it).
-    static const int order_env = getenv("INVR_ORDER") ? atoi(getenv("INVR_ORDER")) : 0;
+    static const int order_env = getenv("INVR_ORDER") ? atoi(getenv("INVR_ORDER")) : 1;      // (0 = ray-major everywhere: A/B switch, tools/ab_order.sh)
     if (order_env && may_reorder && !wpts && !jitter && !weights && n_samples >= 8 && n_samples <= 1024 && (n_samples & (n_samples - 1)) == 0) {
         w.ord_cols = n_samples / 8;
         w.ord_rows = 1024 / w.ord_cols;
