@@ -82,16 +82,16 @@ def _train_worker(rank, world, port, out_path):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    D.DEV = 'cpu'
+    D.DEV, D.STEPS = 'cpu', 2
     with harness.activate():
         D._rank_body(rank, out_path)
 
 
 def test_two_rank_dp_training_with_the_real_kernels(tmp_path):
-    old = D.DEV
-    D.DEV = 'cpu'
+    old, old_steps = D.DEV, D.STEPS
+    D.DEV, D.STEPS = 'cpu', 2
     try:
         with harness.activate():
             D.test_two_rank_dp_equals_single_rank_averaged_gradients(tmp_path, worker=_train_worker)
     finally:
-        D.DEV = old
+        D.DEV, D.STEPS = old, old_steps

