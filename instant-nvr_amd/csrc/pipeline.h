@@ -50,9 +50,9 @@ struct KnnIndex {
 // per-slot arrays hold one extra entry (slot `cap`) for the per-part far-pair constant.
 struct Workspace {
     unsigned long long* mask;     // ceil(N/64): survivor bit per ray-sample
-    int32_t* block_cnt;           // ceil(N/256)
-    int32_t* block_off;           // ceil(N/256)
-    int32_t* super_tot;           // ceil(tiles/1024): survivors per super-block of 1024 cull tiles (k_scan_blocks -> k_compact)
+    int32_t* block_cnt;           // ceil(N/1024): survivors per cull tile (k_cull_flag)
+    int32_t* block_off;           // ceil(N/1024): rank of a tile's (ray-major) / of an 8192-sample block's (windowed order) first survivor inside its super-block
+    int32_t* super_tot;           // survivors per super-block of 1024 tiles / blocks (k_scan_blocks[_win] -> k_compact[_win])
     int32_t* counters;            // CNT_ALLOC, followed by gcount (one memset clears both)
     int32_t* gcount;              // [ceil(lcap / PAIR_GROUP)][INVR_NUM_PARTS]: flagged pairs per group of PAIR_GROUP survivor slots
     int64_t n_groups;

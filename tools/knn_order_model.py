@@ -77,11 +77,13 @@ def main():
                   % (name, prof[8], prof[9], prof[10], prof[11], prof[11] / max(base[11], 1), 100 * diag))
 
         report('ray-major (today)', base, None)
-        for R, D in ((64, 16), (64, 32), (16, 16), (256, 16), (64, 8)):
+        for R, D in [tuple(int(v) for v in a.split('x')) for a in os.environ.get('KNN_ORDERS', '64x16,64x32,16x16,256x16,64x8').split(',')]:
             key = (ray // R) * (S // D + 1) * R * S + (smp // D) * R * S + (ray % R) * S + smp
             perm = np.argsort(key, kind='stable')
             _, prof, _ = run(perm)
             report('tile %d rays x window %d samples' % (R, D), prof, perm)
+        if os.environ.get('KNN_ORDERS'):
+            return
         lo = pts.min(0)
         q = np.floor((pts - lo) / 0.04).astype(np.int64)
         key = (q[:, 0] * 4096 + q[:, 1]) * 4096 + q[:, 2]
