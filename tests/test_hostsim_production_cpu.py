@@ -96,3 +96,11 @@ def test_hostsim_edge_cases(small_net):
     for sl in (slice(0, n // 3), slice(n // 3, n)):
         o = net.render_rays(ctx, ro[sl], rd[sl], nr[sl], fa[sl], 64)
         assert torch.equal(o['rgb_map'], rgb[sl])
+
+
+def test_hostsim_survivor_order_does_not_change_the_frame(tmp_path):
+    """tests/test_gpu_fullsize.py:test_survivor_order_does_not_change_the_frame on a 96 x 96 x 64 frame, both processes on the wave
+    machine (the full 512 x 512 x 128 frame was compared this way once, by hand: bit-identical)."""
+    import tests.test_gpu_fullsize as F
+    a, b = F.order_frames(tmp_path, 'cpu', 96, 64, extra=('hostsim',))
+    F.check_order_frames(a, b, 64, 12000)
