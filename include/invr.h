@@ -165,10 +165,12 @@ int invr_field_fwd(const InvrScene* scene, const InvrModel* model, const float* 
 typedef struct InvrWsLayout {
     int64_t cap, lcap;
     int64_t counters;                      /* int32[16]: INVR_STAT_* layout                        */
-    int64_t active_idx;                    /* int32[lcap]: ray-sample index of each survivor slot  */
-    int64_t word_off;                      /* int32[ceil(N/1024)*16]: rank of the first survivor of each 64-sample mask word */
+    int64_t active_idx;                    /* int32[lcap]: ray-sample index of each survivor slot (ray-major for training-mode calls; eval frames
+                                            * with a power-of-two sample count: by 8-sample depth window inside blocks of 8192 ray-samples) */
+    int64_t word_off;                      /* int32[ceil(N/1024)*16]: rank of the first survivor of each 64-sample mask word (ray-major calls) */
     int64_t mask;                          /* uint64[ceil(N/1024)*16]: survivor bit of ray-sample i = bit i&63 of word i>>6;
-                                              slot of a surviving sample = word_off[i>>6] + popcount(lower bits)     */
+                                              slot of a surviving sample = word_off[i>>6] + popcount(lower bits) after a ray-major call,
+                                              byte_off[i>>3] + popcount(bits of its mask byte below bit i&7) after a depth-windowed one  */
     int64_t pflags, farflags;              /* uint8[lcap]: bit p = (slot, part p) listed / far     */
     int64_t l_slot[INVR_NUM_PARTS];        /* int32[lcap]: survivor slot of each listed pair, ascending; the last entry is the far constant (slot cap) */
     int64_t l_nn[INVR_NUM_PARTS];          /* int32[lcap*4] indexed by SURVIVOR SLOT: the 4 neighbour rows inside part_pbw[p] of a flagged (slot, part) */
@@ -187,6 +189,9 @@ typedef struct InvrWsLayout {
     int64_t rgbw;                          /* float4[lcap+8]: [rgb, occ] of the winning listed pair per survivor; [lcap+p] = far constant of part p */
     int64_t n_groups;
     int64_t knn_dfar2;                     /* float[1]: squared far-fold distance of the frame (0.4624 = (0.68 m)^2 while |A|, |big_A| entries <= 2) */
+    int64_t byte_off;                      /* int32[ceil(N/1024)*128]: rank of the first survivor of each 8-sample mask byte — written by eval
+                                              frames (invr_render_fwd without jitter / weights, power-of-two n_samples in 8..1024), whose
+                                              survivors are ranked by depth window inside blocks of 8192 ray-samples       */
 } InvrWsLayout;
 int invr_workspace_layout(int64_t n_rays, int32_t n_samples, int64_t max_active, InvrWsLayout* out);
 

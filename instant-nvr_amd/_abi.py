@@ -79,7 +79,8 @@ class InvrWsLayout(C.Structure):
                 ('l_slot', C.c_int64 * NUM_PARTS), ('l_nn', C.c_int64 * NUM_PARTS), ('l_w', C.c_int64 * NUM_PARTS),
                 ('l_x', C.c_int64 * NUM_PARTS), ('l_d', C.c_int64 * NUM_PARTS), ('l_r', C.c_int64 * NUM_PARTS),
                 ('emb', C.c_int64 * NUM_PARTS), ('occp', C.c_int64 * NUM_PARTS), ('wl', C.c_int64 * NUM_PARTS),
-                ('wcnt', C.c_int64), ('wsel', C.c_int64), ('rgbw', C.c_int64), ('n_groups', C.c_int64), ('knn_dfar2', C.c_int64)]
+                ('wcnt', C.c_int64), ('wsel', C.c_int64), ('rgbw', C.c_int64), ('n_groups', C.c_int64), ('knn_dfar2', C.c_int64),
+                ('byte_off', C.c_int64)]
 
 
 EXPORTS = ['invr_last_error', 'invr_version', 'invr_sizeof', 'invr_workspace_bytes', 'invr_render_fwd',
@@ -214,6 +215,7 @@ def ws_views(ws, n_rays, S, max_active, n_active=None):
          'active_idx': view(lay.active_idx, lc, torch.int32),
          'word_off': view(lay.word_off, (n_rays * S + 1023) // 1024 * 16, torch.int32),
          'mask': view(lay.mask, (n_rays * S + 1023) // 1024 * 16, torch.int64),
+         'byte_off': view(lay.byte_off, (n_rays * S + 1023) // 1024 * 128, torch.int32),        # (eval frames: depth-windowed order)
          'pflags': view(lay.pflags, lc, torch.uint8), 'farflags': view(lay.farflags, lc, torch.uint8),
          'knn_dfar2': view(lay.knn_dfar2, 1, torch.float32),
          'wsel': view(lay.wsel, lc, torch.uint8),                   # merge result per survivor (p / 8 + p / 255)

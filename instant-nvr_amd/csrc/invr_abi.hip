@@ -261,7 +261,7 @@ extern "C" int invr_workspace_layout(int64_t n_rays, int32_t n_samples, int64_t 
     auto off = [&](const void* p) { return (int64_t)(reinterpret_cast<const char*>(p) - base); };
     o->cap = w.cap; o->lcap = w.lcap;
     o->counters = off(w.counters); o->active_idx = off(w.active_idx); o->word_off = off(w.word_off); o->mask = off(w.mask);
-    o->pflags = off(w.pflags); o->farflags = off(w.farflags); o->knn_dfar2 = off(w.knn.dfar2);
+    o->pflags = off(w.pflags); o->farflags = off(w.farflags); o->knn_dfar2 = off(w.knn.dfar2); o->byte_off = off(w.byte_off);
     for (int p = 0; p < INVR_NUM_PARTS; ++p) {
         o->l_slot[p] = off(w.l_slot[p]); o->l_nn[p] = off(w.l_nn[p]); o->l_w[p] = off(w.l_w[p]);
         o->l_x[p] = off(w.l_x[p]); o->l_d[p] = off(w.l_d[p]); o->l_r[p] = off(w.l_r[p]);

@@ -6,7 +6,8 @@
 //   k_scan_blocks : exclusive scan of the tile counts inside super-blocks of 1024 tiles + the super-blocks' totals
 //   k_compact     : rank = totals of the super-blocks before + tile offset + wave prefix + popcount(mask below lane) -> active list
 // The active list is in ray-major / sample-minor order, exactly the order torch.nonzero gives,
-// so the train-time (Na*P, .) layouts of resd/tpts/tocc keep the reference's row order.
+// so the train-time (Na*P, .) layouts of resd/tpts/tocc keep the reference's row order.  Eval frames
+// (Workspace::ord_rows > 0) use the depth-windowed order of k_scan_blocks_win / k_compact_win below instead.
 #include <stdlib.h>
 #include "pipeline.h"
 
