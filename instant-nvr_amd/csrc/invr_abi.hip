@@ -56,7 +56,9 @@ GridDev make_grid_dev(const InvrGrid* g) {
                 d.mod32 = 1;
             // 24-bit multiplies: c and the multiplicands h0 <= 2^41 >> k, h1 <= y1 >> k, h2 <= y2 >> k below 2^24
             d.mod24 = d.mod32 && c < (1u << 24) && ((1ull << 41) >> k) < (1ull << 24) && (y1 >> k) < (1ull << 24) && (y2 >> k) < (1ull << 24);
-            d.xdelta = d.mod24 && d.T > (1ll << 14);         // (resolutions are <= 8192: |delta| < 2^13 < T / 2)
+            // x-corner delta fold (k_encode.hip:level_rowsum): resolutions are <= 8192, so |delta| < 2^13 < T / 2; its c0x corners take
+            // the TWO-round reduction (common.h:hash_mod24_2r), valid when the second fold already lands below 2^k (h2 = 0)
+            d.xdelta = d.mod24 && d.T > (1ll << 14) && y2 < (1ull << k);
         }
     }
     for (int l = 0; l < INVR_MAX_LEVELS; ++l) {

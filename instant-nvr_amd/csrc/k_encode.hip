@@ -611,7 +611,7 @@ __device__ __forceinline__ float level_rowsum(const GridDev& g, const float* __r
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const uint64_t X = hx[0] ^ hy[(k >> 1) & 1] ^ hz[k & 1];
-                const uint32_t r0 = hash_mod24(X, g.mod_k, g.mod_c, (uint32_t)g.T);
+                const uint32_t r0 = hash_mod24_2r(X, g.mod_k, g.mod_c, (uint32_t)g.T);
                 row[k] = r0;
                 int32_t r1 = (int32_t)r0 + (int32_t)m - 2 * (int32_t)((uint32_t)X & m);
                 r1 += (r1 < 0) ? (int32_t)g.T : 0;

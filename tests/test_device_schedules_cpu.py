@@ -199,3 +199,26 @@ def test_hashed_x_corner_delta_fold_equals_the_direct_hash():
             r1 = np.where(r1 < 0, r1 + T, r1)
             r1 = np.where(r1 >= T, r1 - T, r1)
             assert np.array_equal(r1, want), (T, res)
+
+
+def test_two_round_hash_reduction_equals_the_modulo():
+    """common.h:hash_mod24_2r — (key mod T) for T = 2^k + c by two folding rounds 2^k == -c (mod T) and one fix-up each way, valid when
+    c * h1 < 2^k (invr_abi.hip:make_grid_dev checks it on worst-case bounds; asserted here on the values): integer mirror against
+    Python's % on random 40-bit keys and on the extremes, for every table size the x-corner fold is enabled for (k >= 18)."""
+    rng = np.random.default_rng(33)
+    for T in (262147, 524309, 1048583, 2097169, 4194319):
+        k = T.bit_length() - 1
+        c = T - (1 << k)
+        mask = (1 << k) - 1
+        keys = np.concatenate([rng.integers(0, 1 << 40, 200000, dtype=np.int64), np.array([0, 1, T - 1, T, T + 1, (1 << 40) - 1, (1 << 41) - 1], dtype=np.int64),
+                               (np.arange(1, 2000, dtype=np.int64) * T) - 1, np.arange(1, 2000, dtype=np.int64) * T])
+        a0, h0 = keys & mask, keys >> k
+        assert int(h0.max()) < 1 << 24 and c < 1 << 24                      # operands of v_mul_u32_u24
+        y1 = c * h0
+        a1, h1 = y1 & mask, y1 >> k
+        assert int((c * h1).max()) < 1 << k                                 # the second fold lands below 2^k: no third round
+        v = a0 + c * h1 - a1
+        assert int(v.min()) > -(1 << k) and int(v.max()) < 2 * T
+        v = np.where(v < 0, v + T, v)
+        v = np.where(v >= T, v - T, v)
+        assert np.array_equal(v, keys % T), T
