@@ -34,6 +34,8 @@ def main():
         net = net.to(dev).eval()
         bnp, _ = scene.make_scene(res, res, seed=1, pose_scale=1.0, frame=17, cam_dist=1.8)
         gb = {k: v.to(dev) for k, v in scene.to_torch(bnp).items()}
+        junk = torch.full((int(res * res * S * 6),), float('nan'), device=dev)          # the outputs come from dirtied allocator blocks
+        del junk
         o = net.render_rays(gb, gb['ray_o'][0], gb['ray_d'][0], gb['near'][0], gb['far'][0], S, want_raw=True)
         v = None
         from invr import _abi
