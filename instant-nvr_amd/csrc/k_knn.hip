@@ -396,7 +396,12 @@ __device__ __forceinline__ void scan_sub16(const float4* sv, v2f px, v2f py, v2f
     for (int m0 = 0; m0 < 8; m0 += 4) {
         float4 A[4], B[4];
 #pragma unroll
+#ifdef EXP_KNN_B128      // experiment build (tools/build_variant.sh): the whole second record up front — the compiler otherwise reads {z0,z1} here and
+                         // {row0,row1} lazily inside the insert branch (one more exposed LDS round trip per insert)
+        for (int k = 0; k < 4; ++k) { A[k] = sv[(m0 + k) * 2]; B[k] = lds_ld4(sv + (m0 + k) * 2 + 1); }
+#else
         for (int k = 0; k < 4; ++k) { A[k] = sv[(m0 + k) * 2]; B[k] = sv[(m0 + k) * 2 + 1]; }   // wave-uniform addresses
+#endif
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const v2f dx = px - (v2f){A[k].x, A[k].y}, dy = py - (v2f){A[k].z, A[k].w}, dz = pz - (v2f){B[k].x, B[k].y};
