@@ -66,7 +66,7 @@ def test_hostsim_edge_cases(small_net):
     tools/hostsim_asan.sh — no kernel writes past its arrays), rays in any order."""
     from invr import scene
     cfg, net = small_net
-    bnp, _ = scene.make_scene(SMALL['RES'], SMALL['RES'], seed=0, cam_dist=1.8)
+    bnp, _ = scene.make_scene(64, 64, seed=0, cam_dist=1.8)                 # (a smaller frame than the kernels' tests: nine whole renders below)
     gb = scene.to_torch(bnp)
     ctx = net.prepare(gb)
     ro, rd, nr, fa = (gb[k][0] for k in ('ray_o', 'ray_d', 'near', 'far'))
@@ -83,7 +83,7 @@ def test_hostsim_edge_cases(small_net):
     assert int(o['stats'][0]) == 0 and float(o['rgb_map'].abs().max()) == 0 and float(o['raw'].abs().max()) == 0
     full = net.render_rays(ctx, ro, rd, nr, fa, 64, want_raw=True)
     na = int(full['stats'][0])
-    assert na > 8192 and int(full['stats'][6]) == 0
+    assert na > 4096 and int(full['stats'][6]) == 0
     rgb, raw = full['rgb_map'].clone(), full['raw'].clone()
     for cap in (1000, 4096, na - 1):                       # too small: reported, nothing written out of bounds
         o = net.render_rays(ctx, ro, rd, nr, fa, 64, max_active=cap)
