@@ -87,7 +87,10 @@ def _compile(job):
 
 
 def build(force=False, verbose=False, extra=()):
-    """-> path of the library (built when the sources changed)."""
+    """-> path of the library (built when the sources changed).  Every set of extra flags (sanitizer / experiment builds) has its own
+    directory, so that a test process never finds the library it has loaded replaced by another build."""
+    OUT = os.path.join(globals()['OUT'], hashlib.sha256(' '.join(extra).encode()).hexdigest()[:8]) if extra else globals()['OUT']
+    LIB = os.path.join(OUT, 'libinvr_hostsim.so')
     os.makedirs(OUT, exist_ok=True)
     stamp = os.path.join(OUT, 'digest.txt')
     dg = digest() + ' ' + ' '.join(extra)
