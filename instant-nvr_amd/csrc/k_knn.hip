@@ -187,12 +187,16 @@ extern "C" int invr_debug_knn_prof(unsigned long long* out, int reset) {
 #define KP_DECL long long kp_t0 = clock64(); long long kp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define KP(i) { const long long kp_now = clock64(); kp_acc[i] += kp_now - kp_t0; kp_t0 = kp_now; }
 #define KP_CNT(i) { kp_acc[i] += 1; }
+#define KP_MARK const long long kp_mark = kp_acc[11];
+#define KP_BAND(c) { if (c) kp_acc[7] += kp_acc[11] - kp_mark; }
 #define KP_FLUSH if ((threadIdx.x & 63) == 0) { for (int kp_i = 0; kp_i < 12; ++kp_i) atomicAdd(&g_knn_prof[kp_i], (unsigned long long)kp_acc[kp_i]); }
 #define KP_FLUSH_AT(base) if (threadIdx.x == 0 && blockIdx.x == 0) { for (int kp_i = 0; kp_i < 12; ++kp_i) atomicAdd(&g_knn_prof[(base) + kp_i], (unsigned long long)kp_acc[kp_i]); }
 #else
 #define KP_DECL
 #define KP(i)
 #define KP_CNT(i)
+#define KP_MARK
+#define KP_BAND(c)
 #define KP_FLUSH
 #define KP_FLUSH_AT(base)
 #endif
@@ -652,6 +656,7 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w) 
             if (__ballot(scan) == 0 || (dbg & 1)) continue;
             KP(2)
             KP_CNT(9)
+            KP_MARK
             // exact 4-NN: seed with the cluster of the wave's first scanning lane, then a pruned sweep that
             // walks outwards from the seed in Morton order (neighbouring indices are mostly neighbouring
             // patches, so the 4th-best bound tightens early); clusters are pruned as a whole and then per
@@ -693,6 +698,7 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w) 
             }
             KP(3)
             t.finish();
+            KP_BAND(__ballot(scan && t.d[0] < a.scene.near_hi2) == 0ull)      // (profiling builds: sub-cluster scans of part scans without a near lane)
 #pragma unroll
             for (int j = 0; j < KNN_K; ++j) t.i[j] = min(t.i[j] & 0x7FFFFFFF, len - 1);      // (a surviving placeholder would be a bug; never index out of the part)
             float wt[KNN_K];
