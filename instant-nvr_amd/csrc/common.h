@@ -318,6 +318,19 @@ __device__ __forceinline__ int wave_incl_sum_i(int x) {
     return x;
 }
 
+// OR over the 64 lanes (wave-uniform result) on the same network: the partial ORs travel down the rows and across them, lane 63 holds
+// the total.  ALL 64 lanes must be active.  (The __shfl_xor butterfly is six dependent ds_bpermute round trips per word.)
+__device__ __forceinline__ unsigned wave_or_u32(unsigned v) {
+    int x = (int)v;
+    x |= dpp_i<0x111, 0xF>(0, x);
+    x |= dpp_i<0x112, 0xF>(0, x);
+    x |= dpp_i<0x114, 0xF>(0, x);
+    x |= dpp_i<0x118, 0xF>(0, x);
+    x |= dpp_i<0x142, 0xA>(0, x);
+    x |= dpp_i<0x143, 0xC>(0, x);
+    return (unsigned)__builtin_amdgcn_readlane(x, 63);
+}
+
 // ---- kernel launchers (defined in the .hip files) ---------------------------------------------
 int launch_grid_encode_generic(const GridDev& g, const float* xyz, int64_t n, float* out, hipStream_t st);
 int launch_grid_encode_bwd_generic(const GridDev& g, const float* xyz, const float* gout, int64_t n, float* g_dense,

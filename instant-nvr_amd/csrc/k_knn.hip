@@ -184,13 +184,16 @@ extern "C" int invr_debug_knn_prof(unsigned long long* out, int reset) {
     if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_knn_prof), z, sizeof(z)) != hipSuccess) return 1; }
     return 0;
 }
-#define KP_DECL long long kp_t0 = clock64(); long long kp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define KP_DECL long long kp_t0 = clock64(); long long kp_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define KP(i) { const long long kp_now = clock64(); kp_acc[i] += kp_now - kp_t0; kp_t0 = kp_now; }
 #define KP_CNT(i) { kp_acc[i] += 1; }
 #define KP_MARK const long long kp_mark = kp_acc[11];
 #define KP_BAND(c) { if (c) kp_acc[7] += kp_acc[11] - kp_mark; }
-#define KP_FLUSH if ((threadIdx.x & 63) == 0) { for (int kp_i = 0; kp_i < 12; ++kp_i) atomicAdd(&g_knn_prof[kp_i], (unsigned long long)kp_acc[kp_i]); }
+#define KP_FLUSH if ((threadIdx.x & 63) == 0) { for (int kp_i = 0; kp_i < 16; ++kp_i) atomicAdd(&g_knn_prof[kp_i], (unsigned long long)kp_acc[kp_i]); }
 #define KP_FLUSH_AT(base) if (threadIdx.x == 0 && blockIdx.x == 0) { for (int kp_i = 0; kp_i < 12; ++kp_i) atomicAdd(&g_knn_prof[(base) + kp_i], (unsigned long long)kp_acc[kp_i]); }
+#define KP_SCAN_ARG , long long* kp_acc
+#define KP_SCAN_PASS , kp_acc
+#define KP_INS(c) { if (__ballot(c)) kp_acc[12] += 1; }      // pair records whose insert branch the wave executes
 #else
 #define KP_DECL
 #define KP(i)
@@ -199,6 +202,9 @@ extern "C" int invr_debug_knn_prof(unsigned long long* out, int reset) {
 #define KP_BAND(c)
 #define KP_FLUSH
 #define KP_FLUSH_AT(base)
+#define KP_SCAN_ARG
+#define KP_SCAN_PASS
+#define KP_INS(c)
 #endif
 
 // ---- per-frame prepare: Morton sort + clusters ------------------------------------------------------
@@ -395,7 +401,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // reads are issued together; the squared distances of two vertices are formed with packed fp32 ops
 // (v_pk_add/mul_f32 — each component is the same IEEE op sequence as ((p1-p2)**2).sum(-1)); one fp32
 // compare against the current 4th best guards the exact 64-bit-key inserts of both.
-__device__ __forceinline__ void scan_sub16(const float4* sv, v2f px, v2f py, v2f pz, Top4& t) {
+__device__ __forceinline__ void scan_sub16(const float4* sv, v2f px, v2f py, v2f pz, Top4& t KP_SCAN_ARG) {
 #pragma unroll
     for (int m0 = 0; m0 < 8; m0 += 4) {
         float4 A[4], B[4];
@@ -410,6 +416,7 @@ __device__ __forceinline__ void scan_sub16(const float4* sv, v2f px, v2f py, v2f
         for (int k = 0; k < 4; ++k) {
             const v2f dx = px - (v2f){A[k].x, A[k].y}, dy = py - (v2f){A[k].z, A[k].w}, dz = pz - (v2f){B[k].x, B[k].y};
             const v2f d2 = (dx * dx + dy * dy) + dz * dz;
+            KP_INS(fminf(d2.x, d2.y) <= t.worst())
             if (fminf(d2.x, d2.y) <= t.worst()) {
                 t.push_net(d2.x, __float_as_int(B[k].z));
                 t.push_net(d2.y, __float_as_int(B[k].w));
@@ -615,11 +622,8 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w) 
             unsigned long long mym = 0ull;
             if (maybe && c2 == 3u) mym = p == 0 ? cell_mask[0] : p == 1 ? cell_mask[1] : p == 2 ? cell_mask[2] : p == 3 ? cell_mask[3] : cell_mask[4];
             else if (maybe) mym = ~0ull;
-            unsigned mlo = (unsigned)mym, mhi = (unsigned)(mym >> 32);
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { mlo |= __shfl_xor(mlo, d); mhi |= __shfl_xor(mhi, d); }
-            const unsigned long long M = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)mhi) << 32) |
-                                         (unsigned)__builtin_amdgcn_readfirstlane((int)mlo);
+            // (every lane of the wave is active here: `live` / `maybe` are predicates, the control flow around is wave-uniform)
+            const unsigned long long M = ((unsigned long long)wave_or_u32((unsigned)(mym >> 32)) << 32) | wave_or_u32((unsigned)mym);
             const bool full = M == ~0ull || ncl > 64;
             const unsigned long long Mc = ncl >= 64 ? M : (M & ((1ull << ncl) - 1ull));
             // bounds on the nearest-vertex distance from the cluster records
@@ -675,7 +679,7 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w) 
             const int seed_c = __builtin_amdgcn_readlane(seed, __ffsll((long long)__ballot(scan)) - 1);
             if (full) {                                  // no bound to start from: the seed cluster is scanned unconditionally
 #pragma unroll 1
-                for (int s4 = 0; s4 < 4; ++s4) scan_sub16(sv + seed_c * 64 + s4 * 16, px2, py2, pz2, t);
+                for (int s4 = 0; s4 < 4; ++s4) scan_sub16(sv + seed_c * 64 + s4 * 16, px2, py2, pz2, t KP_SCAN_PASS);
             }
 #pragma unroll 1
             for (int k = full ? 1 : 0; (seed_c + k < ncl || seed_c - k >= 0) && !(dbg & 2); ++k) {
@@ -692,7 +696,7 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w) 
                         const bool need_s = need && aabb_dist2(px, py, pz, lds_ld4(sb + c * 8 + s4 * 2), lds_ld4(sb + c * 8 + s4 * 2 + 1)) <= t.worst();
                         if (__ballot(need_s) == 0) continue;
                         KP_CNT(11)
-                        scan_sub16(sv + c * 64 + s4 * 16, px2, py2, pz2, t);
+                        scan_sub16(sv + c * 64 + s4 * 16, px2, py2, pz2, t KP_SCAN_PASS);
                     }
                 }
             }

@@ -73,8 +73,8 @@ def main():
             n = Na // 64 * 64
             p = pts[order[:n]].reshape(-1, 64, 3)
             diag = np.linalg.norm(p.max(1) - p.min(1), axis=1).mean()
-            print('%-34s tickets %6d  part scans %7d  clusters visited %8d  sub-clusters scanned %8d (%.3f of ray-major; %d of them in part scans without a near lane)  mean ticket diagonal %.1f cm'
-                  % (name, prof[8], prof[9], prof[10], prof[11], prof[11] / max(base[11], 1), prof[7], 100 * diag))
+            print('%-34s tickets %6d  part scans %7d  clusters visited %8d  sub-clusters scanned %8d (%.3f of ray-major; %d of them in part scans without a near lane); insert branch taken for %d of %d pair records  mean ticket diagonal %.1f cm'
+                  % (name, prof[8], prof[9], prof[10], prof[11], prof[11] / max(base[11], 1), prof[7], prof[12], 8 * prof[11], 100 * diag))
 
         report('ray-major (today)', base, None)
         for R, D in [tuple(int(v) for v in a.split('x')) for a in os.environ.get('KNN_ORDERS', '64x16,64x32,16x16,256x16,64x8').split(',')]:
