@@ -13,7 +13,8 @@ sys.path.insert(0, ROOT)
 
 
 def main():
-    out, dev, res, S = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+    out, dev, res, S = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4].split(',')[0])
+    more = [int(x) for x in sys.argv[4].split(',')[1:]]              # further sample counts, rendered on a 1/4 ray subset: keys '<name>_<S>'
     ctx = contextlib.nullcontext()
     if len(sys.argv) > 5 and sys.argv[5] == 'hostsim':
         from tests.hostsim import harness
@@ -41,8 +42,16 @@ def main():
         from invr import _abi
         v = _abi.ws_views(*o['_ws'])
         na = int(o['stats'][0])
-        np.savez(out, rgb=o['rgb_map'].cpu().numpy(), acc=o['acc_map'].cpu().numpy(), raw=o['raw'].cpu().numpy(), occ=o['occ'].cpu().numpy(),
-                 stats=o['stats'].cpu().numpy(), act=v['active_idx'][:na].cpu().numpy())
+        res_d = dict(rgb=o['rgb_map'].cpu().numpy(), acc=o['acc_map'].cpu().numpy(), raw=o['raw'].cpu().numpy(), occ=o['occ'].cpu().numpy(),
+                     stats=o['stats'].cpu().numpy(), act=v['active_idx'][:na].clone().cpu().numpy())
+        sub = torch.arange(0, gb['ray_o'].shape[1], 4, device=dev)
+        for S2 in more:
+            o = net.render_rays(gb, gb['ray_o'][0][sub], gb['ray_d'][0][sub], gb['near'][0][sub], gb['far'][0][sub], S2, want_raw=True)
+            v = _abi.ws_views(*o['_ws'])
+            na = int(o['stats'][0])
+            res_d.update({'rgb_%d' % S2: o['rgb_map'].cpu().numpy(), 'raw_%d' % S2: o['raw'].cpu().numpy(), 'occ_%d' % S2: o['occ'].cpu().numpy(),
+                          'stats_%d' % S2: o['stats'].cpu().numpy(), 'act_%d' % S2: v['active_idx'][:na].clone().cpu().numpy()})
+        np.savez(out, **res_d)
 
 
 if __name__ == '__main__':

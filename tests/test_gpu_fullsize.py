@@ -205,6 +205,20 @@ def order_frames(tmp_path, dev, res, S, extra=()):
     return outs
 
 
+def check_more_sample_counts(a, b, counts):
+    """every power-of-two sample count the windowed order takes (8 ... 1024: 1 ... 128 windows per ray, 1024 ... 8 rays per block)"""
+    for S2 in counts:
+        act0, act1 = a['act_%d' % S2].astype(np.int64), b['act_%d' % S2].astype(np.int64)
+        assert act0.size > 200 and np.array_equal(act0, np.sort(act0)) and np.array_equal(np.sort(act1), act0), S2
+        rows = 8192 // S2
+        ray, smp = act1 // S2, act1 % S2
+        key = ((ray // rows) * (S2 // 8) + smp // 8) * 8192 + (ray % rows) * 8 + smp % 8
+        assert bool((key[1:] > key[:-1]).all()), S2
+        assert np.array_equal(a['stats_%d' % S2][:12], b['stats_%d' % S2][:12]), S2
+        for k in ('rgb', 'raw', 'occ'):
+            assert np.array_equal(a['%s_%d' % (k, S2)], b['%s_%d' % (k, S2)]), (k, S2)
+
+
 def check_order_frames(a, b, S, min_survivors):
     na = int(a['stats'][0])
     assert na > min_survivors and na == int(b['stats'][0]) and a['stats'][6] == 0 and b['stats'][6] == 0
@@ -224,5 +238,6 @@ def test_survivor_order_does_not_change_the_frame(tmp_path):
     """Eval frames rank their survivors by depth window inside blocks of 64 rays (csrc/k_cull.hip) so that a KNN ticket /
     an encoder wave is one compact slab; the pair lists, the merge and the compositing only see slots.  The 512x512x128 bench frame
     (2^12-row tables, seeded) rendered in both orders: same survivors, same counts, rgb_map / acc_map / raw / occ bit-identical."""
-    a, b = order_frames(tmp_path, DEV, 512, 128)
+    a, b = order_frames(tmp_path, DEV, 512, '128,8,16,32,64,256')
     check_order_frames(a, b, 128, 1000000)
+    check_more_sample_counts(a, b, (8, 16, 32, 64, 256))

@@ -102,5 +102,6 @@ def test_hostsim_survivor_order_does_not_change_the_frame(tmp_path):
     """tests/test_gpu_fullsize.py:test_survivor_order_does_not_change_the_frame on a 96 x 96 x 64 frame, both processes on the wave
     machine (the full 512 x 512 x 128 frame was compared this way once, by hand: bit-identical)."""
     import tests.test_gpu_fullsize as F
-    a, b = F.order_frames(tmp_path, 'cpu', 96, 64, extra=('hostsim',))
+    a, b = F.order_frames(tmp_path, 'cpu', 96, '64,8,256', extra=('hostsim',))
     F.check_order_frames(a, b, 64, 12000)
+    F.check_more_sample_counts(a, b, (8, 256))          # (16 and 1024 were run once by hand: equal)
