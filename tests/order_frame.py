@@ -49,7 +49,7 @@ def main():
             o = net.render_rays(gb, gb['ray_o'][0][sub], gb['ray_d'][0][sub], gb['near'][0][sub], gb['far'][0][sub], S2, want_raw=True)
             v = _abi.ws_views(*o['_ws'])
             na = int(o['stats'][0])
-            res_d.update({'rgb_%d' % S2: o['rgb_map'].cpu().numpy(), 'raw_%d' % S2: o['raw'].cpu().numpy(), 'occ_%d' % S2: o['occ'].cpu().numpy(),
+            res_d.update({'rgb_%d' % S2: o['rgb_map'].cpu().numpy(), 'occ_%d' % S2: o['occ'].cpu().numpy(),      # (raw = 16 B per ray-sample: left out)
                           'stats_%d' % S2: o['stats'].cpu().numpy(), 'act_%d' % S2: v['active_idx'][:na].clone().cpu().numpy()})
         np.savez(out, **res_d)
 

@@ -215,7 +215,7 @@ def check_more_sample_counts(a, b, counts):
         key = ((ray // rows) * (S2 // 8) + smp // 8) * 8192 + (ray % rows) * 8 + smp % 8
         assert bool((key[1:] > key[:-1]).all()), S2
         assert np.array_equal(a['stats_%d' % S2][:12], b['stats_%d' % S2][:12]), S2
-        for k in ('rgb', 'raw', 'occ'):
+        for k in ('rgb', 'occ'):
             assert np.array_equal(a['%s_%d' % (k, S2)], b['%s_%d' % (k, S2)]), (k, S2)
 
 
