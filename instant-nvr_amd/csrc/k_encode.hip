@@ -576,7 +576,7 @@ int launch_part_encode_bwd_lists(const GridDev& g, const float* x_soa, const flo
 // sum commutes with the trilinear interpolation: a derived (rows,) table of row sums (rebuilt by the host
 // whenever the tables change) shrinks the 1.09 GB of tables to 68 MB — resident in the 256 MB Infinity
 // Cache — and each corner fetch to one dword.  Thread-per-pair: the 64 lanes of a wave hold 64 consecutive
-// pairs of the list (consecutive samples of a ray), so on the dense levels neighbouring lanes fall into the
+// pairs of the list (eval frames: one depth slab of a few neighbouring rays, k_cull.hip; else consecutive samples of a ray), so neighbouring lanes fall into the
 // same / adjacent 64-byte lines; the level constants are wave-uniform (scalar registers).
 #define RS_BLOCK 256
 // one level of one point through the row-sum table (wave-uniform level l)

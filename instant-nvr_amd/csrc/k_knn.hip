@@ -499,7 +499,7 @@ struct KnnLds { int voff[INVR_NUM_PARTS], coff[INVR_NUM_PARTS], soff[INVR_NUM_PA
 // Outputs per survivor slot: pflags / farflags bytes and, for every flagged part, the 4 neighbour rows and weights at
 // l_nn[p][slot] / l_w[p][slot]; k_pair_lists then builds the dense per-part lists of flagged slots.  (The lists used to be
 // appended here, aggregated per 1024-point workgroup tile: the two barriers per tile made every wave wait for the slowest of
-// the 16 — 64 consecutive survivors are one depth segment of one ray, and the segments differ widely in how many parts they
+// the 16 — 64 consecutive survivors are one depth slab of a few rays (ray-major order: depth segments of a few rays), and they differ widely in how many parts they
 // come near — 29 % of the kernel's wave time on a whole frame and 51 % on a 1/8 shard, tools/knn_phase_prof.py.  Now a wave
 // never waits for another one.)
 // KNN_DBG: ablation switch of the profiling builds only (tools/knn_phase_prof.sh: -DKNN_DBG=1 no exact scans, 2 seed cluster
@@ -741,7 +741,7 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w) 
 }
 
 // The per-part pair lists from the flag bytes k_knn_pairs left per survivor: l_slot[p][0..count) = the survivors flagged for
-// part p, ASCENDING (a deterministic order: consecutive pairs are consecutive samples of a ray); neighbours and weights stay
+// part p, ASCENDING (a deterministic order: consecutive pairs are neighbours in space, k_cull.hip); neighbours and weights stay
 // where the KNN wrote them — at the survivor's slot.  One workgroup per group of PAIR_GROUP slots; its list offsets are the sums
 // of the per-group counts the KNN accumulated (gcount) over the groups before it — no atomics here (device-scope atomics on one
 // address serialise at tens of ns each on the 8-XCD part: 1167 claims per part cost this kernel 90 us).  The workgroup of the
