@@ -556,10 +556,22 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w) 
     const int n_cls = min(16, (int)gridDim.x), my_cls = (int)blockIdx.x % n_cls;
     int32_t* my_counter = w.counters + CNT_TICKETS + my_cls * 32;
     int ticket = (int)blockIdx.x * (KNN_T / 64) + (int)(threadIdx.x >> 6);
-    while ((int64_t)ticket * 64 < na) {
+#ifdef EXP_KNN_TSIZE     // experiment build (tools/build_variant.sh, unmeasured): a frame with fewer than ~1.5 tickets per resident wave — a 1/8
+                         // shard: 4687 tickets for 4096 waves, two latency-bound rounds for 591 of them — deals every wave one or two EQUAL,
+                         // smaller tickets instead (results do not depend on the ticket size)
+    int tsize = 64;
+    {
+        const long long per_wave = ((long long)na + n_wave - 1) / n_wave;
+        if (per_wave <= 64) tsize = max(32, (int)per_wave);
+        else if (per_wave <= 96) tsize = max(32, (int)((per_wave + 1) / 2));
+    }
+#else
+    constexpr int tsize = 64;
+#endif
+    while ((int64_t)ticket * tsize < na) {
         KP_CNT(8)
-        const int64_t slot = (int64_t)ticket * 64 + lane;
-        const bool live = slot < na;
+        const int64_t slot = (int64_t)ticket * tsize + lane;
+        const bool live = lane < tsize && slot < na;
         float px = 0, py = 0, pz = 0;
         if (live) sample_pose_point(a, w.active_idx[slot], px, py, pz, nullptr, nullptr);
         unsigned flags = 0, farflags = 0;
@@ -722,7 +734,22 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w) 
             const int c = __popcll(__ballot((flags >> p) & 1u));
             if (lane == p) my_cnt = c;
         }
+#ifdef EXP_KNN_TSIZE     // a ticket of tsize < 64 survivors may straddle two slot groups: lanes 0..4 count the first group's pairs, 8..12 the second's
+        {
+            const int64_t g0 = (slot - lane) / PAIR_GROUP;
+            my_cnt = 0;
+#pragma unroll
+            for (int p = 0; p < INVR_NUM_PARTS; ++p) {
+                const bool f = (flags >> p) & 1u;
+                const int c0 = __popcll(__ballot(f && slot / PAIR_GROUP == g0)), c1 = __popcll(__ballot(f && slot / PAIR_GROUP != g0));
+                if (lane == p) my_cnt = c0;
+                if (lane == 8 + p) my_cnt = c1;
+            }
+            if (my_cnt) atomicAdd(&w.gcount[(g0 + (lane >> 3)) * INVR_NUM_PARTS + (lane & 7)], my_cnt);
+        }
+#else
         if (my_cnt) atomicAdd(&w.gcount[(slot - lane) / PAIR_GROUP * INVR_NUM_PARTS + lane], my_cnt);      // (64 | PAIR_GROUP; not returned)
+#endif
         if (live) {
             w.pflags[slot] = (uint8_t)flags;
             w.farflags[slot] = (uint8_t)farflags;
