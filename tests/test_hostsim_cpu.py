@@ -4,6 +4,8 @@ tests/test_gpu_parity.py at the golden sizes — the same test bodies, against t
 covers that the other CPU tests cannot: the logic of the kernels themselves (index arithmetic, list building, merge rule, wave
 scans, MFMA operand layouts, LDS carving) on a box without a GPU.  What it does not cover: timing, the hardware's transcendental
 pipes (libm here), real concurrency.  Test infrastructure only — the product never loads the host build."""
+import os
+
 import pytest
 import torch
 
@@ -32,9 +34,13 @@ def hostsim():
             m.DEV = d
 
 
+# The default CPU suite leaves out the slowest bodies (8-10 s each on the wave machine; HOSTSIM_FULL=1 runs everything — they pass)
+SLOW = set() if os.environ.get('HOSTSIM_FULL') else {'test_network_wrapper_optimisation_steps', 'test_network_forward_on_points',
+                                                     'test_reference_step_form_with_disabled_grad_scaler'}
 for _m, _names in BORROWED:
     for _n in (_names or [n for n in dir(_m) if n.startswith('test_')]):
-        globals()['test_hostsim__' + _n[5:]] = getattr(_m, _n)
+        if _n not in SLOW:
+            globals()['test_hostsim__' + _n[5:]] = getattr(_m, _n)
 
 
 def test_hostsim_results_do_not_depend_on_lane_or_wave_order():
