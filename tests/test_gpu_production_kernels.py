@@ -98,12 +98,11 @@ def test_knn_pairs_vs_brute_force_whole_frame(fr):
     # the (ray-sample -> slot) map the compositing uses: rank of the sample's mask word / byte + popcount of the bits below it
     tab = torch.tensor([bin(x).count('1') for x in range(256)], device=DEV)
     word, bit = v['mask'][act >> 6], act & 63
-    if torch.equal(act, asc):
-        below = word & ((torch.ones_like(bit) << bit) - 1)
-        slot = v['word_off'][act >> 6].long() + sum(tab[(below >> (8 * k)) & 255] for k in range(8))
-    else:
-        slot = v['byte_off'][act >> 3].long() + tab[((word >> (bit & ~7)) & 255) & ((torch.ones_like(bit) << (bit & 7)) - 1)]
-    assert torch.equal(slot, torch.arange(Na, device=DEV))
+    below = word & ((torch.ones_like(bit) << bit) - 1)
+    slot_w = v['word_off'][act >> 6].long() + sum(tab[(below >> (8 * k)) & 255] for k in range(8))               # ray-major calls
+    slot_b = v['byte_off'][act >> 3].long() + tab[((word >> (bit & ~7)) & 255) & ((torch.ones_like(bit) << (bit & 7)) - 1)]     # windowed calls
+    ar = torch.arange(Na, device=DEV)
+    assert torch.equal(slot_b, ar) if not torch.equal(act, asc) else (torch.equal(slot_w, ar) or torch.equal(slot_b, ar))
     nn, d2, w, dist = stages.knn_neighbors(f['ctx'].scene, f['pts'])
     pf, ff = v['pflags'][:Na].int(), v['farflags'][:Na].int()
     assert int((pf & ff).max()) == 0
