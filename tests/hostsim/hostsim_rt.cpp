@@ -246,9 +246,13 @@ void launch_impl(dim3 grid, dim3 block, size_t shmem, void (*fn)(void*), void* a
     g_fn = fn;
     g_arg = arg;
     const int n_waves = (int)((nt + 63) / 64);
-    for (unsigned bz = 0; bz < grid.z; ++bz)
-        for (unsigned by = 0; by < grid.y; ++by)
-            for (unsigned bx = 0; bx < grid.x; ++bx) {
+    // HOSTSIM_BLOCK_ORDER=reverse: the workgroups of a launch from the last to the first (no kernel may rely on the dispatch order)
+    static const bool block_reverse = getenv("HOSTSIM_BLOCK_ORDER") && !strcmp(getenv("HOSTSIM_BLOCK_ORDER"), "reverse");
+    for (unsigned bz0 = 0; bz0 < grid.z; ++bz0)
+        for (unsigned by0 = 0; by0 < grid.y; ++by0)
+            for (unsigned bx0 = 0; bx0 < grid.x; ++bx0) {
+                const unsigned bx = block_reverse ? grid.x - 1 - bx0 : bx0, by = block_reverse ? grid.y - 1 - by0 : by0,
+                               bz = block_reverse ? grid.z - 1 - bz0 : bz0;
                 for (size_t t = 0; t < nt; ++t) {
                     Fiber* f = &g_fib[t];
                     f->id.tid = uint3{(unsigned)(t % block.x), (unsigned)(t / block.x % block.y), (unsigned)(t / ((size_t)block.x * block.y))};
