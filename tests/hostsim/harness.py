@@ -22,10 +22,15 @@ def _workspace(self, nbytes, device):
         off = (-raw.data_ptr()) % 256
         self._ws_raw, self._ws = raw, raw[off:off + nbytes]
     self._ws_gen = getattr(self, '_ws_gen', 0) + 1
+    if _WS_FILL is not None:                               # HOSTSIM_WS_FILL=<byte>: every hand-out is junk (nothing may read what it has not written)
+        self._ws.fill_(_WS_FILL)
     if _ASAN is not None:                                  # sanitizer runs: forget the red zones of the previous call's layout
         _ASAN.__asan_unpoison_memory_region(C.c_void_p(self._ws.data_ptr()), C.c_size_t(self._ws.numel()))
     return self._ws
 
+
+import os as _os
+_WS_FILL = int(_os.environ['HOSTSIM_WS_FILL'], 0) if _os.environ.get('HOSTSIM_WS_FILL') else None
 
 try:
     _ASAN = C.CDLL(None)
