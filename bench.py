@@ -494,11 +494,38 @@ def main():
         out = net.render_rays(ctx, ro, rd, nr, fr, S, want_raw=want_raw)
         return out, torch.cat([out['rgb_map'], out['acc_map'][:, None]], 1)
 
+    # N > 1: ONE all-gather in flight — the 4 MB exchange of frame f (RCCL, its own stream) runs beside the kernels of frame f+1 and is
+    # joined when frame f+1's exchange has been issued; every frame's full map is complete before the fence that ends a timed region
+    # (INVR_BENCH_SYNC_GATHER=1: join every exchange before the next frame starts)
+    overlap = [world > 1 and not os.environ.get('INVR_BENCH_SYNC_GATHER')]
+    pend, last_full = [None], [None]
+
+    def gather(rgba):
+        if overlap[0]:
+            try:
+                nxt = idist.gather_maps_async(rgba.clone(), n_rays, rank, world)       # (a copy: the next replay overwrites the graph's buffer)
+            except Exception as e:                  # keep the bench alive: the synchronous exchange measures the same work
+                sys.stderr.write('asynchronous all-gather failed (%s); joining every exchange before the next frame\n' % e)
+                overlap[0] = False
+        if not overlap[0]:
+            if pend[0] is not None:
+                pend[0].result()
+                pend[0] = None
+            last_full[0] = idist.gather_maps(rgba, n_rays, rank, world)
+            return last_full[0]
+        if pend[0] is not None:
+            last_full[0] = pend[0].result()
+        pend[0] = nxt
+        return last_full[0]
+
     def step():
         out, rgba = render()
-        return out, idist.gather_maps(rgba, n_rays, rank, world)
+        return out, gather(rgba)
 
     def fence():
+        if pend[0] is not None:
+            last_full[0] = pend[0].result()
+            pend[0] = None
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -529,11 +556,11 @@ def main():
                 cnt[0] += 1
                 if len(slots) == 1:
                     g.replay()
-                    return g_out, idist.gather_maps(g_rgba, n_rays, rank, world)
+                    return g_out, gather(g_rgba)
                 strm.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(strm):
                     g.replay()
-                    return g_out, idist.gather_maps(g_rgba, n_rays, rank, world)
+                    return g_out, gather(g_rgba)
             out, full = step()
         except Exception as e:                       # keep the bench alive: eager launches measure the same work
             sys.stderr.write('hipGraph capture failed (%s); falling back to eager launches\n' % e)
@@ -541,7 +568,7 @@ def main():
 
             def step():
                 out, rgba = render()
-                return out, idist.gather_maps(rgba, n_rays, rank, world)
+                return out, gather(rgba)
             out, full = step()
         fence()
     # The timed region is EXACTLY K steps between two fences.  A frame takes ~3 ms, so one region is a few tens of
@@ -578,7 +605,8 @@ def main():
         dt = float(t.item())
     stats = out['stats'].cpu().numpy().astype('int64')
     assert stats[6] == 0, 'workspace overflow'
-    assert bool(torch.isfinite(full).all())
+    full = last_full[0]
+    assert full is not None and bool(torch.isfinite(full).all())
     if world > 1:
         st = torch.from_numpy(stats).to(dev)
         dist.all_reduce(st)
@@ -636,7 +664,7 @@ def main():
                 'pairs_per_active_sample': float(stats_all[1:6].sum()) / max(int(stats_all[0]), 1),
                 'colour_mlp_pairs_per_part_rank0': winners,
                 'parameters': int(n_params), 'raw_occ_materialised': want_raw, 'hip_graph': use_graph, 'frames_in_flight': (max(1, args.in_flight) if use_graph else 1),
-                'parallelism': 'tile-cyclic ray shards x%d, full replicas, 1 all-gather/frame' % world,
+                'parallelism': 'tile-cyclic ray shards x%d, full replicas, 1 all-gather/frame%s' % (world, ' (in flight beside the next frame)' if overlap[0] else ''),
                 'rays_per_sec': n_rays * args.steps / dt,
                 'note': 'value counts every ray-sample of the frame; %.1f %% of them survive the near-surface cull (the camera sits at %.1f m so '
                         'that the body fills the frame) — survivors_per_sec is the rate of the samples that reach the networks'

@@ -71,6 +71,39 @@ def gather_maps(local_rgba, n_rays, rank, world, tile=DEFAULT_TILE, group=None):
     return recv.index_select(0, src)
 
 
+class PendingFrame:
+    """An all-gather in flight (gather_maps_async): `result()` joins it and returns the full (n_rays, 4) map."""
+
+    def __init__(self, work, recv, src, keep):
+        self.work, self.recv, self.src, self.keep = work, recv, src, keep
+
+    def result(self):
+        if self.work is not None:
+            self.work.wait()                       # nccl: orders the current stream behind the collective (no host synchronisation)
+            self.work = None
+        return self.recv if self.src is None else self.recv.index_select(0, self.src)
+
+
+def gather_maps_async(local_rgba, n_rays, rank, world, tile=DEFAULT_TILE, group=None):
+    """gather_maps with the collective left in flight: the caller renders the next frame beside it and calls `.result()` when it needs
+    the full map (a frame server keeps one gather pending: the 4 MB exchange of frame f overlaps the kernels of frame f+1).  The send
+    buffer is kept alive by the returned object."""
+    if world == 1 and not FORCE_COLLECTIVES():
+        return PendingFrame(None, local_rgba, None, None)
+    dev = local_rgba.device
+    mx, src = gather_plan(n_rays, world, tile, dev)
+    if local_rgba.shape[0] == mx:
+        send = local_rgba.contiguous()
+    else:
+        send = torch.zeros(mx, 4, device=dev, dtype=local_rgba.dtype)
+        send[:local_rgba.shape[0]] = local_rgba
+    if dist.get_backend(group) == 'gloo' and send.is_cuda:      # gloo (tests) gathers through host memory: synchronous
+        return PendingFrame(None, gather_maps(local_rgba, n_rays, rank, world, tile, group), None, None)
+    recv = torch.empty(world * mx, 4, device=dev, dtype=local_rgba.dtype)
+    work = dist.all_gather_into_tensor(recv, send, group=group, async_op=True)
+    return PendingFrame(work, recv, src, send)
+
+
 def render_frame(render_fn, batch, rank, world, tile=DEFAULT_TILE, group=None):
     """render_fn(ray_o, ray_d, near, far) -> (rgb_map (n,3), acc_map (n,)) on this rank's rays.
     Returns the full-frame (rgb_map (n_rays,3), acc_map (n_rays,)) on every rank."""

@@ -61,6 +61,38 @@ def test_tile_partition_is_exact_cover():
         assert sum(counts) == n and max(counts) - min(counts) <= tile
 
 
+def _async_worker(rank, world, port, n, tile, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        # a frame server with ONE gather in flight: frame f's exchange is joined after frame f+1 has been rendered and sent
+        frames = [make_batch(n, seed=s) for s in range(4)]
+        idx = idist.tile_indices(n, rank, world, tile)
+        pending, got = None, []
+        for b in frames:
+            rgb, acc = fake_render(b['ray_o'][0][idx], b['ray_d'][0][idx], b['near'][0][idx], b['far'][0][idx])
+            nxt = idist.gather_maps_async(torch.cat([rgb, acc[:, None]], 1), n, rank, world, tile)
+            if pending is not None:
+                got.append(pending.result())
+            pending = nxt
+        got.append(pending.result())
+        ok = True
+        for b, full in zip(frames, got):
+            ref_rgb, ref_acc = fake_render(b['ray_o'][0], b['ray_d'][0], b['near'][0], b['far'][0])
+            ok = ok and torch.equal(full[:, :3], ref_rgb) and torch.equal(full[:, 3], ref_acc)
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_async_gather_world2_one_frame_in_flight():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_async_worker, args=(2, _free_port(), 1000, 64, ret), nprocs=2, join=True)
+    assert all(ret[r] for r in range(2)), dict(ret)
+
+
 def test_gather_world2_ragged():
     _run(2, 1000, 64)          # 16 tiles, last one ragged (40 rays)
 
