@@ -69,6 +69,17 @@ def _worker(port, out_path):
         torch.cuda.synchronize()
         res['gather_equal'] = bool(torch.equal(full, ref))
         res['gather_shape'] = tuple(full.shape)
+        # the frame server's form (bench.py --gpus N > 1): ONE exchange in flight, joined after the next frame has been replayed and sent
+        pend, fulls = None, []
+        for _ in range(4):
+            g.replay()
+            nxt = idist.gather_maps_async(rgba.clone(), n, 0, 1)
+            if pend is not None:
+                fulls.append(pend.result())
+            pend = nxt
+        fulls.append(pend.result())
+        torch.cuda.synchronize()
+        res['async_gather_equal'] = len(fulls) == 4 and all(bool(torch.equal(f, ref)) for f in fulls)
         # training: averaged gradients through the reducer (AVG over one rank = identity)
         finals = []
         for use_reducer in (True, False):
@@ -122,5 +133,6 @@ def test_rccl_collectives_execute_on_one_gpu(tmp_path):
     res = torch.load(out)
     assert res.get('ok'), res
     assert res['gather_equal'] and res['gather_shape'][1] == 4
+    assert res['async_gather_equal']
     assert res['reducer_pending_after_step'] == 0                      # the optimiser pre-hook joined every async all-reduce
     assert res['train_worst_abs_diff'] <= 2 * 3 * 1e-3 * 1.01 and res['loss'] == res['loss']
