@@ -57,3 +57,25 @@ def test_struct_sizes_match_header():
     for i, t in enumerate((_abi.InvrGrid, _abi.InvrMlp, _abi.InvrPart, _abi.InvrModel, _abi.InvrScene, _abi.InvrWsLayout, _abi.InvrMlpBwdOut,
                            _abi.InvrAdamTensor, _abi.InvrTrainGrads)):
         assert L.invr_sizeof(i) == C.sizeof(t), t
+
+
+def test_product_path_has_no_cpu_route():
+    """The render path is the HIP library or nothing: the binding refuses host tensors, and nothing in the product tree, bench.py or
+    __graft_entry__.py knows about the test-only host build of the kernels (tests/hostsim) or imports the oracle outside bench.py's
+    cpu_baseline leg / smoke()'s check."""
+    import os
+    import re
+    import pytest
+    import torch
+    from invr import _abi
+    with pytest.raises(AssertionError):
+        _abi.ptr(torch.zeros(4))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = [os.path.join(root, 'bench.py'), os.path.join(root, '__graft_entry__.py')]
+    for d, _, names in os.walk(os.path.join(root, 'instant-nvr_amd')):
+        files += [os.path.join(d, n) for n in names if n.endswith(('.py', '.hip', '.h'))]
+    for f in files:
+        text = open(f).read()
+        assert 'hostsim' not in text.lower(), f
+        if not f.endswith(('bench.py', '__graft_entry__.py')):
+            assert not re.search(r'^\s*(from|import)\s+(oracle|tests)\b', text, re.M), f
