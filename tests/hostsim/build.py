@@ -19,7 +19,16 @@ CSRC = os.path.join(ROOT, 'instant-nvr_amd', 'csrc')
 OUT = os.path.join(HERE, '_build')
 LIB = os.path.join(OUT, 'libinvr_hostsim.so')
 CXX = os.environ.get('HOSTSIM_CXX') or '/opt/rocm/lib/llvm/bin/clang++'
-FLAGS = ['-x', 'c++', '-std=c++17', '-O1', '-g0', '-fPIC', '-fno-strict-aliasing', '-ffp-contract=off', '-mfma', '-mavx2',
+def _cpu_has(flag):
+    try:
+        return any(flag in line.split() for line in open('/proc/cpuinfo') if line.startswith('flags'))
+    except OSError:
+        return False
+
+
+# -ffp-contract=off as the product build (FMAs only where the source says fmaf()); -mfma turns fmaf() into the instruction where the host
+# has it (libm's fmaf is exact too, only slower)
+FLAGS = ['-x', 'c++', '-std=c++17', '-O1', '-g0', '-fPIC', '-fno-strict-aliasing', '-ffp-contract=off'] + (['-mfma'] if _cpu_has('fma') else []) + [
          '-Wno-unused-function', '-Wno-unused-value', '-Wno-unknown-pragmas', '-Wno-pass-failed',
          '-I', HERE, '-I', CSRC]
 
