@@ -58,13 +58,13 @@ def activate(extra_flags=()):
     """HOSTSIM_FLAGS in the environment adds compiler flags (tools/hostsim_asan.sh: the sanitizer builds)."""
     import os
     import platform
-    if platform.machine() != 'x86_64' or not os.path.exists(build.CXX if 'build' in globals() else '/opt/rocm/lib/llvm/bin/clang++'):
+    from . import build
+    if platform.machine() != 'x86_64' or not os.path.exists(build.CXX):
         import pytest
         pytest.skip('the wave machine needs an x86-64 host and the ROCm clang++ (tests/hostsim/hostsim_rt.cpp switches fibers in assembly)')
     extra_flags = tuple(extra_flags) + tuple(os.environ.get('HOSTSIM_FLAGS', '').split())
     from invr import _abi
     from invr.network import Network
-    from . import build
     path = build.build(extra=tuple(extra_flags))
     from invr import driver
     make_opt = driver.make_optimizer
