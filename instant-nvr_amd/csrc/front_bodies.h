@@ -1,0 +1,222 @@
+// Device bodies shared by the stand-alone kernels (k_cull.hip, k_warp.hip) and by the two fused front-of-frame launches of
+// k_knn.hip (k_front_scene: KNN index build + cull cell mask + per-vertex matrices + deformer t-slices as workgroup ranges of ONE
+// launch; k_front_cull: lattice-cell classification + cull flags as workgroup ranges of one launch).  A fork / join through a side
+// stream costs 10-17 us per edge under hipGraph replay on this runtime (gpurun_out/r4c: 74 us of a 0.56 ms ray shard), launches
+// that follow each other on one stream start back to back — so independent small kernels share a launch instead of a stream.
+#pragma once
+#include <stdlib.h>
+#include "pipeline.h"
+
+#define CULL_BLOCK 256
+#define CULL_PER 4                      // ray-samples per thread
+#define CULL_TILE (CULL_BLOCK * CULL_PER)
+
+// Per-frame cell mask of the distance volume: the trilinear value of a sample is a convex combination of the 8
+// corners of its cell (weights in [0,1], sum 1 within 4e-7), so a cell whose corners are all >= thresh*(1+1e-5)
+// cannot hold a survivor — 93 % of the samples of the bench frame then skip the 8 taps.  Cell (x0,y0,z0) pairs
+// with corner x1 = min(x0+1, dx-1) exactly as the border-clamped sampler does, so there are dx*dy*dz cells.
+// The live cells are also appended to a list (wave-aggregated: one atomic per wave), which the KNN's per-cell classification
+// (k_knn_voxel_class, side stream) walks instead of the whole lattice.
+// (body: `i` = the thread's cell; called with whole waves by k_cull_cells and by the scene-setup launch k_front_scene, k_knn.hip)
+__device__ __forceinline__ void cull_cells_body(const VolDev& v, float thresh_hi, uint8_t* __restrict__ mask, int32_t* __restrict__ live,
+                                                int32_t* __restrict__ n_live, uint8_t* __restrict__ voxcls, const int i) {
+    const bool in = i < v.dx * v.dy * v.dz;
+    bool keep = false;
+    if (in) {
+    const int z0 = i % v.dz, y0 = (i / v.dz) % v.dy, x0 = i / (v.dz * v.dy);
+    const int x1 = min(x0 + 1, v.dx - 1), y1 = min(y0 + 1, v.dy - 1), z1 = min(z0 + 1, v.dz - 1);
+    float m = __builtin_inff();
+    bool nan = false;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int xx = (k & 4) ? x1 : x0, yy = (k & 2) ? y1 : y0, zz = (k & 1) ? z1 : z0;
+        const float d = v.data[(((int64_t)xx * v.dy + yy) * v.dz + zz) * v.c + (v.c - 1)];
+        nan = nan || d != d;
+        m = fminf(m, d);
+    }
+    keep = m < thresh_hi || nan;
+    mask[i] = keep ? 1 : 0;
+    }
+    if (live) {
+        const unsigned long long b = __ballot(keep);
+        if (b) {
+            const int lane = threadIdx.x & 63;
+            int base = 0;
+            if (lane == __ffsll((long long)b) - 1) base = atomicAdd(n_live, __popcll(b));
+            base = __shfl(base, __ffsll((long long)b) - 1);
+            if (keep) live[base + __popcll(b & ((1ull << lane) - 1ull))] = i;
+        }
+        // class "undecided" for every cell: k_knn_pairs maps a point to its cell with slightly different arithmetic than the
+        // sampler, so a survivor on a cell face may look up a neighbour that is not live — and is never classified
+        if (in && voxcls) {
+#pragma unroll
+            for (int p = 0; p < INVR_NUM_PARTS; ++p) voxcls[(int64_t)i * INVR_NUM_PARTS + p] = 0;
+        }
+    }
+}
+
+// distance channel of the pose-space volume at (px,py,pz): sample_volume_dev<1> (same arithmetic, bit for bit)
+// with the cell-mask early-out; returns +inf for samples in masked-out cells (they fail pn < thresh either way)
+template <typename IDX>        // IDX = uint32_t when dx*dy*dz*c < 2^31 (host-checked): 64-bit index multiplies are quarter rate
+__device__ __forceinline__ float cull_distance(const VolDev& v, const uint8_t* __restrict__ mask, float px, float py, float pz, const float* rext) {
+    const float b0x = v.bounds[0], b0y = v.bounds[1], b0z = v.bounds[2];
+    const float b1x = v.bounds[3], b1y = v.bounds[4], b1z = v.bounds[5];
+    // (p - b0) / (b1 - b0): the IEEE quotients through the per-thread reciprocals of the three extents (common.h:div_exact)
+    float gx = div_exact(px - b0x, b1x - b0x, rext[0]) * 2.0f - 1.0f;
+    float gy = div_exact(py - b0y, b1y - b0y, rext[1]) * 2.0f - 1.0f;
+    float gz = div_exact(pz - b0z, b1z - b0z, rext[2]) * 2.0f - 1.0f;
+    float ix = ((gx + 1.0f) * 0.5f) * (float)(v.dx - 1);
+    float iy = ((gy + 1.0f) * 0.5f) * (float)(v.dy - 1);
+    float iz = ((gz + 1.0f) * 0.5f) * (float)(v.dz - 1);
+    ix = fminf(fmaxf(ix, 0.0f), (float)(v.dx - 1));
+    iy = fminf(fmaxf(iy, 0.0f), (float)(v.dy - 1));
+    iz = fminf(fmaxf(iz, 0.0f), (float)(v.dz - 1));
+    const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+    const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+    if (!mask[((IDX)x0 * (IDX)v.dy + (IDX)y0) * (IDX)v.dz + (IDX)z0]) return __builtin_inff();
+    const float tx = ix - fx, ty = iy - fy, tz = iz - fz;
+    const int x1 = min(x0 + 1, v.dx - 1), y1 = min(y0 + 1, v.dy - 1), z1 = min(z0 + 1, v.dz - 1);
+    float out = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int xx = (k & 4) ? x1 : x0, yy = (k & 2) ? y1 : y0, zz = (k & 1) ? z1 : z0;
+        const float wk = ((k & 4) ? tx : 1.0f - tx) * ((k & 2) ? ty : 1.0f - ty) * ((k & 1) ? tz : 1.0f - tz);
+        out = fmaf(wk, v.data[(((IDX)xx * (IDX)v.dy + (IDX)yy) * (IDX)v.dz + (IDX)zz) * (IDX)v.c + (IDX)(v.c - 1)], out);
+    }
+    return out;
+}
+
+// tile of 1024 consecutive ray-samples per workgroup: sub-tile k holds samples base + k*256 + tid,
+// one 64-bit survivor mask per (sub-tile, wave): mask word index = tile*16 + k*4 + wave
+// FAST (rays, no jitter, N < 2^31, small volume): 32-bit sample / ray / volume indices — the generic path spends a
+// third of its instructions on a 64-bit division by S and 64-bit index multiplies (quarter-rate integer ops).  The
+// float arithmetic is the same op sequence as sample_pose_point / sample_z / linspace01, bit for bit.
+template <bool MASKED, bool FAST>
+__device__ __forceinline__ void cull_flag_body(const RenderArgs& a, const Workspace& w, double inv_S, float lin_step, const int64_t tile) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __shared__ int cnt[CULL_PER * (CULL_BLOCK / 64)];
+    float rext[3] = {0.f, 0.f, 0.f};
+    if (MASKED) {
+        const float* pb = a.scene.pbw.bounds;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rext[c] = rcp_for_div(pb[3 + c] - pb[c]);
+    }
+#pragma unroll
+    for (int k = 0; k < CULL_PER; ++k) {
+        const int64_t i = tile * CULL_TILE + k * CULL_BLOCK + threadIdx.x;
+        bool keep = false;
+        if (i < a.N) {
+            float px, py, pz, z;
+            if (FAST) {
+                const unsigned iu = (unsigned)i, S = (unsigned)a.S;
+                unsigned ray = (unsigned)((double)iu * inv_S);            // floor(i / S), possibly one too small
+                unsigned s = iu - ray * S;
+                if (s >= S) { ++ray; s -= S; }
+                const float near = a.near[ray], far = a.far[ray];
+                const float t = ((int)s < a.S / 2) ? lin_step * (float)(int)s : 1.0f - lin_step * (float)(a.S - 1 - (int)s);   // linspace01
+                z = near * (1.0f - t) + far * t;                          // sample_z
+                const unsigned r3 = ray * 3u;
+                const float dx = a.ray_d[r3], dy = a.ray_d[r3 + 1], dz = a.ray_d[r3 + 2];
+                const float wx = a.ray_o[r3] + dx * z, wy = a.ray_o[r3 + 1] + dy * z, wz = a.ray_o[r3 + 2] + dz * z;   // pts = o + d*z
+                const float* R = a.scene.R;
+                const float* Th = a.scene.Th;
+                const float qx = wx - Th[0], qy = wy - Th[1], qz = wz - Th[2];                                         // (p - Th) @ R
+                px = qx * R[0] + qy * R[3] + qz * R[6];
+                py = qx * R[1] + qy * R[4] + qz * R[7];
+                pz = qx * R[2] + qy * R[5] + qz * R[8];
+            } else {
+                sample_pose_point(a, i, px, py, pz, &z, nullptr);
+            }
+            if (a.z_vals) a.z_vals[i] = z;
+            float pn;
+            if (MASKED) pn = FAST ? cull_distance<uint32_t>(a.scene.pbw, w.cullmask, px, py, pz, rext) : cull_distance<int64_t>(a.scene.pbw, w.cullmask, px, py, pz, rext);
+            else sample_volume_dev<1>(a.scene.pbw, a.scene.pbw.c - 1, px, py, pz, &pn);   // distance channel
+            keep = pn < a.scene.thresh;                                               // :135
+        }
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) {
+            w.mask[tile * (CULL_TILE / 64) + k * (CULL_BLOCK / 64) + wv] = m;
+            cnt[k * (CULL_BLOCK / 64) + wv] = __popcll(m);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int c = 0;
+#pragma unroll
+        for (int k = 0; k < CULL_TILE / 64; ++k) c += cnt[k];
+        w.block_cnt[tile] = c;
+    }
+}
+
+// ---- per-vertex pre-blended matrices (k_warp.hip header) ------------------------------------------------
+struct Mat34 { float m[12]; };   // rows 0..2 of a 4x4: [R | t]
+
+__device__ __forceinline__ void blend_mats(const float* __restrict__ A, const float* bw, Mat34& o) {
+#pragma unroll
+    for (int e = 0; e < 12; ++e) o.m[e] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < INVR_NUM_JOINTS; ++j)
+#pragma unroll
+        for (int e = 0; e < 12; ++e) o.m[e] = fmaf(bw[j], A[j * 16 + e], o.m[e]);     // bw @ A.view(24,16)
+}
+
+#define VMAT_BLOCK 128
+__device__ __forceinline__ void vertex_mats_body(const SceneDev& s, const KnnIndex& ix, const float* __restrict__ A,
+                                                 const float* __restrict__ big_A, const int p, const int v) {
+    if (v >= s.M || v >= ix.mpad) return;          // padding rows behind lengths2[p] are zeros in part_pbw: kept finite
+    const float* __restrict__ row = s.part_pbw + ((int64_t)p * s.M + v) * INVR_NUM_JOINTS;
+    float b[INVR_NUM_JOINTS];
+#pragma unroll
+    for (int j = 0; j < INVR_NUM_JOINTS; ++j) b[j] = row[j];
+    Mat34 Ma, Mb;
+    blend_mats(A, b, Ma);
+    blend_mats(big_A, b, Mb);
+    float4* o = ix.vmat + ((int64_t)p * ix.mpad + v) * 6;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        o[r] = make_float4(Ma.m[r * 4], Ma.m[r * 4 + 1], Ma.m[r * 4 + 2], Ma.m[r * 4 + 3]);
+        o[3 + r] = make_float4(Mb.m[r * 4], Mb.m[r * 4 + 1], Mb.m[r * 4 + 2], Mb.m[r * 4 + 3]);
+    }
+}
+
+// ---- per-frame t-slices of the deformer grid (k_warp.hip: k_deform_pairs_slice) ---------------------------
+struct DfSliceInfo { int off[INVR_MAX_LEVELS + 1]; };
+
+__device__ __forceinline__ void deform_slice_body(const GridDev& dg, const DfSliceInfo& si, const float* __restrict__ frame_dim,
+                                                  float2* __restrict__ out, const int e) {
+    if (e >= si.off[dg.L]) return;
+    int l = 0;
+    while (e >= si.off[l + 1]) ++l;
+    const int res = dg.res[l];
+    const float tn = (frame_dim[0] - dg.bounds[2]) / (dg.bounds[5] - dg.bounds[2]);
+    int c0z, c1z;
+    float tz;
+    level_corners(tn, dg.cell[l], res, c0z, c1z, tz);
+    const int idx = e - si.off[l], cx = idx / res, cy = idx - cx * res;
+    const bool hashed = l >= dg.start_hash;
+    const float* tb = dg.separate_dense ? (hashed ? dg.hash + (int64_t)(l - dg.start_hash) * dg.T * 2 : dg.dense + dg.dense_off[l] * 2)
+                                        : dg.hash + (int64_t)l * dg.T * 2;
+    const float2* tab = reinterpret_cast<const float2*>(tb);
+    unsigned r0, r1;
+    if (hashed) {
+        const uint64_t hxy = (uint64_t)(uint32_t)cx ^ ((uint64_t)(uint32_t)cy * HASH_P1);
+        r0 = grid_hash_mod(hxy ^ ((uint64_t)(uint32_t)c0z * HASH_P2), dg);
+        r1 = grid_hash_mod(hxy ^ ((uint64_t)(uint32_t)c1z * HASH_P2), dg);
+    } else {
+        r0 = ((unsigned)cx * (unsigned)res + (unsigned)cy) * (unsigned)res + (unsigned)c0z;
+        r1 = ((unsigned)cx * (unsigned)res + (unsigned)cy) * (unsigned)res + (unsigned)c1z;
+    }
+    const float2 v0 = tab[r0], v1 = tab[r1];
+    const float uz = 1.0f - tz;
+    out[e] = make_float2(fmaf(tz, v1.x, uz * v0.x), fmaf(tz, v1.y, uz * v0.y));
+}
+
+static bool deform_slices_fit(const GridDev& dg, DfSliceInfo& si, int cbv) {
+    si.off[0] = 0;
+    for (int l = 0; l < INVR_MAX_LEVELS; ++l) si.off[l + 1] = si.off[l] + (l < dg.L ? dg.res[l] * dg.res[l] : 0);
+    return dg.L == 8 && si.off[8] <= DF_SLICE_MAX && cbv < 10;
+}
+static int deform_cb() {
+    static int cbv = getenv("INVR_DF_CB") ? atoi(getenv("INVR_DF_CB")) : 2;
+    return cbv;
+}

@@ -359,54 +359,29 @@ static int render_impl(const InvrScene* scene, const InvrModel* model,
     a.wpts = wpts; a.wdirs = wdirs;
     a.R = n_rays; a.S = n_samples; a.N = N;
 
-    // fork: KNN index build (k_part_prepare, 5 workgroups, ~60 us) on a side stream beside the cull kernels
-    struct SideStream { hipStream_t side = nullptr; hipEvent_t fork = nullptr, cells = nullptr, join = nullptr, join2 = nullptr; };
-    static thread_local std::vector<SideStream> side_of_device;   // one per device this thread renders on (CPX mode: up to 64)
-    int dev_id = 0;
-    INVR_HIP(hipGetDevice(&dev_id));
-    INVR_CHECK(dev_id >= 0 && dev_id < 4096, "invr_render_fwd: device index %d out of range", dev_id);
-    if ((size_t)dev_id >= side_of_device.size()) side_of_device.resize((size_t)dev_id + 1);
-    SideStream& ss = side_of_device[dev_id];
-    if (!ss.side) {
-        INVR_HIP(hipStreamCreateWithFlags(&ss.side, hipStreamNonBlocking));
-        INVR_HIP(hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming));
-        INVR_HIP(hipEventCreateWithFlags(&ss.join, hipEventDisableTiming));
-        INVR_HIP(hipEventCreateWithFlags(&ss.join2, hipEventDisableTiming));
-        INVR_HIP(hipEventCreateWithFlags(&ss.cells, hipEventDisableTiming));
-    }
-    hipStream_t side = ss.side;
-    hipEvent_t ev_fork = ss.fork, ev_cells = ss.cells, ev_join = ss.join, ev_join2 = ss.join2;
-    // fork: the KNN index build only needs the posed vertices — it starts at once on the side stream.  On this stream the cell
-    // mask of the distance volume + the list of the cells that can hold a survivor (a few us) feed both the cull (this stream)
-    // and the KNN's lattice classification (side stream, behind the index build)
+    // The front of the frame on the caller's stream (k_knn.hip "the front of a frame as two launches"): one memset, one launch for
+    // everything that depends on the scene alone (KNN index, cull cell mask + live-cell list, per-vertex matrices, deformer slices),
+    // one launch for the lattice-cell classes and the cull flags, then scan / compaction.  No library-owned stream: a fork / join
+    // under hipGraph replay cost more than the kernels it hid.
     INVR_HIP(hipMemsetAsync(w.counters, 0, counters_ints(w.n_groups) * sizeof(int32_t), st));
-    INVR_HIP(hipEventRecord(ev_fork, st));
-    INVR_HIP(hipStreamWaitEvent(side, ev_fork, 0));
-    if (launch_knn_prepare(a, w, side)) return 1;
-    const bool have_cells = launch_cull_cells(a, w, st) != 0;
-    INVR_HIP(hipEventRecord(ev_cells, st));
-    INVR_HIP(hipStreamWaitEvent(side, ev_cells, 0));
+    GridDev dgrid = make_grid_dev(&model->deform_grid);
     // ablation switches: the environment is read once per process, not per frame
     static const bool no_voxmask = getenv("INVR_NO_VOXMASK") != nullptr, no_voxcls = getenv("INVR_NO_VOXCLS") != nullptr,
                       no_merge = getenv("INVR_NO_MERGE") != nullptr;
-    if (no_voxmask) w.knn.voxmask = nullptr;
-    if (!have_cells || no_voxcls) { w.knn.voxcls = nullptr; w.knn.voxmask = nullptr; }
-    else if (launch_knn_voxel_class(a, w, side)) return 1;
-    INVR_HIP(hipEventRecord(ev_join, side));             // the KNN waits for the index and the lattice classes only;
-    GridDev dgrid = make_grid_dev(&model->deform_grid);
-    if (launch_vertex_mats(a, w, side)) return 1;        // the warp needs these two, they run beside the KNN
-    if (launch_deform_slice(a, w, dgrid, side)) return 1;
-    INVR_HIP(hipEventRecord(ev_join2, side));
     {
         ProfStage ps(INVR_STAGE_CULL, st);
-        if (launch_cull(a, w, max_active, have_cells, st)) return 1;
+        int have_cells = 0, flags_done = 0;
+        if (launch_front_scene(a, w, dgrid, &have_cells, st)) return 1;
+        if (no_voxmask) w.knn.voxmask = nullptr;
+        if (!have_cells || no_voxcls) { w.knn.voxcls = nullptr; w.knn.voxmask = nullptr; }
+        else if (launch_front_cull(a, w, &flags_done, st)) return 1;
+        if (w.knn.voxcls && !flags_done && launch_knn_voxel_class(a, w, st)) return 1;      // (small calls: the cull runs unmasked)
+        if (launch_cull(a, w, max_active, have_cells != 0, flags_done != 0, st)) return 1;
     }
-    INVR_HIP(hipStreamWaitEvent(st, ev_join, 0));        // join
     {
         ProfStage ps(INVR_STAGE_KNN, st);
         if (launch_knn_pairs(a, w, stats, st)) return 1;
     }
-    INVR_HIP(hipStreamWaitEvent(st, ev_join2, 0));
     {
         ProfStage ps(INVR_STAGE_WARP, st);
         MlpDev dm = make_mlp_dev(&model->deform_mlp);

@@ -11,145 +11,16 @@
 #include <stdlib.h>
 #include "pipeline.h"
 
-#define CULL_BLOCK 256
-#define CULL_PER 4                      // ray-samples per thread
-#define CULL_TILE (CULL_BLOCK * CULL_PER)
+#include "front_bodies.h"
 
-// Per-frame cell mask of the distance volume: the trilinear value of a sample is a convex combination of the 8
-// corners of its cell (weights in [0,1], sum 1 within 4e-7), so a cell whose corners are all >= thresh*(1+1e-5)
-// cannot hold a survivor — 93 % of the samples of the bench frame then skip the 8 taps.  Cell (x0,y0,z0) pairs
-// with corner x1 = min(x0+1, dx-1) exactly as the border-clamped sampler does, so there are dx*dy*dz cells.
-// The live cells are also appended to a list (wave-aggregated: one atomic per wave), which the KNN's per-cell classification
-// (k_knn_voxel_class, side stream) walks instead of the whole lattice.
 __global__ void k_cull_cells(VolDev v, float thresh_hi, uint8_t* __restrict__ mask, int32_t* __restrict__ live, int32_t* __restrict__ n_live,
                              uint8_t* __restrict__ voxcls) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool in = i < v.dx * v.dy * v.dz;
-    bool keep = false;
-    if (in) {
-    const int z0 = i % v.dz, y0 = (i / v.dz) % v.dy, x0 = i / (v.dz * v.dy);
-    const int x1 = min(x0 + 1, v.dx - 1), y1 = min(y0 + 1, v.dy - 1), z1 = min(z0 + 1, v.dz - 1);
-    float m = __builtin_inff();
-    bool nan = false;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int xx = (k & 4) ? x1 : x0, yy = (k & 2) ? y1 : y0, zz = (k & 1) ? z1 : z0;
-        const float d = v.data[(((int64_t)xx * v.dy + yy) * v.dz + zz) * v.c + (v.c - 1)];
-        nan = nan || d != d;
-        m = fminf(m, d);
-    }
-    keep = m < thresh_hi || nan;
-    mask[i] = keep ? 1 : 0;
-    }
-    if (live) {
-        const unsigned long long b = __ballot(keep);
-        if (b) {
-            const int lane = threadIdx.x & 63;
-            int base = 0;
-            if (lane == __ffsll((long long)b) - 1) base = atomicAdd(n_live, __popcll(b));
-            base = __shfl(base, __ffsll((long long)b) - 1);
-            if (keep) live[base + __popcll(b & ((1ull << lane) - 1ull))] = i;
-        }
-        // class "undecided" for every cell: k_knn_pairs maps a point to its cell with slightly different arithmetic than the
-        // sampler, so a survivor on a cell face may look up a neighbour that is not live — and is never classified
-        if (in && voxcls) {
-#pragma unroll
-            for (int p = 0; p < INVR_NUM_PARTS; ++p) voxcls[(int64_t)i * INVR_NUM_PARTS + p] = 0;
-        }
-    }
+    cull_cells_body(v, thresh_hi, mask, live, n_live, voxcls, (int)(blockIdx.x * blockDim.x + threadIdx.x));
 }
 
-// distance channel of the pose-space volume at (px,py,pz): sample_volume_dev<1> (same arithmetic, bit for bit)
-// with the cell-mask early-out; returns +inf for samples in masked-out cells (they fail pn < thresh either way)
-template <typename IDX>        // IDX = uint32_t when dx*dy*dz*c < 2^31 (host-checked): 64-bit index multiplies are quarter rate
-__device__ __forceinline__ float cull_distance(const VolDev& v, const uint8_t* __restrict__ mask, float px, float py, float pz, const float* rext) {
-    const float b0x = v.bounds[0], b0y = v.bounds[1], b0z = v.bounds[2];
-    const float b1x = v.bounds[3], b1y = v.bounds[4], b1z = v.bounds[5];
-    // (p - b0) / (b1 - b0): the IEEE quotients through the per-thread reciprocals of the three extents (common.h:div_exact)
-    float gx = div_exact(px - b0x, b1x - b0x, rext[0]) * 2.0f - 1.0f;
-    float gy = div_exact(py - b0y, b1y - b0y, rext[1]) * 2.0f - 1.0f;
-    float gz = div_exact(pz - b0z, b1z - b0z, rext[2]) * 2.0f - 1.0f;
-    float ix = ((gx + 1.0f) * 0.5f) * (float)(v.dx - 1);
-    float iy = ((gy + 1.0f) * 0.5f) * (float)(v.dy - 1);
-    float iz = ((gz + 1.0f) * 0.5f) * (float)(v.dz - 1);
-    ix = fminf(fmaxf(ix, 0.0f), (float)(v.dx - 1));
-    iy = fminf(fmaxf(iy, 0.0f), (float)(v.dy - 1));
-    iz = fminf(fmaxf(iz, 0.0f), (float)(v.dz - 1));
-    const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
-    const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
-    if (!mask[((IDX)x0 * (IDX)v.dy + (IDX)y0) * (IDX)v.dz + (IDX)z0]) return __builtin_inff();
-    const float tx = ix - fx, ty = iy - fy, tz = iz - fz;
-    const int x1 = min(x0 + 1, v.dx - 1), y1 = min(y0 + 1, v.dy - 1), z1 = min(z0 + 1, v.dz - 1);
-    float out = 0.0f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int xx = (k & 4) ? x1 : x0, yy = (k & 2) ? y1 : y0, zz = (k & 1) ? z1 : z0;
-        const float wk = ((k & 4) ? tx : 1.0f - tx) * ((k & 2) ? ty : 1.0f - ty) * ((k & 1) ? tz : 1.0f - tz);
-        out = fmaf(wk, v.data[(((IDX)xx * (IDX)v.dy + (IDX)yy) * (IDX)v.dz + (IDX)zz) * (IDX)v.c + (IDX)(v.c - 1)], out);
-    }
-    return out;
-}
-
-// tile of 1024 consecutive ray-samples per workgroup: sub-tile k holds samples base + k*256 + tid,
-// one 64-bit survivor mask per (sub-tile, wave): mask word index = tile*16 + k*4 + wave
-// FAST (rays, no jitter, N < 2^31, small volume): 32-bit sample / ray / volume indices — the generic path spends a
-// third of its instructions on a 64-bit division by S and 64-bit index multiplies (quarter-rate integer ops).  The
-// float arithmetic is the same op sequence as sample_pose_point / sample_z / linspace01, bit for bit.
 template <bool MASKED, bool FAST>
 __global__ __launch_bounds__(CULL_BLOCK) void k_cull_flag(RenderArgs a, Workspace w, double inv_S, float lin_step) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    __shared__ int cnt[CULL_PER * (CULL_BLOCK / 64)];
-    float rext[3] = {0.f, 0.f, 0.f};
-    if (MASKED) {
-        const float* pb = a.scene.pbw.bounds;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) rext[c] = rcp_for_div(pb[3 + c] - pb[c]);
-    }
-#pragma unroll
-    for (int k = 0; k < CULL_PER; ++k) {
-        const int64_t i = (int64_t)blockIdx.x * CULL_TILE + k * CULL_BLOCK + threadIdx.x;
-        bool keep = false;
-        if (i < a.N) {
-            float px, py, pz, z;
-            if (FAST) {
-                const unsigned iu = (unsigned)i, S = (unsigned)a.S;
-                unsigned ray = (unsigned)((double)iu * inv_S);            // floor(i / S), possibly one too small
-                unsigned s = iu - ray * S;
-                if (s >= S) { ++ray; s -= S; }
-                const float near = a.near[ray], far = a.far[ray];
-                const float t = ((int)s < a.S / 2) ? lin_step * (float)(int)s : 1.0f - lin_step * (float)(a.S - 1 - (int)s);   // linspace01
-                z = near * (1.0f - t) + far * t;                          // sample_z
-                const unsigned r3 = ray * 3u;
-                const float dx = a.ray_d[r3], dy = a.ray_d[r3 + 1], dz = a.ray_d[r3 + 2];
-                const float wx = a.ray_o[r3] + dx * z, wy = a.ray_o[r3 + 1] + dy * z, wz = a.ray_o[r3 + 2] + dz * z;   // pts = o + d*z
-                const float* R = a.scene.R;
-                const float* Th = a.scene.Th;
-                const float qx = wx - Th[0], qy = wy - Th[1], qz = wz - Th[2];                                         // (p - Th) @ R
-                px = qx * R[0] + qy * R[3] + qz * R[6];
-                py = qx * R[1] + qy * R[4] + qz * R[7];
-                pz = qx * R[2] + qy * R[5] + qz * R[8];
-            } else {
-                sample_pose_point(a, i, px, py, pz, &z, nullptr);
-            }
-            if (a.z_vals) a.z_vals[i] = z;
-            float pn;
-            if (MASKED) pn = FAST ? cull_distance<uint32_t>(a.scene.pbw, w.cullmask, px, py, pz, rext) : cull_distance<int64_t>(a.scene.pbw, w.cullmask, px, py, pz, rext);
-            else sample_volume_dev<1>(a.scene.pbw, a.scene.pbw.c - 1, px, py, pz, &pn);   // distance channel
-            keep = pn < a.scene.thresh;                                               // :135
-        }
-        const unsigned long long m = __ballot(keep);
-        if (lane == 0) {
-            w.mask[(int64_t)blockIdx.x * (CULL_TILE / 64) + k * (CULL_BLOCK / 64) + wv] = m;
-            cnt[k * (CULL_BLOCK / 64) + wv] = __popcll(m);
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int c = 0;
-#pragma unroll
-        for (int k = 0; k < CULL_TILE / 64; ++k) c += cnt[k];
-        w.block_cnt[blockIdx.x] = c;
-    }
+    cull_flag_body<MASKED, FAST>(a, w, inv_S, lin_step, (int64_t)blockIdx.x);
 }
 
 #define SCAN_T 1024
@@ -313,13 +184,14 @@ int launch_cull_cells(const RenderArgs& a, const Workspace& w, hipStream_t st) {
     return 1;
 }
 
-int launch_cull(const RenderArgs& a, const Workspace& w, int64_t max_active, bool have_cells, hipStream_t st) {
+int launch_cull(const RenderArgs& a, const Workspace& w, int64_t max_active, bool have_cells, bool flags_done, hipStream_t st) {
     int64_t nb = cdiv(a.N, CULL_TILE);
     const VolDev& v = a.scene.pbw;
     const int64_t cells = (int64_t)v.dx * v.dy * v.dz;
     const double inv_S = 1.0 / (double)a.S;
     const float lin_step = 1.0f / (float)(a.S - 1);                // linspace01's step, the same IEEE division
-    if (have_cells && a.N >= 4 * cells) {        // the mask pays for itself on full frames only
+    if (flags_done) {
+    } else if (have_cells && a.N >= 4 * cells) {        // the mask pays for itself on full frames only
         const bool fast = !a.wpts && !a.jitter && a.N < (1ll << 31) && cells * v.c < (1ll << 31) && a.S >= 2;
         if (fast) hipLaunchKernelGGL((k_cull_flag<true, true>), dim3((unsigned)nb), dim3(CULL_BLOCK), 0, st, a, w, inv_S, lin_step);
         else hipLaunchKernelGGL((k_cull_flag<true, false>), dim3((unsigned)nb), dim3(CULL_BLOCK), 0, st, a, w, inv_S, lin_step);

@@ -35,6 +35,7 @@
 // lb(box) <= current 4th-best, distances of two vertices per packed-fp32 instruction, top-4 kept as 64-bit (distance, row) keys.
 #include <stdlib.h>
 #include "pipeline.h"
+#include "front_bodies.h"
 
 #define KNN_BLOCK 256
 #define KNN_K 4
@@ -219,12 +220,11 @@ __device__ __forceinline__ unsigned spread6(unsigned v) {       // 6 bits -> eve
     return v;
 }
 
-__global__ __launch_bounds__(PREP_T) void k_part_prepare(SceneDev s, KnnIndex ix) {
-    extern __shared__ unsigned prep_lds[];                // [keys PREP_MAX | counting-sort output PREP_MAX | 4096 buckets] = 80 KB
+// (body: one PREP_T-thread workgroup per part p; prep_lds = [keys PREP_MAX | counting-sort output PREP_MAX | 4096 buckets] = 80 KB)
+__device__ __forceinline__ void part_prepare_body(const SceneDev& s, const KnnIndex& ix, const int p, unsigned* prep_lds) {
     unsigned* keys = prep_lds;
     unsigned* sorted = prep_lds + PREP_MAX;
     __shared__ float red[6][PREP_T / 64];
-    const int p = blockIdx.x;
     const int len = min((int)s.lengths2[p], PREP_MAX);
     const float* v = s.part_pts + (int64_t)p * s.M * 3;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -378,6 +378,12 @@ __global__ __launch_bounds__(PREP_T) void k_part_prepare(SceneDev s, KnnIndex ix
     KP(4)
     KP_CNT(8)
     KP_FLUSH_AT(16)
+}
+
+#define PREP_LDS_BYTES ((size_t)(2 * PREP_MAX + 4096) * sizeof(unsigned))
+__global__ __launch_bounds__(PREP_T) void k_part_prepare(SceneDev s, KnnIndex ix) {
+    extern __shared__ unsigned prep_lds[];
+    part_prepare_body(s, ix, (int)blockIdx.x, prep_lds);
 }
 
 // wave-uniform 16-byte LDS read that stays a ds_read_b128 (256 B/clk): when .w is unused the compiler narrows
@@ -858,34 +864,43 @@ __global__ __launch_bounds__(PL_BLOCK) void k_pair_lists(Workspace w, int32_t* _
 #define VC_Q 4
 __device__ __forceinline__ float quad_min(float x) { x = fminf(x, __shfl_xor(x, 1)); return fminf(x, __shfl_xor(x, 2)); }
 
-__global__ __launch_bounds__(VC_BLOCK) void k_knn_voxel_class(SceneDev s, KnnIndex ix, const int32_t* __restrict__ n_live_dev) {
+// (body: workgroup bx of gx of part p)
+__device__ __forceinline__ void voxel_class_body(const SceneDev& s, const KnnIndex& ix, const int32_t* __restrict__ n_live_dev,
+                                                 const int bx, const int n_bx, const int p) {
     const VolDev& v = s.pbw;
     // the live cells — a corner below the cull threshold, 7 % of the lattice on the bench frame; all other cells are never looked
     // up — were listed by k_cull_cells
     const int n_live = n_live_dev[0];
     const float dfar2 = ix.dfar2[0];
     const int per_block = VC_BLOCK / VC_Q;
-    if ((int)blockIdx.x * per_block >= n_live) return;
+    if (bx * per_block >= n_live) return;
     // cluster {lo, hi, rep} and sub-cluster {lo, hi} records of this block's part, staged once
     __shared__ float4 s_cl[(PREP_MAX / 64) * 3];
-    __shared__ float4 s_sub[(PREP_MAX / 64) * 8];
-    const int p = blockIdx.y;
+    __shared__ float4 s_sub[64 * 8];                               // (only read for parts with <= 64 clusters: the mask path)
     const int len = min((int)s.lengths2[p], PREP_MAX), ncl = (len + 63) >> 6;
     for (int j = threadIdx.x; j < ncl * 3; j += VC_BLOCK) s_cl[j] = ix.cl[(int64_t)p * ix.cpad * 3 + j];
-    for (int j = threadIdx.x; j < ncl * 8; j += VC_BLOCK) s_sub[j] = ix.sub[(int64_t)p * ix.cpad * 8 + j];
+    if (ncl <= 64)
+        for (int j = threadIdx.x; j < ncl * 8; j += VC_BLOCK) s_sub[j] = ix.sub[(int64_t)p * ix.cpad * 8 + j];
     __syncthreads();
     const int q = threadIdx.x & (VC_Q - 1);
     const int qbase = (threadIdx.x & 63) & ~(VC_Q - 1);            // lane of the quad's first thread inside its wave
-    for (int e = (int)blockIdx.x * per_block + (int)(threadIdx.x >> 2); e < n_live; e += (int)gridDim.x * per_block) {
+    for (int e = bx * per_block + (int)(threadIdx.x >> 2); e < n_live; e += n_bx * per_block) {
         const int idx = ix.live_cells[e];
-        const int z0 = idx % v.dz, y0 = (idx / v.dz) % v.dy, x0 = idx / (v.dz * v.dy);
-        const int c0[3] = {x0, y0, z0}, dims[3] = {v.dx, v.dy, v.dz};
+        // the cell's box, inflated: the point -> cell map of k_knn_pairs is approximate
+        auto cell_box = [&](int cell, float* blo, float* bhi) {
+            const int z0 = cell % v.dz, y0 = (cell / v.dz) % v.dy, x0 = cell / (v.dz * v.dy);
+            const int c0[3] = {x0, y0, z0}, dims[3] = {v.dx, v.dy, v.dz};
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float b0 = v.bounds[a], ext = v.bounds[3 + a] - b0, den = (float)(dims[a] - 1);
+                blo[a] = b0 + ext * ((float)c0[a] / den) - 1e-4f;
+                bhi[a] = b0 + ext * ((float)min(c0[a] + 1, dims[a] - 1) / den) + 1e-4f;
+            }
+        };
         float lo[3], hi[3], ce[3], h2 = 0.0f;
+        cell_box(idx, lo, hi);
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            const float b0 = v.bounds[a], ext = v.bounds[3 + a] - b0, den = (float)(dims[a] - 1);
-            lo[a] = b0 + ext * ((float)c0[a] / den) - 1e-4f;                      // inflated: the point -> cell map of k_knn_pairs is approximate
-            hi[a] = b0 + ext * ((float)min(c0[a] + 1, dims[a] - 1) / den) + 1e-4f;
             ce[a] = 0.5f * (lo[a] + hi[a]);
             h2 += 0.25f * (hi[a] - lo[a]) * (hi[a] - lo[a]);
         }
@@ -893,6 +908,7 @@ __global__ __launch_bounds__(VC_BLOCK) void k_knn_voxel_class(SceneDev s, KnnInd
         // bounds on the nearest-vertex distance of any point of the cell: box-to-box (lower), centre-to-representative + half
         // diagonal (upper) — the two tests k_knn_pairs applies per point
         float lb2 = __builtin_inff(), ub2 = __builtin_inff();
+#pragma unroll 1
         for (int c = q; c < ncl; c += VC_Q) {
             const float4 klo = s_cl[c * 3], khi = s_cl[c * 3 + 1];
             const float4 rep = s_cl[c * 3 + 2];
@@ -931,6 +947,7 @@ __global__ __launch_bounds__(VC_BLOCK) void k_knn_voxel_class(SceneDev s, KnnInd
                     if (b1 < b0 || (b1 == b0 && i1 < i0)) { const float tf = b0; b0 = b1; b1 = tf; const int ti = i0; i0 = i1; i1 = ti; }
                 }
             };
+#pragma unroll 1
             for (int c = q; c < ncl; c += VC_Q) {
                 // a sub-cluster's farthest-corner distance is at least the centre's distance to the cluster box: clusters beyond
                 // the lane's current third-best cannot enter
@@ -971,20 +988,24 @@ __global__ __launch_bounds__(VC_BLOCK) void k_knn_voxel_class(SceneDev s, KnnInd
                     }
                 };
                 const int ids[3] = {i0, i1, i2};
-                float4 ra[3][4], rb[3][4];
-#pragma unroll
-                for (int t3 = 0; t3 < 3; ++t3) {
-                    // the lane's 4 vertices of the sub-cluster sit in pair records (q>>1) + 2m: all 24 loads are issued before the first use
-                    const float4* rec = ix.sverts + (int64_t)p * ix.mpad + (ids[t3] == 0x7fffffff ? 0 : ids[t3]) * 16;
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) { ra[t3][m] = rec[2 * ((q >> 1) + 2 * m)]; rb[t3][m] = rec[2 * ((q >> 1) + 2 * m) + 1]; }
-                }
-#pragma unroll
+                // one sub-cluster at a time (8 loads in flight): all 24 loads up front cost 96 registers, and this body shares its
+                // launch — and with it its register allocation — with the cull flags, which need 8 waves per SIMD (k_front_cull)
+#pragma unroll 1
                 for (int t3 = 0; t3 < 3; ++t3) {
                     if (ids[t3] == 0x7fffffff) continue;
+                    // the lane's 4 vertices of the sub-cluster sit in pair records (q>>1) + 2m
+                    const float4* rec = ix.sverts + (int64_t)p * ix.mpad + ids[t3] * 16;
+                    float4 ra[4];
+                    float2 rb[4];                                  // {z0, z1} of the pair record's second half
 #pragma unroll
                     for (int m = 0; m < 4; ++m) {
-                        const float4 A = ra[t3][m], B = rb[t3][m];
+                        ra[m] = rec[2 * ((q >> 1) + 2 * m)];
+                        rb[m] = *reinterpret_cast<const float2*>(rec + 2 * ((q >> 1) + 2 * m) + 1);
+                    }
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        const float4 A = ra[m];
+                        const float2 B = rb[m];
                         const float vx = (q & 1) ? A.y : A.x, vy = (q & 1) ? A.w : A.z, vz = (q & 1) ? B.y : B.x;
                         const float dx = ce[0] - vx, dy = ce[1] - vy, dz = ce[2] - vz;
                         ins4(dx * dx + dy * dy + dz * dz);
@@ -1002,11 +1023,18 @@ __global__ __launch_bounds__(VC_BLOCK) void k_knn_voxel_class(SceneDev s, KnnInd
             const float u2 = u * u * 1.0002f;
             u2_out = u2;
             unsigned mlo = 0u, mhi = 0u;
+            // (the box is formed again from the cell index, behind a register fence: six registers less across the phases above —
+            // this body shares its launch and its register allocation with the cull flags, k_front_cull)
+            int idx2 = idx;
+            asm volatile("" : "+v"(idx2));
+            float lo2[3], hi2[3];
+            cell_box(idx2, lo2, hi2);
+#pragma unroll 1
             for (int c = q; c < ncl; c += VC_Q) {
                 const float4 klo = s_cl[c * 3], khi = s_cl[c * 3 + 1];
-                const float gx = fmaxf(fmaxf(klo.x - hi[0], lo[0] - khi.x), 0.0f);
-                const float gy = fmaxf(fmaxf(klo.y - hi[1], lo[1] - khi.y), 0.0f);
-                const float gz = fmaxf(fmaxf(klo.z - hi[2], lo[2] - khi.z), 0.0f);
+                const float gx = fmaxf(fmaxf(klo.x - hi2[0], lo2[0] - khi.x), 0.0f);
+                const float gy = fmaxf(fmaxf(klo.y - hi2[1], lo2[1] - khi.y), 0.0f);
+                const float gz = fmaxf(fmaxf(klo.z - hi2[2], lo2[2] - khi.z), 0.0f);
                 if ((gx * gx + gy * gy + gz * gz) * 0.9999f <= u2) { if (c < 32) mlo |= 1u << c; else mhi |= 1u << (c - 32); }
             }
             mlo |= __shfl_xor(mlo, 1); mlo |= __shfl_xor(mlo, 2);
@@ -1020,26 +1048,118 @@ __global__ __launch_bounds__(VC_BLOCK) void k_knn_voxel_class(SceneDev s, KnnInd
     }
 }
 
-int launch_knn_voxel_class(const RenderArgs& a, const Workspace& w, hipStream_t st) {
-    const VolDev& v = a.scene.pbw;
+__global__ __launch_bounds__(VC_BLOCK) void k_knn_voxel_class(SceneDev s, KnnIndex ix, const int32_t* __restrict__ n_live_dev) {
+    voxel_class_body(s, ix, n_live_dev, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y);
+}
+
+static unsigned voxel_class_grid(const VolDev& v) {
     const int64_t cells = (int64_t)v.dx * v.dy * v.dz, items = VC_BLOCK / VC_Q;
-    hipLaunchKernelGGL(k_knn_voxel_class, dim3((unsigned)(cells / items < 2048 ? cdiv(cells, items) : 2048), INVR_NUM_PARTS), dim3(VC_BLOCK), 0, st,
+    return (unsigned)(cells / items < 2048 ? cdiv(cells, items) : 2048);
+}
+
+int launch_knn_voxel_class(const RenderArgs& a, const Workspace& w, hipStream_t st) {
+    hipLaunchKernelGGL(k_knn_voxel_class, dim3(voxel_class_grid(a.scene.pbw), INVR_NUM_PARTS), dim3(VC_BLOCK), 0, st,
                        a.scene, w.knn, w.counters + CNT_LIVE);
     INVR_LAUNCH_CHECK();
     return 0;
 }
 
-// The per-frame KNN index only depends on the posed vertices, not on the rays: it is built on a side stream
-// beside the cull kernels (fork / join with events — also a valid pattern under hipGraph capture).
+// The per-frame KNN index only depends on the posed vertices, not on the rays.
 int launch_knn_prepare(const RenderArgs& a, const Workspace& w, hipStream_t st) {
-    const size_t lds_bytes = (size_t)(2 * PREP_MAX + 4096) * sizeof(unsigned);
     static bool attr_set = false;
     if (!attr_set) {
-        INVR_HIP(hipFuncSetAttribute((const void*)k_part_prepare, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        INVR_HIP(hipFuncSetAttribute((const void*)k_part_prepare, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PREP_LDS_BYTES));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_part_prepare, dim3(INVR_NUM_PARTS), dim3(PREP_T), lds_bytes, st, a.scene, w.knn);
+    hipLaunchKernelGGL(k_part_prepare, dim3(INVR_NUM_PARTS), dim3(PREP_T), PREP_LDS_BYTES, st, a.scene, w.knn);
     INVR_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- the front of a frame as two launches on ONE stream ------------------------------------------------------------------------
+// Everything in front of the KNN used to be two chains joined by events: {cell mask -> cull flags -> scan -> compaction} on the
+// caller's stream, {index build -> lattice classes -> vertex matrices -> deformer slices} on a library stream.  Under hipGraph replay
+// every edge between the two chains costs 10-17 us on this runtime (the kernel behind a cross-stream dependency starts that much
+// after its predecessor ends; kernels that follow each other on one stream start back to back): 74 us per frame, a fifth of a 1/8
+// ray shard (gpurun_out/r4c).  Independent kernels now share a LAUNCH instead: workgroup ranges of one grid run different bodies.
+//   k_front_scene : [5 x index build | cull cell mask + live-cell list | per-vertex matrices | deformer t-slices]   (scene only)
+//   k_front_cull  : [lattice-cell classes of the live cells x 5 parts | cull flags of the ray-samples]
+// Both bodies of a launch run side by side on the chip; the launch lasts as long as its longest range.
+struct FrontSceneArgs {
+    SceneDev s; KnnIndex ix;
+    float thresh_hi; uint8_t* cullmask; int32_t* n_live;          // cell mask (n_cells_wg == 0: no mask this frame)
+    GridDev dg; DfSliceInfo si; float2* dslice;                   // deformer slices (n_slice_wg == 0: they do not fit)
+    int n_cells_wg, n_vmat_wg, n_slice_wg, vmat_m;
+};
+__global__ __launch_bounds__(PREP_T) void k_front_scene(FrontSceneArgs f) {
+    extern __shared__ unsigned prep_lds[];
+    int b = (int)blockIdx.x;
+    if (b < INVR_NUM_PARTS) { part_prepare_body(f.s, f.ix, b, prep_lds); return; }
+    b -= INVR_NUM_PARTS;
+    if (b < f.n_cells_wg) {
+        cull_cells_body(f.s.pbw, f.thresh_hi, f.cullmask, f.ix.live_cells, f.n_live, f.ix.voxcls, b * PREP_T + (int)threadIdx.x);
+        return;
+    }
+    b -= f.n_cells_wg;
+    if (b < f.n_vmat_wg * INVR_NUM_PARTS) {
+        vertex_mats_body(f.s, f.ix, f.s.A, f.s.big_A, b / f.n_vmat_wg, (b % f.n_vmat_wg) * PREP_T + (int)threadIdx.x);
+        return;
+    }
+    b -= f.n_vmat_wg * INVR_NUM_PARTS;
+    deform_slice_body(f.dg, f.si, f.s.frame_dim, f.dslice, b * PREP_T + (int)threadIdx.x);
+}
+
+// -> *have_cells = 1 if the cell mask / live-cell list were built (launch_cull_cells' conditions)
+int launch_front_scene(const RenderArgs& a, const Workspace& w, const GridDev& dg, int* have_cells, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        INVR_HIP(hipFuncSetAttribute((const void*)k_front_scene, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PREP_LDS_BYTES));
+        attr_set = true;
+    }
+    FrontSceneArgs f;
+    f.s = a.scene; f.ix = w.knn;
+    const VolDev& v = a.scene.pbw;
+    const int64_t cells = (int64_t)v.dx * v.dy * v.dz;
+    static const bool no_mask = getenv("INVR_NO_CULLMASK") != nullptr;
+    *have_cells = !(cells > CULL_MASK_MAX || cells > VOXMASK_MAX_CELLS || no_mask);
+    f.thresh_hi = a.scene.thresh * (1.0f + 1e-5f); f.cullmask = w.cullmask; f.n_live = w.counters + CNT_LIVE;
+    f.n_cells_wg = *have_cells ? (int)cdiv(cells, PREP_T) : 0;
+    f.vmat_m = a.scene.M < w.knn.mpad ? a.scene.M : w.knn.mpad;
+    f.n_vmat_wg = (int)cdiv(f.vmat_m, PREP_T);
+    f.dg = dg; f.dslice = w.dslice;
+    f.n_slice_wg = deform_slices_fit(dg, f.si, deform_cb()) ? (int)cdiv(f.si.off[8], PREP_T) : 0;
+    const unsigned grid = (unsigned)(INVR_NUM_PARTS + f.n_cells_wg + f.n_vmat_wg * INVR_NUM_PARTS + f.n_slice_wg);
+    hipLaunchKernelGGL(k_front_scene, dim3(grid), dim3(PREP_T), PREP_LDS_BYTES, st, f);
+    INVR_LAUNCH_CHECK();
+    return 0;
+}
+
+template <bool FAST>
+__attribute__((amdgpu_waves_per_eu(8, 8)))
+__global__ __launch_bounds__(CULL_BLOCK) void k_front_cull(RenderArgs a, Workspace w, double inv_S, float lin_step, int vc_gx) {
+    static_assert(VC_BLOCK == CULL_BLOCK, "the two bodies share a launch");
+    const int b = (int)blockIdx.x;
+    if (b < vc_gx * INVR_NUM_PARTS) { voxel_class_body(a.scene, w.knn, w.counters + CNT_LIVE, b % vc_gx, vc_gx, b / vc_gx); return; }
+    cull_flag_body<true, FAST>(a, w, inv_S, lin_step, (int64_t)(b - vc_gx * INVR_NUM_PARTS));
+}
+
+// lattice classes + cull flags in one launch; returns 0 and sets *done = 0 when the frame does not take the masked cull
+// (launch_cull's condition), in which case the caller runs launch_cull alone
+int launch_front_cull(const RenderArgs& a, const Workspace& w, int* done, hipStream_t st) {
+    const VolDev& v = a.scene.pbw;
+    const int64_t cells = (int64_t)v.dx * v.dy * v.dz, nb = cdiv(a.N, CULL_TILE);
+    static const bool no_voxcls = getenv("INVR_NO_VOXCLS") != nullptr;
+    *done = 0;
+    if (!(a.N >= 4 * cells) || no_voxcls) return 0;
+    const unsigned gx = voxel_class_grid(v);
+    const double inv_S = 1.0 / (double)a.S;
+    const float lin_step = 1.0f / (float)(a.S - 1);
+    const bool fast = !a.wpts && !a.jitter && a.N < (1ll << 31) && cells * v.c < (1ll << 31) && a.S >= 2;
+    const unsigned grid = gx * INVR_NUM_PARTS + (unsigned)nb;
+    if (fast) hipLaunchKernelGGL((k_front_cull<true>), dim3(grid), dim3(CULL_BLOCK), 0, st, a, w, inv_S, lin_step, (int)gx);
+    else hipLaunchKernelGGL((k_front_cull<false>), dim3(grid), dim3(CULL_BLOCK), 0, st, a, w, inv_S, lin_step, (int)gx);
+    INVR_LAUNCH_CHECK();
+    *done = 1;
     return 0;
 }
 

@@ -13,19 +13,9 @@
 #include <stdlib.h>
 #include "pipeline.h"
 #include "grid_generic.h"
+#include "front_bodies.h"
 
 #define WARP_BLOCK 128
-
-struct Mat34 { float m[12]; };   // rows 0..2 of a 4x4: [R | t]
-
-__device__ __forceinline__ void blend_mats(const float* __restrict__ A, const float* bw, Mat34& o) {
-#pragma unroll
-    for (int e = 0; e < 12; ++e) o.m[e] = 0.0f;
-#pragma unroll
-    for (int j = 0; j < INVR_NUM_JOINTS; ++j)
-#pragma unroll
-        for (int e = 0; e < 12; ++e) o.m[e] = fmaf(bw[j], A[j * 16 + e], o.m[e]);     // bw @ A.view(24,16)
-}
 
 // adjugate / (det + eps)  (blend_utils.py:293-317)
 __device__ __forceinline__ void inverse3x3(const Mat34& M, float* inv) {
@@ -149,24 +139,9 @@ int launch_warp_deform_dense(const SceneDev& s, const GridDev& dg, const MlpDev&
 // for big_A).  A pair then needs 4 x 96 B gathers and 96 FMAs instead of 4 x 96 B gathers, the 24-wide blend and
 // 576 FMAs against 576 scalar matrix entries (which the compiler could only keep by spilling SGPRs into VGPR
 // lanes: 2.2 k v_readlane / v_writelane per pair made the old kernel VALU-bound at 0.32 ms).
-#define VMAT_BLOCK 128
 __global__ __launch_bounds__(VMAT_BLOCK) void k_vertex_mats(SceneDev s, KnnIndex ix, const float* __restrict__ A,
                                                            const float* __restrict__ big_A) {
-    const int p = blockIdx.y, v = blockIdx.x * VMAT_BLOCK + threadIdx.x;
-    if (v >= s.M || v >= ix.mpad) return;          // padding rows behind lengths2[p] are zeros in part_pbw: kept finite
-    const float* __restrict__ row = s.part_pbw + ((int64_t)p * s.M + v) * INVR_NUM_JOINTS;
-    float b[INVR_NUM_JOINTS];
-#pragma unroll
-    for (int j = 0; j < INVR_NUM_JOINTS; ++j) b[j] = row[j];
-    Mat34 Ma, Mb;
-    blend_mats(A, b, Ma);
-    blend_mats(big_A, b, Mb);
-    float4* o = ix.vmat + ((int64_t)p * ix.mpad + v) * 6;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        o[r] = make_float4(Ma.m[r * 4], Ma.m[r * 4 + 1], Ma.m[r * 4 + 2], Ma.m[r * 4 + 3]);
-        o[3 + r] = make_float4(Mb.m[r * 4], Mb.m[r * 4 + 1], Mb.m[r * 4 + 2], Mb.m[r * 4 + 3]);
-    }
+    vertex_mats_body(s, ix, A, big_A, (int)blockIdx.y, (int)(blockIdx.x * VMAT_BLOCK + threadIdx.x));
 }
 
 int launch_vertex_mats(const RenderArgs& a, const Workspace& w, hipStream_t st) {
@@ -411,35 +386,8 @@ __global__ __launch_bounds__(DF_BLOCK) void k_deform_pairs(RenderArgs a, Workspa
 // the slice of a hashed level is materialised densely).  sum_l res_l^2 = 2959 entries (24 KB) for the
 // reference's 8 levels — built once per call by k_deform_slice and held in LDS, so the 64 L1-line gathers
 // per pair that bounded the kernel become 32 ds_read_b64.  (u,v) index math stays the reference's.
-struct DfSliceInfo { int off[INVR_MAX_LEVELS + 1]; };
-
 __global__ void k_deform_slice(GridDev dg, DfSliceInfo si, const float* __restrict__ frame_dim, float2* __restrict__ out) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= si.off[dg.L]) return;
-    int l = 0;
-    while (e >= si.off[l + 1]) ++l;
-    const int res = dg.res[l];
-    const float tn = (frame_dim[0] - dg.bounds[2]) / (dg.bounds[5] - dg.bounds[2]);
-    int c0z, c1z;
-    float tz;
-    level_corners(tn, dg.cell[l], res, c0z, c1z, tz);
-    const int idx = e - si.off[l], cx = idx / res, cy = idx - cx * res;
-    const bool hashed = l >= dg.start_hash;
-    const float* tb = dg.separate_dense ? (hashed ? dg.hash + (int64_t)(l - dg.start_hash) * dg.T * 2 : dg.dense + dg.dense_off[l] * 2)
-                                        : dg.hash + (int64_t)l * dg.T * 2;
-    const float2* tab = reinterpret_cast<const float2*>(tb);
-    unsigned r0, r1;
-    if (hashed) {
-        const uint64_t hxy = (uint64_t)(uint32_t)cx ^ ((uint64_t)(uint32_t)cy * HASH_P1);
-        r0 = grid_hash_mod(hxy ^ ((uint64_t)(uint32_t)c0z * HASH_P2), dg);
-        r1 = grid_hash_mod(hxy ^ ((uint64_t)(uint32_t)c1z * HASH_P2), dg);
-    } else {
-        r0 = ((unsigned)cx * (unsigned)res + (unsigned)cy) * (unsigned)res + (unsigned)c0z;
-        r1 = ((unsigned)cx * (unsigned)res + (unsigned)cy) * (unsigned)res + (unsigned)c1z;
-    }
-    const float2 v0 = tab[r0], v1 = tab[r1];
-    const float uz = 1.0f - tz;
-    out[e] = make_float2(fmaf(tz, v1.x, uz * v0.x), fmaf(tz, v1.y, uz * v0.y));
+    deform_slice_body(dg, si, frame_dim, out, (int)(blockIdx.x * blockDim.x + threadIdx.x));
 }
 
 struct LaneSlice { int off, res; float cell; };
@@ -591,16 +539,6 @@ __global__ __launch_bounds__(DF_BLOCK) void k_deform_pairs_slice(RenderArgs a, W
             }
         }
     }
-}
-
-static bool deform_slices_fit(const GridDev& dg, DfSliceInfo& si, int cbv) {
-    si.off[0] = 0;
-    for (int l = 0; l < INVR_MAX_LEVELS; ++l) si.off[l + 1] = si.off[l] + (l < dg.L ? dg.res[l] * dg.res[l] : 0);
-    return dg.L == 8 && si.off[8] <= DF_SLICE_MAX && cbv < 10;
-}
-static int deform_cb() {
-    static int cbv = getenv("INVR_DF_CB") ? atoi(getenv("INVR_DF_CB")) : 2;
-    return cbv;
 }
 
 // depends on the grid and frame_dim only (not on the pair lists): launched on the side stream beside the KNN

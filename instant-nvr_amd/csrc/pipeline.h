@@ -138,7 +138,9 @@ __device__ __forceinline__ void sample_pose_point(const RenderArgs& a, int64_t i
 
 // ---- pipeline stage launchers ------------------------------------------------------------------
 int launch_cull_cells(const RenderArgs& a, const Workspace& w, hipStream_t st);      // -> 1 if the cell mask / live list were built
-int launch_cull(const RenderArgs& a, const Workspace& w, int64_t max_active, bool have_cells, hipStream_t st);
+int launch_cull(const RenderArgs& a, const Workspace& w, int64_t max_active, bool have_cells, bool flags_done, hipStream_t st);   // flags_done: k_front_cull wrote the masks, only scan + compaction remain
+int launch_front_scene(const RenderArgs& a, const Workspace& w, const GridDev& dg, int* have_cells, hipStream_t st);     // k_knn.hip: index + cell mask + vertex matrices + deformer slices, one launch
+int launch_front_cull(const RenderArgs& a, const Workspace& w, int* done, hipStream_t st);                               // k_knn.hip: lattice-cell classes + cull flags, one launch
 int launch_pose_points(const RenderArgs& a, const int32_t* idx, int64_t n, float* pts, float* dirs, hipStream_t st);
 int launch_knn_prepare(const RenderArgs& a, const Workspace& w, hipStream_t st);
 int launch_vertex_mats(const RenderArgs& a, const Workspace& w, hipStream_t st);

@@ -4,7 +4,7 @@ kernel code of the product at toy sizes.  The sources are used as they are, exce
 host spelling and are rewritten on the fly (the csrc tree stays free of host-simulation conditionals):
   * `extern __shared__ T name[];`                 -> a pointer to the simulated dynamic LDS
   * the v_min_f64 / v_max_f64 inline assembly      -> fmin / fmax (the keys are finite non-negative doubles, k_knn.hip:68-72)
-  * the empty `asm volatile("" : "+v"...)` fences  -> dropped
+  * the empty `asm volatile("" : "+v"...)` fences  -> dropped (also `amdgpu_waves_per_eu` occupancy attributes)
 Nothing under instant-nvr_amd/ imports this module or loads its output."""
 import concurrent.futures as cf
 import hashlib
@@ -38,6 +38,7 @@ REWRITES = [
     (re.compile(r'asm\("v_min_f64 %0, %1, %2" : "=v"\((\w+)\) : "v"\((\w+)\), "v"\((\w+)\)\);'), r'\1 = fmin(\2, \3);'),
     (re.compile(r'asm\("v_max_f64 %0, %1, %2" : "=v"\((\w+)\) : "v"\((\w+)\), "v"\((\w+)\)\);'), r'\1 = fmax(\2, \3);'),
     (re.compile(r'asm volatile\("" : [^;]*\);'), r''),
+    (re.compile(r'__attribute__\(\(amdgpu_waves_per_eu\([^)]*\)\)\)'), r''),        # (an occupancy request of the device compiler)
 ]
 
 
