@@ -46,6 +46,7 @@ import torch.distributed as dist           # noqa: E402
 import invr                                # noqa: E402,F401
 from invr import scene as scene_mod, _abi  # noqa: E402
 from invr import dist as idist             # noqa: E402
+from invr import frames as iframes         # noqa: E402
 from invr.config import make_cfg           # noqa: E402
 from invr.network import Network           # noqa: E402
 
@@ -159,38 +160,26 @@ def winner_counts(out, stats):
     return [int(x) - 1 for x in v['wcnt'][:g_last + 1].sum(0).cpu().tolist()]
 
 
-def graph_of(render):
-    """Capture one frame (the kernels of invr_render_fwd, enqueued on torch's capture stream) as a hipGraph -> (replay, outputs)."""
-    graph = torch.cuda.CUDAGraph()
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        render()
-    torch.cuda.current_stream().wait_stream(side)
-    with torch.cuda.graph(graph, capture_error_mode='thread_local'):
-        res = render()
-    return graph, res
+def frame_batches(res, cam_dist, K, dev):
+    """K frames of a synthetic sequence: the same body, K poses / body orientations / latent codes (frame 0 = the frame of the round-1..3
+    bench lines).  -> (collated batches on the host, on the device)."""
+    cpu, gpu = [], []
+    for k in range(K):
+        bnp, _ = scene_mod.make_scene(res, res, seed=0, frame=(3 + 7 * k) % 100, cam_dist=cam_dist, pose_seed=k)
+        b = scene_mod.to_torch(bnp)
+        cpu.append(b)
+        gpu.append({kk: v.to(dev) for kk, v in b.items()})
+    return cpu, gpu
 
 
-def pipelined(net, render, depth):
-    """`depth` captured graphs of render() (own workspace / outputs each), replayed round-robin on `depth` streams -> fn()."""
-    slots = []
-    for _ in range(max(1, depth)):
-        net._ws = None
-        g, _ = graph_of(render)
-        slots.append((g, torch.cuda.Stream()))
-    torch.cuda.synchronize()
-    cnt = [0]
-
-    def fn():
-        g, strm = slots[cnt[0] % len(slots)]
-        cnt[0] += 1
-        if len(slots) == 1:
-            return g.replay()
-        strm.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(strm):
-            g.replay()
-    return fn
+def frame_set(net, batches, S, rank, world, shard_of=0, want_raw=True, capture=True):
+    """invr.frames.FrameSet over this rank's shards of `batches`: one hipGraph replay renders all of them side by side (and, world > 1,
+    exchanges their tiles with one captured all-gather).  shard_of = W renders rank 0's shard of a W-way split without any exchange."""
+    fns, n_rays, keep = iframes.shard_render_fns(net, batches, S, 0 if shard_of else rank, shard_of or world, want_raw=want_raw)
+    fs = iframes.FrameSet(fns, n_rays, rank=0 if shard_of else rank, world=1 if shard_of else world, device=batches[0]['ray_o'].device,
+                          capture=capture)
+    fs._keep = keep
+    return fs
 
 
 def time_frames(fn, frames, min_time=0.0, max_regions=200):
@@ -209,63 +198,82 @@ def time_frames(fn, frames, min_time=0.0, max_regions=200):
             return tot / n * 1e3
 
 
-def variant_lines(net, cfg, batch, dev, S, n_rays, in_flight=1):
-    """Driver-visible variants of the headline frame (SURVEY 8d asks for them): the yaml-default 64 samples/ray,
-    the dense stress frame (smpl_thresh = +inf: every ray-sample survives), the trainable 64-byte rows instead of the row-sum
-    tables, the 8-way strong-scaling projection from rank 0's shard of a W-way split on this one GPU, and the wall clock of the
-    drop-in call Renderer.render(batch) itself."""
+def variant_lines(net, cfg, batches, dev, S, in_flight=1):
+    """Driver-visible variants of the headline frames (SURVEY 8d asks for them): the strong-scaling projection from
+    rank 0's shard of a W-way split on this one GPU, the yaml-default 64 samples/ray, a mid-density frame (smpl_thresh 0.1: ~3x the
+    survivors), the trainable 64-byte rows instead of the row-sum tables, the dense stress frame (smpl_thresh = +inf: every ray-sample
+    survives), and the wall clock of the drop-in call Renderer.render(batch) itself."""
     import copy
     from invr.renderer import Renderer
-    ro, rd, nr, fr = (batch[k][0].contiguous() for k in ('ray_o', 'ray_d', 'near', 'far'))
+    batch = batches[0]
+    n_rays = int(batch['ray_o'].shape[1])
+    mean_rays = sum(int(b['ray_o'].shape[1]) for b in batches) / len(batches)
     out = {}
 
-    def frame_ms(ctx, s, frames, idx=None, graph=True, min_time=0.25):
-        a = (ro, rd, nr, fr) if idx is None else tuple(t[idx].contiguous() for t in (ro, rd, nr, fr))
-        render = lambda: net.render_rays(ctx, a[0], a[1], a[2], a[3], s, want_raw=True)
-        if graph:
-            try:
-                return time_frames(pipelined(net, render, in_flight), frames, min_time)
-            except Exception as e:
-                sys.stderr.write('variant: hipGraph capture failed (%s), eager launches\n' % e)
-        return time_frames(render, frames, min_time)
+    def frames_ms(s, frames, shard_of=0, bs=None, min_time=0.25):
+        """ms per frame of the frames `bs` (default: the headline's) rendered `in_flight` at a time by one graph replay"""
+        bs = bs or batches
+        fs = frame_set(net, bs, s, 0, 1, shard_of=shard_of)
+        ms = time_frames(fs.replay, max(1, frames // len(bs)), min_time) / len(bs)
+        assert iframes.check_overflow(fs), 'workspace overflow in a variant'
+        st = [o['stats'].cpu().numpy().astype('int64') for o in fs.local]
+        del fs
+        torch.cuda.empty_cache()
+        return ms, st
 
-    ctx = net.prepare(batch)
-    # (1) strong-scaling projection: rank 0's tile-cyclic shard of a W-way split, one GPU, hipGraph replay as in the headline
-    shard = {}
+    # (1) strong-scaling projection: rank 0's tile-cyclic shard of a W-way split, one GPU, frames in flight as in the headline —
+    #     and with strictly one frame at a time (the latency of a single frame)
+    shard, shard1 = {}, {}
     for W in (1, 2, 4, 8):
-        shard[str(W)] = frame_ms(ctx, S, 20, idx=idist.tile_indices(n_rays, 0, W, device=dev))
+        shard[str(W)] = frames_ms(S, 20, shard_of=W)[0]
+        shard1[str(W)] = frames_ms(S, 20, shard_of=W, bs=batches[:1])[0]
     out['shard_projection'] = {
         'ms_per_frame_of_rank0_shard': shard, 'projected_speedup': {w: shard['1'] / shard[w] for w in shard},
-        'frames_in_flight': in_flight,
-        'note': 'rank 0 of a W-way tile-cyclic split rendered on ONE GPU (full per-frame scene work included, the 4 MB all-gather is '
-                'not), frames pipelined as in the headline: the single-GPU evidence for strong scaling; the measured multi-GPU curve is '
-                'the driver\'s SCALE record'}
+        'frames_in_flight': len(batches),
+        'one_frame_at_a_time': {'ms_per_frame_of_rank0_shard': shard1, 'projected_speedup': {w: shard1['1'] / shard1[w] for w in shard1}},
+        'note': 'rank 0 of a W-way tile-cyclic split rendered on ONE GPU (full per-frame scene work included, the all-gather is not), '
+                '%d frames of the sequence per hipGraph replay as in the headline; one_frame_at_a_time = frame 0 alone, one replay per '
+                'frame (the latency view): the single-GPU evidence for strong scaling; the measured multi-GPU curve is the driver\'s SCALE '
+                'record' % len(batches)}
     # (2) 64 samples per ray (configs/inb/inb_377.yaml default)
-    ms = frame_ms(ctx, 64, 20)
-    out['samples_64'] = {'ms_per_frame': ms, 'ray_samples_per_sec': n_rays * 64 / (ms * 1e-3), 'samples_per_ray': 64}
-    # (3) the 64-byte trainable rows (what a training-mode forward reads) instead of the derived row-sum tables
+    ms, _ = frames_ms(64, 20)
+    out['samples_64'] = {'ms_per_frame': ms, 'ray_samples_per_sec': mean_rays * 64 / (ms * 1e-3), 'samples_per_ray': 64}
+    # (3) a mid-density frame: smpl_thresh 0.1 (inb_lan.yaml's value) keeps ~3x the survivors of inb_377's 0.05
+    mcfg = copy.deepcopy(cfg)
+    mcfg['smpl_thresh'] = 0.1
+    net.cfg = mcfg
+    try:
+        ms, st = frames_ms(S, 12)
+    finally:
+        net.cfg = cfg
+    out['mid_density'] = {'ms_per_frame': ms, 'ray_samples_per_sec': mean_rays * S / (ms * 1e-3), 'smpl_thresh': 0.1,
+                          'active_fraction': float(sum(int(s[0]) for s in st)) / (mean_rays * S * len(st)),
+                          'pairs_per_active_sample': float(sum(int(s[1:6].sum()) for s in st)) / max(1, sum(int(s[0]) for s in st))}
+    # (4) the 64-byte trainable rows (what a training-mode forward reads) instead of the derived row-sum tables
     old = cfg.get('eval_row_sums', True)
     cfg['eval_row_sums'] = False
     try:
-        ms = frame_ms(net.prepare(batch), S, 10)
+        ms, _ = frames_ms(S, 12)
     finally:
         cfg['eval_row_sums'] = old
-    out['full_rows'] = {'ms_per_frame': ms, 'ray_samples_per_sec': n_rays * S / (ms * 1e-3),
+    out['full_rows'] = {'ms_per_frame': ms, 'ray_samples_per_sec': mean_rays * S / (ms * 1e-3),
                         'table_bytes_per_pair': PAIR_TABLE_BYTES, 'note': 'k_part_encode: 16 levels x 8 corners x 64-byte rows per pair'}
-    # (4) dense stress: every ray-sample survives the cull (113 M evaluated pairs, 28 GB workspace), 3 frames
+    # (5) dense stress: every ray-sample survives the cull (113 M evaluated pairs, 28 GB workspace), 3 eager frames of frame 0
+    ro, rd, nr, fr = (batch[k][0].contiguous() for k in ('ray_o', 'ray_d', 'near', 'far'))
     dcfg = copy.deepcopy(cfg)
     dcfg['smpl_thresh'] = 1e9
     net.cfg = dcfg
     try:
         dctx = net.prepare(batch)
-        ms = frame_ms(dctx, S, 3, graph=False, min_time=0.0)
+        net._ws = None
+        ms = time_frames(lambda: net.render_rays(dctx, ro, rd, nr, fr, S, want_raw=True), 3, 0.0)
         st = net.render_rays(dctx, ro, rd, nr, fr, S, want_raw=True)['stats'].cpu().numpy().astype('int64')
     finally:
         net.cfg = cfg
         net._ws = None                                       # give the 28 GB back
     out['dense_stress'] = {'ms_per_frame': ms, 'ray_samples_per_sec': n_rays * S / (ms * 1e-3), 'frames': 3,
                            'active_samples': int(st[0]), 'evaluated_pairs': int(st[1:6].sum())}
-    # (5) the drop-in call: Renderer.render(batch) as run.py / the evaluator call it (wall clock, host side included)
+    # (6) the drop-in call: Renderer.render(batch) as run.py / the evaluator call it (wall clock, host side included)
     api = {}
     for to_cpu, pin, key in ((False, True, 'eval_to_cpu_false_ms'), (True, True, 'eval_to_cpu_true_ms'), (True, False, 'eval_to_cpu_true_pageable_ms')):
         r = Renderer(net)
@@ -277,6 +285,7 @@ def variant_lines(net, cfg, batch, dev, S, n_rays, in_flight=1):
         t0 = time.perf_counter()
         for _ in range(3):
             ret = r.render(b)
+            _ = ret['rgb_map'], ret['acc_map']              # what the reference's evaluator / visualizers read (evaluators/if_nerf.py:77)
         torch.cuda.synchronize()
         api[key] = (time.perf_counter() - t0) / 3 * 1e3
     api['outputs'] = sorted(ret.keys())
@@ -444,7 +453,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--train-iters', type=int, default=10, help='iterations of the informational training-step probe (0 = skip; N=1 only)')
     ap.add_argument('--no-graph', action='store_true', help='launch the ~25 kernels of a frame eagerly instead of replaying one captured hipGraph')
-    ap.add_argument('--in-flight', type=int, default=1, help='frames in flight (captured graphs replayed round-robin on as many streams); 1 = strictly one frame at a time')
+    ap.add_argument('--in-flight', type=int, default=4, help='frames of the sequence rendered side by side by one hipGraph replay (invr.frames); reduced to a divisor of --steps; 1 = strictly one frame at a time')
     ap.add_argument('--no-variants', action='store_true', help='skip the S=64 / dense / full-row / shard-projection / API-frame variants of the default line')
     ap.add_argument('--shard-of', type=int, default=0, help='debug (1 GPU): render only rank 0\'s ray shard of a W-way split')
     args = ap.parse_args()
@@ -477,108 +486,59 @@ def main():
     cfg['eval_row_sums'] = not args.full_rows
     net = build_model(cfg, dev)
     n_params = sum(p.numel() for p in net.parameters())
-    batch_np, _ = scene_mod.make_scene(args.res, args.res, seed=0, cam_dist=args.cam_dist)
-    batch_cpu = scene_mod.to_torch(batch_np)
-    batch = {k: v.to(dev) for k, v in batch_cpu.items()}
-    n_rays = batch['ray_o'].shape[1]
     S = args.samples
+    want_raw = not args.no_raw
+    # Frames in flight: K frames of the sequence (K poses) are rendered by ONE hipGraph replay, as K parallel branches (invr.frames);
+    # a step is still one frame, and a timed region is exactly --steps frames = --steps / K replays, so K divides --steps.
+    K = max(1, min(args.in_flight, args.steps))
+    while args.steps % K:
+        K -= 1
+    if args.dense or args.no_graph:
+        K = 1
+    batches_cpu, batches = frame_batches(args.res, args.cam_dist, K, dev)
+    batch_cpu, batch = batches_cpu[0], batches[0]
+    n_rays = batch['ray_o'].shape[1]
+    rays_per_frame = [int(b['ray_o'].shape[1]) for b in batches]
+    mean_rays = sum(rays_per_frame) / K
 
-    # shard the frame's rays (tile-cyclic) once; inputs stay resident in HBM
+    # frame 0's shard for the eager per-stage profile (below) — the timed frames are rendered through the FrameSet
     idx = idist.tile_indices(n_rays, rank, args.shard_of or world, device=dev)
     ro, rd = batch['ray_o'][0][idx].contiguous(), batch['ray_d'][0][idx].contiguous()
     nr, fr = batch['near'][0][idx].contiguous(), batch['far'][0][idx].contiguous()
     ctx = net.prepare(batch)
-    want_raw = not args.no_raw
 
     def render():
-        out = net.render_rays(ctx, ro, rd, nr, fr, S, want_raw=want_raw)
-        return out, torch.cat([out['rgb_map'], out['acc_map'][:, None]], 1)
-
-    # N > 1: ONE all-gather in flight — the 4 MB exchange of frame f (RCCL, its own stream) runs beside the kernels of frame f+1 and is
-    # joined when frame f+1's exchange has been issued; every frame's full map is complete before the fence that ends a timed region
-    # (INVR_BENCH_SYNC_GATHER=1: join every exchange before the next frame starts)
-    overlap = [world > 1 and not os.environ.get('INVR_BENCH_SYNC_GATHER')]
-    pend, last_full = [None], [None]
-
-    def gather(rgba):
-        if overlap[0]:
-            try:
-                nxt = idist.gather_maps_async(rgba.clone(), n_rays, rank, world)       # (a copy: the next replay overwrites the graph's buffer)
-            except Exception as e:                  # keep the bench alive: the synchronous exchange measures the same work
-                sys.stderr.write('asynchronous all-gather failed (%s); joining every exchange before the next frame\n' % e)
-                overlap[0] = False
-        if not overlap[0]:
-            if pend[0] is not None:
-                pend[0].result()
-                pend[0] = None
-            last_full[0] = idist.gather_maps(rgba, n_rays, rank, world)
-            return last_full[0]
-        if pend[0] is not None:
-            last_full[0] = pend[0].result()
-        pend[0] = nxt
-        return last_full[0]
-
-    def step():
-        out, rgba = render()
-        return out, gather(rgba)
+        return net.render_rays(ctx, ro, rd, nr, fr, S, want_raw=want_raw)
 
     def fence():
-        if pend[0] is not None:
-            last_full[0] = pend[0].result()
-            pend[0] = None
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(max(args.warmup, 1)):
-        out, full = step()
-    fence()
+    # N > 1: every rank renders its tile-cyclic shard of the K frames; ONE all-gather of the K frames' [r, g, b, acc] tiles and the K
+    # index_selects are part of the same captured graph: one replay = K complete frames on every rank, no per-frame host work.
     use_graph = not args.no_graph
+    fs = None
     if use_graph:
-        # one hipGraph per frame: the kernels of invr_render_fwd are enqueued on torch's capture stream
-        # (the library never synchronises or allocates), so a frame replays with one launch.  thread_local capture
-        # mode: the RCCL watchdog thread of a multi-rank run may query events while this thread captures.
         try:
-            # --in-flight D frames at a time: D captured graphs with their own workspace / output buffers, replayed round-robin
-            # on D streams — frame f+1's kernels start while frame f's short, latency-bound launches (a 1/8 ray shard keeps a
-            # fraction of the 256 CUs busy) are still running.  Frames are independent; every frame still does all its work.
-            slots = []
-            for k in range(max(1, args.in_flight)):
-                net._ws = None                                       # a workspace of its own (allocated in the graph's pool)
-                g, (g_out, g_rgba) = graph_of(render)
-                slots.append((g, torch.cuda.Stream(), g_out, g_rgba))
-            torch.cuda.synchronize()
-            cnt = [0]
-
-            def step():
-                g, strm, g_out, g_rgba = slots[cnt[0] % len(slots)]
-                cnt[0] += 1
-                if len(slots) == 1:
-                    g.replay()
-                    return g_out, gather(g_rgba)
-                strm.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(strm):
-                    g.replay()
-                    return g_out, gather(g_rgba)
-            out, full = step()
+            fs = frame_set(net, batches, S, rank, world, shard_of=args.shard_of, want_raw=want_raw)
         except Exception as e:                       # keep the bench alive: eager launches measure the same work
             sys.stderr.write('hipGraph capture failed (%s); falling back to eager launches\n' % e)
             use_graph = False
-
-            def step():
-                out, rgba = render()
-                return out, gather(rgba)
-            out, full = step()
-        fence()
-    # The timed region is EXACTLY K steps between two fences.  A frame takes ~3 ms, so one region is a few tens of
+    if fs is None:
+        fs = frame_set(net, batches, S, rank, world, shard_of=args.shard_of, want_raw=want_raw, capture=False)
+    for _ in range(max(1, -(-args.warmup // K))):
+        fs.replay()
+    fence()
+    # The timed region is EXACTLY K steps (frames) between two fences.  A frame takes ~2 ms, so one region is a few tens of
     # milliseconds: the region is repeated (each repeat again exactly K steps between fences) until >= --min-time seconds
     # have been timed, and the reported time per step is the mean over all repeats.
     region = []
     while True:
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out, full = step()
+        for _ in range(args.steps // K):
+            fs.replay()
         fence()
         region.append(time.perf_counter() - t0)
         enough = sum(region) >= args.min_time or len(region) >= 1000
@@ -590,34 +550,53 @@ def main():
             break
     repeats = len(region)
     dt = sum(region) / repeats
-    # per-stage HIP-event times: a few extra eager frames outside the timed region (event records are not
+    assert iframes.check_overflow(fs), 'workspace overflow'
+    for k in range(K):
+        assert fs.full[k] is not None and fs.full[k].shape[0] == (rays_per_frame[k] if not args.shard_of else fs.full[k].shape[0])
+        assert bool(torch.isfinite(fs.full[k]).all())
+    frame_stats = [o['stats'].cpu().numpy().astype('int64') for o in fs.local]
+    # the exchange alone (N > 1): the captured all-gather + index_selects replayed without the renders
+    exchange_ms = None
+    if world > 1 and fs.exchange and fs.graph is not None:
+        try:
+            gx = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gx, capture_error_mode='thread_local'):
+                fs._exchange()
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(50):
+                gx.replay()
+            fence()
+            exchange_ms = (time.perf_counter() - t0) / 50 * 1e3
+        except Exception as e:
+            sys.stderr.write('exchange-only timing failed (%s)\n' % e)
+    # per-stage HIP-event times: a few extra eager frames (frame 0) outside the timed region (event records are not
     # replayable graph nodes)
+    net._ws = None
     _abi.profile_enable(True)
     _abi.profile_read()
     for _ in range(3):
-        render()
+        out = render()
     torch.cuda.synchronize()
     _abi.profile_enable(False)
     stage_ms, n_prof = _abi.profile_read()
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    stats = out['stats'].cpu().numpy().astype('int64')
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    stats = out['stats'].cpu().numpy().astype('int64')              # frame 0, this rank's shard (the eager profile frames)
     assert stats[6] == 0, 'workspace overflow'
-    full = last_full[0]
-    assert full is not None and bool(torch.isfinite(full).all())
+    stats_sum = sum(frame_stats)                                     # the K timed frames, this rank's shards
     if world > 1:
-        st = torch.from_numpy(stats).to(dev)
+        st = torch.from_numpy(stats_sum).to(dev)
         dist.all_reduce(st)
-        stats_all = st.cpu().numpy()
-    else:
-        stats_all = stats
+        stats_sum = st.cpu().numpy()
+    stats_all = stats_sum / K                                        # per frame, all ranks
 
     if rank == 0:
-        total_samples = n_rays * S
+        total_samples = mean_rays * S                    # per step (frame): the K frames of the sequence differ by a few rays
         ms_per_step = dt / args.steps * 1e3
-        value = total_samples * args.steps / dt          # dt = mean duration of one K-step region
+        value = total_samples * args.steps / dt          # dt = mean duration of one K-step region (= steps / K replays of K frames)
         pairs_local = int(stats[1:6].sum())
         winners = winner_counts(out, stats)              # rank 0's shard
         n_rgb = [len(pn.rgb.linears) for pn in net.tpose_human.part_networks]
@@ -657,18 +636,23 @@ def main():
             'config': {
                 'workload': 'configs[1]: ZJU-MoCap-377-shaped synthetic frame, inb_377 defaults (full 1.09 GB tables), '
                             '%dx%d, %d samples/ray%s' % (args.res, args.res, S, ', DENSE stress (smpl_thresh=inf)' if args.dense else ''),
-                'rays': int(n_rays), 'samples_per_ray': S, 'ray_samples_per_step': int(total_samples),
-                'active_samples': int(stats_all[0]), 'active_fraction': float(stats_all[0]) / total_samples,
+                'rays': int(round(mean_rays)), 'rays_per_frame': rays_per_frame, 'samples_per_ray': S, 'ray_samples_per_step': int(total_samples),
+                'active_samples': int(stats_all[0]), 'active_samples_per_frame_rank0': [int(s[0]) for s in frame_stats],
+                'active_fraction': float(stats_all[0]) / total_samples,
                 'survivors_per_sec': float(stats_all[0]) * args.steps / dt,
                 'pairs_per_part': [int(v) for v in stats_all[1:6]],
                 'pairs_per_active_sample': float(stats_all[1:6].sum()) / max(int(stats_all[0]), 1),
                 'colour_mlp_pairs_per_part_rank0': winners,
-                'parameters': int(n_params), 'raw_occ_materialised': want_raw, 'hip_graph': use_graph, 'frames_in_flight': (max(1, args.in_flight) if use_graph else 1),
-                'parallelism': 'tile-cyclic ray shards x%d, full replicas, 1 all-gather/frame%s' % (world, ' (in flight beside the next frame)' if overlap[0] else ''),
-                'rays_per_sec': n_rays * args.steps / dt,
-                'note': 'value counts every ray-sample of the frame; %.1f %% of them survive the near-surface cull (the camera sits at %.1f m so '
-                        'that the body fills the frame) — survivors_per_sec is the rate of the samples that reach the networks'
-                        % (100.0 * float(stats_all[0]) / total_samples, args.cam_dist),
+                'parameters': int(n_params), 'raw_occ_materialised': want_raw, 'hip_graph': use_graph, 'frames_in_flight': K,
+                'frames': '%d frames of a synthetic sequence (same body, %d poses / orientations / latent codes; frame 0 = the frame of the '
+                          'round-1..3 lines) rendered side by side by ONE hipGraph replay (parallel branches, invr.frames.FrameSet); a step is '
+                          'one frame, every frame does all of its per-frame scene work' % (K, K),
+                'parallelism': 'tile-cyclic ray shards x%d, full replicas, 1 all-gather per %d frames inside the same graph replay' % (world, K),
+                'exchange_only_ms_per_replay': exchange_ms,
+                'rays_per_sec': mean_rays * args.steps / dt,
+                'note': 'value counts every ray-sample of the frames; %.1f %% of them survive the near-surface cull (the camera sits at %.1f m so '
+                        'that the body fills the frame) — survivors_per_sec is the rate of the samples that reach the networks; mid_density is '
+                        'the same sequence at smpl_thresh 0.1' % (100.0 * float(stats_all[0]) / total_samples, args.cam_dist),
             },
             # dominant roofline-bound stage: the tiny MLPs of all five parts on the fp32 matrix cores
             'roofline': {
@@ -718,10 +702,14 @@ def main():
                 'note': 'the frame is issue-bound: KNN = VALU, part MLPs = MFMA + transcendental issue, encoder = VALU index math + L2-miss '
                         'latency; see roofline / roofline_other counters'},
             'stage_ms_per_step': {k: v / per for k, v in stage_ms.items()},
+            'stage_note': 'HIP-event stage times of frame 0 rendered ALONE (eager launches after the timed region); with %d frames in flight '
+                          'the stages of different frames overlap, so their sum exceeds ms_per_step' % K,
         }
         if world == 1 and not args.no_variants and headline:
             try:
-                line.update(variant_lines(net, cfg, batch, dev, S, n_rays, max(1, args.in_flight)))
+                del fs
+                torch.cuda.empty_cache()
+                line.update(variant_lines(net, cfg, batches, dev, S, K))
             except Exception as e:          # informational: never lose the bench line over a variant
                 line['variants_error'] = repr(e)
         if world == 1 and args.train_iters > 0 and not args.shard_of:

@@ -724,15 +724,8 @@ __global__ __launch_bounds__(RS_BLOCK) void k_part_encode_rs_xcd(EncodeAllArgs a
         const float b0x = g.bounds[0], b0y = g.bounds[1], b0z = g.bounds[2];
         const float ex = g.bounds[3] - b0x, ey = g.bounds[4] - b0y, ez = g.bounds[5] - b0z;
         const int hstart = g.separate_dense ? g.start_hash : 0;
-#ifdef EXP_ENC_RCPNORM   // experiment build (tools/build_variant.sh, unmeasured): the three normalising quotients through exact reciprocals
-        const float rex = rcp_for_div(ex), rey = rcp_for_div(ey), rez = rcp_for_div(ez);
-#endif
         for (int64_t i = tile0 * RS_BLOCK + threadIdx.x; i < cnt; i += (int64_t)tstride * RS_BLOCK) {
-#ifdef EXP_ENC_RCPNORM
-            const float x = div_exact(xs[i] - b0x, ex, rex), y = div_exact(xs[a.stride + i] - b0y, ey, rey), z = div_exact(xs[2 * a.stride + i] - b0z, ez, rez);
-#else
             const float x = (xs[i] - b0x) / ex, y = (xs[a.stride + i] - b0y) / ey, z = (xs[2 * a.stride + i] - b0z) / ez;   // :112
-#endif
             if (lg < 3) emb[(int64_t)lg * a.cap + i] = lg == 0 ? x : (lg == 1 ? y : z);
             else if (lg == 3) emb[(int64_t)(EMB_K - 1) * a.cap + i] = 0.0f;          // pad column
             emb[(int64_t)(3 + la) * a.cap + i] = level_rowsum(g, rs, hstart, la, x, y, z);

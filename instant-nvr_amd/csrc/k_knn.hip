@@ -412,12 +412,7 @@ __device__ __forceinline__ void scan_sub16(const float4* sv, v2f px, v2f py, v2f
     for (int m0 = 0; m0 < 8; m0 += 4) {
         float4 A[4], B[4];
 #pragma unroll
-#ifdef EXP_KNN_B128      // experiment build (tools/build_variant.sh): the whole second record up front — the compiler otherwise reads {z0,z1} here and
-                         // {row0,row1} lazily inside the insert branch (one more exposed LDS round trip per insert)
-        for (int k = 0; k < 4; ++k) { A[k] = sv[(m0 + k) * 2]; B[k] = lds_ld4(sv + (m0 + k) * 2 + 1); }
-#else
         for (int k = 0; k < 4; ++k) { A[k] = sv[(m0 + k) * 2]; B[k] = sv[(m0 + k) * 2 + 1]; }   // wave-uniform addresses
-#endif
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const v2f dx = px - (v2f){A[k].x, A[k].y}, dy = py - (v2f){A[k].z, A[k].w}, dz = pz - (v2f){B[k].x, B[k].y};
@@ -562,18 +557,7 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w) 
     const int n_cls = min(16, (int)gridDim.x), my_cls = (int)blockIdx.x % n_cls;
     int32_t* my_counter = w.counters + CNT_TICKETS + my_cls * 32;
     int ticket = (int)blockIdx.x * (KNN_T / 64) + (int)(threadIdx.x >> 6);
-#ifdef EXP_KNN_TSIZE     // experiment build (tools/build_variant.sh, unmeasured): a frame with fewer than ~1.5 tickets per resident wave — a 1/8
-                         // shard: 4687 tickets for 4096 waves, two latency-bound rounds for 591 of them — deals every wave one or two EQUAL,
-                         // smaller tickets instead (results do not depend on the ticket size)
-    int tsize = 64;
-    {
-        const long long per_wave = ((long long)na + n_wave - 1) / n_wave;
-        if (per_wave <= 64) tsize = max(32, (int)per_wave);
-        else if (per_wave <= 96) tsize = max(32, (int)((per_wave + 1) / 2));
-    }
-#else
     constexpr int tsize = 64;
-#endif
     while ((int64_t)ticket * tsize < na) {
         KP_CNT(8)
         const int64_t slot = (int64_t)ticket * tsize + lane;
@@ -740,22 +724,7 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w) 
             const int c = __popcll(__ballot((flags >> p) & 1u));
             if (lane == p) my_cnt = c;
         }
-#ifdef EXP_KNN_TSIZE     // a ticket of tsize < 64 survivors may straddle two slot groups: lanes 0..4 count the first group's pairs, 8..12 the second's
-        {
-            const int64_t g0 = (slot - lane) / PAIR_GROUP;
-            my_cnt = 0;
-#pragma unroll
-            for (int p = 0; p < INVR_NUM_PARTS; ++p) {
-                const bool f = (flags >> p) & 1u;
-                const int c0 = __popcll(__ballot(f && slot / PAIR_GROUP == g0)), c1 = __popcll(__ballot(f && slot / PAIR_GROUP != g0));
-                if (lane == p) my_cnt = c0;
-                if (lane == 8 + p) my_cnt = c1;
-            }
-            if (my_cnt) atomicAdd(&w.gcount[(g0 + (lane >> 3)) * INVR_NUM_PARTS + (lane & 7)], my_cnt);
-        }
-#else
         if (my_cnt) atomicAdd(&w.gcount[(slot - lane) / PAIR_GROUP * INVR_NUM_PARTS + lane], my_cnt);      // (64 | PAIR_GROUP; not returned)
-#endif
         if (live) {
             w.pflags[slot] = (uint8_t)flags;
             w.farflags[slot] = (uint8_t)farflags;

@@ -152,14 +152,16 @@ def get_near_far(bounds, ray_o, ray_d):
 
 
 def make_scene(H=64, W=64, seed=0, frame=3, num_train_frame=100, bbox_overlap=0.2, pose_scale=0.5,
-               cam_dist=3.0, crop=None):
+               cam_dist=3.0, crop=None, pose_seed=None):
     """Build one collated ``batch`` (numpy arrays with the leading batch dim of 1).
 
     ``crop`` = (y0, x0, h, w) keeps only the rays of that pixel window (training patches).
+    ``pose_seed`` draws the pose / body orientation of the SAME body (``seed``) from another stream: the frames of a sequence
+    (None = the pose of ``seed``, the frame every fixture and the round-1..3 bench lines use).
     Returns (batch, extras) where extras holds un-batched helper arrays (rest verts, ...).
     """
     from scipy.spatial import cKDTree
-    rng = np.random.RandomState(seed + 1000)
+    rng = np.random.RandomState((seed if pose_seed is None else 7919 * pose_seed + seed) + 1000)
     tverts, weights, parts, vuv = make_body(seed)
 
     poses = rng.uniform(-1, 1, (24, 3)) * pose_scale / np.sqrt(3)
