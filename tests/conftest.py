@@ -1,3 +1,6 @@
+import os as _os
+_os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')      # before the first device call of the session: see instant-nvr_amd/__init__.py
+
 import os
 import sys
 

@@ -93,6 +93,51 @@ def test_async_gather_world2_one_frame_in_flight():
     assert all(ret[r] for r in range(2)), dict(ret)
 
 
+def _frameset_worker(rank, world, port, sizes, tile, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        # K frames of different sizes per exchange (invr.frames.FrameSet, eager on CPU: the graph capture is a GPU matter): ONE
+        # all-gather for all of them, every rank ends with every frame's full map in ray order
+        from invr import frames as iframes
+        frames = [make_batch(n, seed=10 + k) for k, n in enumerate(sizes)]
+        fns = []
+        for b, n in zip(frames, sizes):
+            idx = idist.tile_indices(n, rank, world, tile)
+
+            def fn(b=b, idx=idx):
+                rgb, acc = fake_render(b['ray_o'][0][idx], b['ray_d'][0][idx], b['near'][0][idx], b['far'][0][idx])
+                return {'rgb_map': rgb, 'acc_map': acc}
+            fns.append(fn)
+        fs = iframes.FrameSet(fns, sizes, rank=rank, world=world, device='cpu', tile=tile, capture=False)
+        ok = fs.exchange and fs.plan['rows'] == sum(max(idist.shard_counts(n, world, tile)) for n in sizes)
+        for _ in range(2):                                           # a second replay reuses the buffers
+            fs.replay()
+            for b, full in zip(frames, fs.full):
+                ref_rgb, ref_acc = fake_render(b['ray_o'][0], b['ray_d'][0], b['near'][0], b['far'][0])
+                ok = ok and torch.equal(full[:, :3], ref_rgb) and torch.equal(full[:, 3], ref_acc)
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_frame_set_world2_ragged_frames_one_exchange():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_frameset_worker, args=(2, _free_port(), (1000, 30, 517, 64), 64, ret), nprocs=2, join=True)
+    assert all(ret[r] for r in range(2)), dict(ret)
+
+
+def test_frame_set_single_rank_is_the_local_render():
+    from invr import frames as iframes
+    b = make_batch(300, seed=3)
+    rgb, acc = fake_render(b['ray_o'][0], b['ray_d'][0], b['near'][0], b['far'][0])
+    fs = iframes.FrameSet([lambda: torch.cat([rgb, acc[:, None]], 1)], [300], device='cpu', capture=False)
+    fs.replay()
+    assert not fs.exchange and torch.equal(fs.full[0][:, :3], rgb) and torch.equal(fs.full[0][:, 3], acc)
+
+
 def test_gather_world2_ragged():
     _run(2, 1000, 64)          # 16 tiles, last one ragged (40 rays)
 

@@ -9,6 +9,7 @@ executes, on cuda:0,
   * dist_train.GradReducer: ReduceOp.AVG all-reduces of the row-scalar table gradients and of the flat small-tensor buffer with
     async handles, started from inside TrainRenderFn.backward between the part chains and the deformer stage, joined by the
     optimiser's pre-hook — through NetworkWrapper + FusedAdam for 3 steps,
+  * frames.FrameSet: three frames as branches of one hipGraph with ONE all_gather_into_tensor + the index_selects captured in the graph,
 and checks that a group of one leaves the numbers untouched (the collectives are identities there)."""
 import os
 import socket
@@ -68,6 +69,7 @@ def _worker(port, out_path):
             full = idist.gather_maps(rgba, n, 0, 1)
         torch.cuda.synchronize()
         res['gather_equal'] = bool(torch.equal(full, ref))
+        torch.save(res, out_path)
         res['gather_shape'] = tuple(full.shape)
         # the frame server's form (bench.py --gpus N > 1): ONE exchange in flight, joined after the next frame has been replayed and sent
         pend, fulls = None, []
@@ -80,6 +82,24 @@ def _worker(port, out_path):
         fulls.append(pend.result())
         torch.cuda.synchronize()
         res['async_gather_equal'] = len(fulls) == 4 and all(bool(torch.equal(f, ref)) for f in fulls)
+        torch.save(res, out_path)
+        # frames in flight (bench.py --gpus N): K frames as parallel branches of ONE hipGraph with the RCCL all-gather of their tiles and the
+        # index_selects CAPTURED in the same graph — one replay per K frames, nothing issued from the host per frame
+        from invr import frames as iframes
+        fbatches = []
+        for k in range(3):
+            fb, _ = scene.make_scene(96, 96, seed=1, cam_dist=1.8, frame=5 + k, pose_seed=k)
+            fbatches.append({kk: v.to(dev) for kk, v in scene.to_torch(fb).items()})
+        fns, nrs, keep = iframes.shard_render_fns(net, fbatches, 32, 0, 1, want_raw=False)
+        singles = [iframes.FrameSet._rgba(fn()).clone() for fn in fns]
+        fs = iframes.FrameSet(fns, nrs, rank=0, world=1, device=dev)
+        res['frameset_exchange_captured'] = bool(fs.exchange and fs.graph is not None)
+        for _ in range(3):
+            fs.replay()
+        torch.cuda.synchronize()
+        res['frameset_equal'] = all(bool(torch.equal(f, s_)) for f, s_ in zip(fs.full, singles)) and iframes.check_overflow(fs)
+        res['frameset_poses_differ'] = singles[0].shape != singles[1].shape or not bool(torch.equal(singles[0], singles[1]))
+        torch.save(res, out_path)
         # training: averaged gradients through the reducer (AVG over one rank = identity)
         finals = []
         for use_reducer in (True, False):
@@ -129,10 +149,11 @@ def test_rccl_collectives_execute_on_one_gpu(tmp_path):
     p = ctx.Process(target=_worker, args=(port, out))
     p.start()
     p.join(600)
-    assert p.exitcode == 0, p.exitcode
-    res = torch.load(out)
+    res = torch.load(out) if os.path.exists(out) else {}
+    assert p.exitcode == 0, (p.exitcode, res)          # (the worker saves its partial results: a crash names the stage it got to)
     assert res.get('ok'), res
     assert res['gather_equal'] and res['gather_shape'][1] == 4
     assert res['async_gather_equal']
+    assert res['frameset_exchange_captured'] and res['frameset_equal'] and res['frameset_poses_differ']
     assert res['reducer_pending_after_step'] == 0                      # the optimiser pre-hook joined every async all-reduce
     assert res['train_worst_abs_diff'] <= 2 * 3 * 1e-3 * 1.01 and res['loss'] == res['loss']
