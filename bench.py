@@ -123,16 +123,24 @@ def cpu_baseline(net, cfg, batch_cpu, n_rays, S, seed=0):
                    % (c1['ray_o'].shape[1], dt1)}}
 
 
-def train_probe(net, dev, S, iters):
+def train_probe(net, dev, S, iters, fused=None):
     """BASELINE configs[4]-shaped training iteration on this GPU: a 32x32 patch (1024 rays) x S samples, forward +
-    backward (HIP kernels behind autograd) + the fused Adam step over all parameters; informational extra object."""
+    backward (HIP kernels behind autograd) + the Adam step over all parameters; informational extra object.  fused=None: the
+    build's own driver.make_optimizer (FusedAdam: one launch, row-scalar table gradients); fused=False: the optimizer exactly as
+    the reference's train_net.py builds it (lib/train/optimizer.py:15-31: torch.optim.Adam, one group per tensor) driven through
+    the reference's step form (trainer.py:116-149) — what a user who changes nothing but the three module strings gets."""
     from invr import driver
     from invr.trainer import NetworkWrapper
     bnp, _ = scene_mod.make_scene(512, 512, seed=0, cam_dist=1.8, crop=(240, 240, 32, 32))
     batch = {k: v.to(dev) for k, v in scene_mod.to_torch(bnp).items()}
     net.train()
+    if hasattr(net, '_grad_arena'):
+        del net._grad_arena              # (an earlier FusedAdam's persistent arena: every optimizer here starts from a plain network)
+    for p_ in net.parameters():
+        p_.grad = None
     wrap = NetworkWrapper(net)
-    opt = driver.make_optimizer(net)
+    opt = driver.make_optimizer(net, fused=fused)
+    opt_name = '%s.%s' % (type(opt).__module__, type(opt).__name__)
     for i in range(4):
         driver.train_step(wrap, opt, batch, i + 2)
     torch.cuda.synchronize()
@@ -142,8 +150,13 @@ def train_probe(net, dev, S, iters):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / iters
     net.eval()
+    if hasattr(net, '_grad_arena'):
+        del net._grad_arena
+    for p_ in net.parameters():
+        p_.grad = None
+    del opt
     return {'ms_per_iter': dt * 1e3, 'rays_per_iter': int(batch['ray_o'].shape[1]), 'samples_per_ray': S,
-            'ray_samples_per_sec': batch['ray_o'].shape[1] * S / dt, 'optimizer': type(opt).__name__,
+            'ray_samples_per_sec': batch['ray_o'].shape[1] * S / dt, 'optimizer': opt_name,
             'parameters_updated': int(sum(p.numel() for p in net.parameters() if p.requires_grad)), 'final_loss': float(loss)}
 
 
@@ -557,7 +570,7 @@ def main():
     frame_stats = [o['stats'].cpu().numpy().astype('int64') for o in fs.local]
     # the exchange alone (N > 1): the captured all-gather + index_selects replayed without the renders
     exchange_ms = None
-    if world > 1 and fs.exchange and fs.graph is not None:
+    if world > 1 and fs.exchange and fs.exchange_captured:
         try:
             gx = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gx, capture_error_mode='thread_local'):
@@ -717,6 +730,13 @@ def main():
                 line['train_step'] = train_probe(net, dev, S, args.train_iters)
             except Exception as e:          # informational only: never lose the bench line over it
                 line['train_step'] = {'error': repr(e)}
+            try:
+                torch.cuda.empty_cache()
+                line['api_train_step'] = train_probe(net, dev, S, args.train_iters, fused=False)
+                line['api_train_step']['note'] = ('NetworkWrapper + the reference\'s own optimizer construction (torch.optim.Adam, 186 one-tensor '
+                                                  'groups) + its step form: the drop-in training call; train_step = the same with driver.make_optimizer (FusedAdam)')
+            except Exception as e:
+                line['api_train_step'] = {'error': repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(net, cfg, batch_cpu, min(args.cpu_rays, n_rays), S)
         else:

@@ -71,8 +71,12 @@ def train_step(wrapper, optimizer, batch, iter_step, epoch=0, scaler=None):
 
 
 def make_optimizer(net, lr=5e-4, eps=1e-15, weight_decay=0.0, fused=None):
-    """lib/train/optimizer.py:15-31: Adam, one parameter group per tensor."""
-    groups = [{'params': [p], 'lr': lr, 'weight_decay': weight_decay} for p in net.parameters() if p.requires_grad]
+    """lib/train/optimizer.py:15-31: Adam, one parameter group per tensor; keys without 'data' in their name (every key of this
+    network) take lr * cfg.mlp_weight_decay (1.0 in lib/config/config.py:245 and in every INB yaml).  fused=False builds exactly the
+    reference's optimizer (torch.optim.Adam over the same groups): the fused training node then hands it dense table gradients."""
+    mwd = float(getattr(net, 'cfg', {}).get('mlp_weight_decay', 1.0))
+    groups = [{'params': [p], 'lr': lr if 'data' in k else lr * mwd, 'weight_decay': weight_decay}
+              for k, p in net.named_parameters() if p.requires_grad]
     if fused is None:
         fused = all(p.is_cuda for g in groups for p in g['params'])
     if fused:                      # one HIP launch for all tensors (invr_adam_step) instead of ~8 launches per tensor

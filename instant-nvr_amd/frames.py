@@ -44,7 +44,7 @@ class FrameSet:
         self.K = len(self.fns)
         self.exchange = world > 1 or (FORCE_COLLECTIVES() and dist.is_initialized())
         self.plan = exchange_plan(self.n_rays, world, tile, self.device) if self.exchange else None
-        self.graph = None
+        self.graph, self.exchange_captured = None, False
         self.local, self.full = [None] * self.K, [None] * self.K
         if self.exchange:
             self.send = torch.zeros(self.plan['rows'], 4, device=self.device)
@@ -81,8 +81,8 @@ class FrameSet:
 
     def _capture(self):
         assert self.device.type == 'cuda', 'graph capture needs a GPU (capture=False runs eagerly)'
-        if self.exchange:
-            assert dist.get_backend(self.group) == 'nccl', 'a captured exchange needs RCCL (backend "nccl"); use capture=False with gloo'
+        # the exchange is part of the graph on RCCL; any other backend (gloo in 1-GPU debugging runs) exchanges eagerly behind the replay
+        self.exchange_captured = self.exchange and dist.get_backend(self.group) == 'nccl'
         # warm-up outside the capture (workspace allocation, lazy module state, RCCL communicator set-up)
         side = torch.cuda.Stream(self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
@@ -104,12 +104,15 @@ class FrameSet:
                     self._render(k)
             for k in range(self.K):
                 cur.wait_stream(self.streams[k])
-            self._exchange()
+            if self.exchange_captured:
+                self._exchange()
         torch.cuda.synchronize(self.device)
 
     def replay(self):
         if self.graph is not None:
             self.graph.replay()
+            if self.exchange and not self.exchange_captured:
+                self._exchange()
             return
         for k in range(self.K):
             self._render(k)

@@ -63,6 +63,65 @@ def dense_train_rows(v, stats, ctx, rays, S, jitter):
     return resd, tpts, tocc
 
 
+class LazyHostRet(dict):
+    """The eval return dict of Renderer.render under the reference's move-everything-to-the-host contract (inb_renderer.py:199-200).
+    The image maps (rgb_map, acc_map: what the reference's evaluator and visualizers read, evaluators/if_nerf.py:77,
+    visualizers/if_nerf.py:24) are host tensors when render() returns; the per-sample tensors (raw, occ: 656 MB for a 512x512x128
+    frame, 12 ms of PCIe for a 2.5 ms render) are copied on first access — by key, or all of them by keys() / items() / values() /
+    iteration — and are host tensors of the reference's shapes from then on.  The device tensors they come from stay alive inside
+    this object until then; a dict built from it (`dict(ret)`) is the plain all-host dict."""
+    def __init__(self, host, lazy_dev, pin):
+        super().__init__(host)
+        self._lazy, self._pin = dict(lazy_dev), pin
+
+    def _fetch(self, keys):
+        todo = [k for k in keys if k in self._lazy]
+        if not todo:
+            return
+        on_dev = False
+        for k in todo:
+            v = self._lazy.pop(k).detach()
+            h = torch.empty(v.shape, dtype=v.dtype, device='cpu', pin_memory=self._pin and v.is_cuda)
+            h.copy_(v, non_blocking=True)
+            on_dev = on_dev or v.is_cuda
+            dict.__setitem__(self, k, h)
+        if on_dev:
+            torch.cuda.current_stream().synchronize()
+
+    def __contains__(self, k):
+        return dict.__contains__(self, k) or k in self._lazy
+
+    def __getitem__(self, k):
+        self._fetch((k,))
+        return dict.__getitem__(self, k)
+
+    def get(self, k, d=None):
+        return self[k] if k in self else d
+
+    def __len__(self):
+        return dict.__len__(self) + len(self._lazy)
+
+    def __iter__(self):
+        self._fetch(tuple(self._lazy))
+        return dict.__iter__(self)
+
+    def keys(self):
+        self._fetch(tuple(self._lazy))
+        return dict.keys(self)
+
+    def items(self):
+        self._fetch(tuple(self._lazy))
+        return dict.items(self)
+
+    def values(self):
+        self._fetch(tuple(self._lazy))
+        return dict.values(self)
+
+    def pending(self):
+        """keys whose host copy has not been made yet"""
+        return tuple(self._lazy)
+
+
 class Renderer:
     def __init__(self, net):
         self.net = net
@@ -71,7 +130,10 @@ class Renderer:
         self.eval_to_cpu = True        # reference moves every eval output to the CPU (:199-200)
         self.want_raw = True           # reference always returns raw/occ
         self.adaptive_cap = True       # size the workspace from the previous frame's survivor count (eval_to_cpu only)
-        self.pin_host = True           # eval_to_cpu: page-locked host tensors for the outputs (False: ordinary pageable tensors)
+        self.pin_host = True           # eval_to_cpu: page-locked host tensors for the outputs (False: ordinary pageable tensors; note
+                                       # that torch's caching host allocator keeps page-locked blocks: a caller that retains the raw /
+                                       # occ of many frames pins that much host memory)
+        self.lazy_host = True          # eval_to_cpu: raw / occ reach the host on first access (LazyHostRet); False: with the maps
         self._cap_hint = None
 
     def render(self, batch, test=False, epoch=-1):
@@ -126,14 +188,11 @@ class Renderer:
             # the reference moves every eval output to the host (:199-200).  raw + occ of a 512x512x128 frame are 656 MB: through
             # pageable memory that copy takes ~25x the render; page-locked destinations (torch's caching host allocator: fresh
             # tensors per call, no aliasing between frames) and one stream synchronisation bring it to the PCIe rate
-            host = {}
-            for k, v in ret.items():
-                v = v.detach()
-                h = torch.empty(v.shape, dtype=v.dtype, device='cpu', pin_memory=self.pin_host and v.is_cuda)
-                h.copy_(v, non_blocking=True)
-                host[k] = h
-            if any(v.is_cuda for v in ret.values()):
-                torch.cuda.current_stream().synchronize()
+            # — for the image maps at once, for raw / occ on first access (LazyHostRet; lazy_host = False: all four at once)
+            lazy = {k: ret[k] for k in ('raw', 'occ') if self.lazy_host and k in ret}
+            host = LazyHostRet({}, {k: v for k, v in ret.items() if k not in lazy}, self.pin_host)
+            host._fetch(tuple(host._lazy))
+            host._lazy = lazy
             ret = host
         return ret
 

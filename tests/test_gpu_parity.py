@@ -263,7 +263,10 @@ def test_render_64x64x32_vs_reference_golden(gpu_setup, golden, row_sums):
     r = Renderer(net)
     with encoder_mode(cfg, row_sums):
         ret = r.render(dict(gb))
-    assert set(ret.keys()) == {'rgb_map', 'acc_map', 'raw', 'occ'}
+    # the image maps are on the host when render() returns, raw / occ (N x 20 bytes) follow on first access (LazyHostRet) —
+    assert set(ret.pending()) == {'raw', 'occ'} and not ret['rgb_map'].is_cuda and not ret['acc_map'].is_cuda and len(ret) == 4
+    assert 'raw' in ret and set(ret.pending()) == {'raw', 'occ'}
+    assert set(ret.keys()) == {'rgb_map', 'acc_map', 'raw', 'occ'} and ret.pending() == ()
     assert all(not v.is_cuda for v in ret.values())                       # reference moves eval outputs to CPU
     assert ret['raw'].shape == (1, gb['ray_o'].shape[1] * cfg.N_samples, 4)
     assert ret['occ'].shape == (1, gb['ray_o'].shape[1] * cfg.N_samples, 1)

@@ -93,7 +93,7 @@ def _worker(port, out_path):
         fns, nrs, keep = iframes.shard_render_fns(net, fbatches, 32, 0, 1, want_raw=False)
         singles = [iframes.FrameSet._rgba(fn()).clone() for fn in fns]
         fs = iframes.FrameSet(fns, nrs, rank=0, world=1, device=dev)
-        res['frameset_exchange_captured'] = bool(fs.exchange and fs.graph is not None)
+        res['frameset_exchange_captured'] = bool(fs.exchange and fs.graph is not None and fs.exchange_captured)
         for _ in range(3):
             fs.replay()
         torch.cuda.synchronize()
@@ -134,6 +134,42 @@ def _worker(port, out_path):
                 assert frac >= 0.99, (k, frac)
         res['train_worst_abs_diff'] = worst
         res['loss'] = float(loss)
+        # the reference's own distributed form (trainer.py:18-26): DistributedDataParallel(NetworkWrapper) + ITS optimizer (torch.optim.Adam,
+        # one group per tensor) around the FUSED training node — the node returns ordinary dense gradients when no arena is attached, so
+        # DDP's bucket hooks see every parameter; a group of one must leave the plain (non-DDP) run's parameters untouched
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        ddp_final = []
+        for use_ddp in (True, False):
+            net3 = Network(cfg=cfg)
+            net3.load_state_dict(sd, strict=True)
+            net3 = net3.to(dev).train()
+            wrap3 = NetworkWrapper(net3)
+            wrap3.renderer._jitter = lambda shape, device: jit
+            wrap3.renderer._pair_noise_dense = lambda rows, device: noi[:rows]
+            model = DDP(wrap3, device_ids=[0]) if use_ddp else wrap3
+            opt3 = driver.make_optimizer(net3, lr=1e-3, eps=1e-15, fused=False)
+            assert type(opt3) is torch.optim.Adam and len(opt3.param_groups) == sum(1 for p in net3.parameters() if p.requires_grad)
+            for it in range(2):
+                b3 = dict(tb)
+                b3['iter_step'] = it + 2
+                ret3, loss3, _, _ = model(b3, 0, split='train')
+                loss3 = loss3.mean()
+                opt3.zero_grad(set_to_none=True)
+                loss3.backward()
+                opt3.step()
+            torch.cuda.synchronize()
+            ddp_final.append({k: v.detach().cpu() for k, v in net3.state_dict().items()})
+        # (same closeness rule as above: the backward's float atomics are unordered, and Adam with eps 1e-15 turns a rounding-level
+        # gradient difference into a +-lr step on a few elements)
+        ddp_worst, ddp_frac = 0.0, 1.0
+        for k in ddp_final[0]:
+            if ddp_final[0][k].is_floating_point():
+                d = (ddp_final[0][k].double() - ddp_final[1][k].double()).abs()
+                ddp_worst = max(ddp_worst, float(d.max()))
+                ddp_frac = min(ddp_frac, float((d <= 1e-6 + 1e-5 * ddp_final[1][k].double().abs()).double().mean()))
+        res['ddp_worst'], res['ddp_frac'] = ddp_worst, ddp_frac
+        res['ddp_equal'] = ddp_frac >= 0.99 and ddp_worst <= 2 * 2 * 1e-3 * 1.01
+        res['ddp_loss'] = float(loss3)
         res['ok'] = True
     finally:
         torch.save(res, out_path)
@@ -157,3 +193,4 @@ def test_rccl_collectives_execute_on_one_gpu(tmp_path):
     assert res['frameset_exchange_captured'] and res['frameset_equal'] and res['frameset_poses_differ']
     assert res['reducer_pending_after_step'] == 0                      # the optimiser pre-hook joined every async all-reduce
     assert res['train_worst_abs_diff'] <= 2 * 3 * 1e-3 * 1.01 and res['loss'] == res['loss']
+    assert res['ddp_equal'] and res['ddp_loss'] == res['ddp_loss']      # DistributedDataParallel(NetworkWrapper) around the fused node
