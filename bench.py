@@ -149,13 +149,26 @@ def train_probe(net, dev, S, iters, fused=None):
         loss, _ = driver.train_step(wrap, opt, batch, i + 6)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / iters
+    # where the iteration goes: forward / backward / optimizer step, synchronised (3 extra iterations)
+    parts = [0.0, 0.0, 0.0]
+    for i in range(3):
+        b = dict(batch); b['iter_step'] = 50 + i
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        ret, l2, _, _ = wrap(b, 0, split='train')
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        opt.zero_grad(set_to_none=True)
+        l2.mean().backward()
+        torch.cuda.synchronize(); t3 = time.perf_counter()
+        opt.step()
+        torch.cuda.synchronize(); t4 = time.perf_counter()
+        parts = [parts[0] + (t2 - t1) / 3, parts[1] + (t3 - t2) / 3, parts[2] + (t4 - t3) / 3]
     net.eval()
     if hasattr(net, '_grad_arena'):
         del net._grad_arena
     for p_ in net.parameters():
         p_.grad = None
     del opt
-    return {'ms_per_iter': dt * 1e3, 'rays_per_iter': int(batch['ray_o'].shape[1]), 'samples_per_ray': S,
+    return {'ms_per_iter': dt * 1e3, 'synchronised_ms': {'forward': parts[0] * 1e3, 'backward': parts[1] * 1e3, 'optimizer_step': parts[2] * 1e3}, 'rays_per_iter': int(batch['ray_o'].shape[1]), 'samples_per_ray': S,
             'ray_samples_per_sec': batch['ray_o'].shape[1] * S / dt, 'optimizer': opt_name,
             'parameters_updated': int(sum(p.numel() for p in net.parameters() if p.requires_grad)), 'final_loss': float(loss)}
 

@@ -25,3 +25,28 @@ def pixel_noise(O, model64, b64, exact, n_samples, chunk=64, ref32=None, trials=
             r = O.render(model64, bp, n_samples=n_samples, chunk=chunk)
         noise = torch.maximum(noise, (r['rgb_map'][0] - exact).abs().max(1)[0])
     return noise
+
+
+def part_field_noise(O, model64, pid, tpts, tdirs, latent_index, ref32=None, trials=4, seed=0, column=None):
+    """How ill-conditioned is the field value of part `pid` at the canonical points `tpts` (n,3) / directions `tdirs` (n,3)?  The
+    noise scale per point = the largest move of the FLOAT64 value [rgb, occ] (or of output `column` alone: 3 = the occupancy, which
+    does not depend on the direction) under `trials` independent fp32-ulp-sized random perturbations of the inputs (what any fp32
+    evaluation upstream does to them), together with the deviation of an fp32 evaluation `ref32` (n,4) when given.  Inside the part's
+    box this is ~1e-7; outside it the encoder extrapolates (part_base_embedder.py:117-118) with trilinear weights that grow with the
+    distance and cancel, and the scale grows with them.  -> (exact (n,4) float64, noise (n,))."""
+    sd = model64.sd
+    x, d = tpts.double(), tdirs.double()
+    ev = lambda xx, dd: O.part_field(xx, dd, sd, pid, model64.pspec[pid], model64.n_occ[pid], model64.n_rgb[pid], latent_index, model64.n_freq)
+    sel = (lambda v: v.abs().max(1)[0]) if column is None else (lambda v: v[:, column].abs())
+    with torch.no_grad():
+        exact = ev(x, d)
+        noise = torch.zeros(x.shape[0], dtype=torch.float64)
+        if ref32 is not None:
+            noise = torch.maximum(noise, sel(ref32.double() - exact))
+        g = torch.Generator().manual_seed(2000 + seed)
+        sgn = lambda t: (torch.randint(0, 2, t.shape, generator=g).double() * 2.0 - 1.0)
+        # one ulp of the coordinate itself and of the box-relative coordinate (|x| + 1 covers the normalisation by the bounds)
+        for _ in range(trials):
+            r = ev(x + sgn(x) * (x.abs() + 1.0) * 2.0 ** -23, d * (1.0 + sgn(d) * 2.0 ** -22))
+            noise = torch.maximum(noise, sel(r - exact))
+    return exact, noise

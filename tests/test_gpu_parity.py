@@ -11,7 +11,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import nvr_oracle as O          # noqa: E402  (checker only)
-from tests.conditioning import pixel_noise  # noqa: E402  (checker only)
+from tests.conditioning import pixel_noise, part_field_noise  # noqa: E402  (checker only)
 from invr import _abi, params               # noqa: E402
 from invr.network import Network            # noqa: E402
 from invr.renderer import Renderer          # noqa: E402
@@ -181,7 +181,9 @@ def test_part_fields(gpu_setup, golden, row_sums):
     assert bool(model.part[0].grid.row_sums) == row_sums
     li = gb['latent_index'].reshape(-1)[:1].to(torch.int64).contiguous()
     pflag = golden['pflag'][0]
-    n_inside = 0
+    n_inside = n_checked_outside = 0
+    worst_outside = 0.0
+    model64 = O.Model({k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}, cfg)
     for pid in range(5):
         f = pflag[:, pid]
         tp = cu(golden['tpose'][0][f, pid].copy())
@@ -201,8 +203,17 @@ def test_part_fields(gpu_setup, golden, row_sums):
         err = np.abs(raw.cpu().numpy() - golden['part%d_raw' % pid]).max(1)
         n_inside += int(inside.sum())
         assert inside.sum() == 0 or err[inside].max() < 2e-5, pid
-        assert err.max() < 1e-3, pid
+        # outside the box: the allowance follows the CONDITIONING of each point (tests/conditioning.py: the move of the float64 field
+        # value under fp32-ulp perturbations of its inputs, and the reference's own fp32 deviation from float64), not a flat 1e-3
+        _, noise = part_field_noise(O, model64, pid, torch.from_numpy(golden['tpose'][0][f, pid].copy()),
+                                    torch.from_numpy(golden['tpose_dirs'][0][f, pid].copy()), int(li[0]),
+                                    ref32=torch.from_numpy(golden['part%d_raw' % pid]))
+        bound = 2e-5 + 8.0 * noise.numpy()
+        assert (err <= bound).all(), (pid, float((err - bound).max()), float(err.max()))
+        n_checked_outside += int((~inside).sum())
+        worst_outside = max(worst_outside, float(err[~inside].max()) if (~inside).any() else 0.0)
     assert n_inside >= 100
+    print('part fields: %d points outside their box, worst error %.2e (condition-aware bound)' % (n_checked_outside, worst_outside))
 
 
 def test_composite_random(gpu_setup):
@@ -289,6 +300,25 @@ def test_render_64x64x32_vs_reference_golden(gpu_setup, golden, row_sums):
     assert np.abs(raw[mask]).max() == 0.0                                 # untouched samples are exact zeros
 
 
+def tocc_bound(golden, sd, cfg, latent_index):
+    """Per-row allowance for the train-mode occupancies `tocc` (Na x P rows, part = row % 5): 2e-6 on rows the reference left at zero
+    (unflagged pairs), 2e-5 + 8 x the conditioning of the occupancy at the row's canonical point (tests/conditioning.py) elsewhere —
+    far pairs sit far outside their part's box, where the encoder extrapolates (see test_part_fields)."""
+    model64 = O.Model({k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}, cfg)
+    ref = torch.from_numpy(golden['train_tocc'][0, :, 0].copy())
+    tpose = torch.from_numpy(golden['train_tpts'][0] + golden['train_resd'][0])
+    bound = torch.full(ref.shape, 2e-6, dtype=torch.float64)
+    for pid in range(5):
+        rows = torch.arange(pid, ref.shape[0], 5)
+        rows = rows[ref[rows] != 0]
+        if rows.numel():
+            ref4 = torch.zeros(rows.numel(), 4)
+            ref4[:, 3] = ref[rows]
+            _, noise = part_field_noise(O, model64, pid, tpose[rows], torch.zeros(rows.numel(), 3), latent_index, ref32=ref4, column=3)
+            bound[rows] = 2e-5 + 8.0 * noise
+    return bound
+
+
 def test_train_mode_forward_vs_reference_golden(gpu_setup, golden):
     """Train-mode forward (fixed jitter / pair noise): rgb_map, dense resd/tocc layouts, oresd and the
     distortion regulariser against the reference, and NetworkWrapper's loss assembly."""
@@ -314,7 +344,8 @@ def test_train_mode_forward_vs_reference_golden(gpu_setup, golden):
     assert maxerr(ret['resd'], golden['train_resd']) < 5e-6
     # tpts = init_bigpose of ALL Na x P rows (inb_part_network_multiassign.py:96-120,162-166), unflagged pairs included
     assert ret['tpts'].shape == golden['train_tpts'].shape and maxerr(ret['tpts'], golden['train_tpts']) < 1e-5
-    assert maxerr(ret['tocc'], golden['train_tocc']) < 1e-3        # far pairs are extrapolated (see test_part_fields)
+    terr = (ret['tocc'].detach().cpu().double()[0, :, 0] - torch.from_numpy(golden['train_tocc'][0, :, 0]).double()).abs()
+    assert bool((terr <= tocc_bound(golden, sd, cfg, int(gb['latent_index'].reshape(-1)[0]))).all()), float(terr.max())   # condition-aware, not a flat 1e-3
     assert ret['oresd'].shape == golden['train_oresd'].shape
     assert maxerr(ret['oresd'], golden['train_oresd']) < 5e-6
     assert maxerr(ret['reg_distortion_loss'], golden['train_reg_distortion_loss']) < 1e-5
@@ -426,7 +457,9 @@ def test_train_step_gradients_vs_reference_golden(gpu_setup, golden, mode):
     loss.backward()
     # the reference's dynamic-shape outputs (lazy in the fused modes)
     assert ret['resd'].shape == golden['train_resd'].shape and maxerr(ret['resd'], golden['train_resd']) < 5e-6
-    assert ret['tocc'].shape == golden['train_tocc'].shape and maxerr(ret['tocc'], golden['train_tocc']) < 1e-3
+    assert ret['tocc'].shape == golden['train_tocc'].shape
+    terr = (ret['tocc'].detach().cpu().double()[0, :, 0] - torch.from_numpy(golden['train_tocc'][0, :, 0]).double()).abs()
+    assert bool((terr <= tocc_bound(golden, sd, cfg, int(gb['latent_index'].reshape(-1)[0]))).all()), float(terr.max())   # condition-aware, not a flat 1e-3
     assert ret['oresd'].shape == golden['train_oresd'].shape and maxerr(ret['oresd'], golden['train_oresd']) < 5e-6
     if mode == 'fused_arena':
         assert all(pn.embedder.hash.grad is None for pn in net.tpose_human.part_networks)     # tables: row scalars only

@@ -327,19 +327,26 @@ def test_configs3_real_shape_three_steps_vs_oracle_autograd(full_net):
             mine.append(float(loss))
         torch.cuda.synchronize()
         got = {k: v.detach().cpu() for k, v in net.state_dict().items()}
-        # ---- the oracle's three steps on the CPU
+        # ---- the oracle's three steps on the CPU, in float32 (the reference's arithmetic) and in float64 (the arbiter, below)
         train_keys = [k for k, p in net.named_parameters() if p.requires_grad]
-        sd = {k: v.clone() for k, v in sd0.items()}
-        for k in train_keys:
-            sd[k].requires_grad_()
-        ref_opt = torch.optim.Adam([{'params': [sd[k]], 'lr': LR} for k in train_keys], LR, eps=1e-15)
-        ref = []
-        for k in range(STEPS):
-            loss, _ = OT.train_loss(sd, cfg, bc, jit[k], noi[k], chunk=1024)
-            ref_opt.zero_grad(set_to_none=True)
-            loss.backward()
-            ref_opt.step()
-            ref.append(float(loss))
+        runs = {}
+        for dt in (torch.float32, torch.float64):
+            sdt = {k: (v.clone().to(dt) if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
+            for k in train_keys:
+                sdt[k].requires_grad_()
+            bdt = {k: (v.to(dt) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in bc.items()}
+            ref_opt = torch.optim.Adam([{'params': [sdt[k]], 'lr': LR} for k in train_keys], LR, eps=1e-15)
+            losses = []
+            for k in range(STEPS):
+                loss, _ = OT.train_loss(sdt, cfg, bdt, jit[k].to(dt), noi[k].to(dt), chunk=1024)
+                ref_opt.zero_grad(set_to_none=True)
+                loss.backward()
+                ref_opt.step()
+                losses.append(float(loss))
+            runs[dt] = ({k: sdt[k].detach().double() for k in train_keys}, losses)
+            del ref_opt, sdt
+        sd, ref = {k: v for k, v in runs[torch.float32][0].items()}, runs[torch.float32][1]
+        sd64 = runs[torch.float64][0]
         print('configs[3] real shape: losses', mine, 'oracle', ref)
         assert abs(mine[0] - ref[0]) < 2e-5 * max(1.0, abs(ref[0]))            # identical parameters: fp32 agreement of the objective
         for a, b in zip(mine, ref):
@@ -349,22 +356,31 @@ def test_configs3_real_shape_three_steps_vs_oracle_autograd(full_net):
         checked = 0
         for k in train_keys:
             a, b, o = got[k].double(), sd[k].detach().double(), sd0[k].double()
+            x = sd64[k]
             moved_ref = (b - o).abs()
             if a.numel() > (1 << 22):                                           # part tables: the rows the three steps touched
                 rows = (moved_ref.reshape(-1, a.shape[-1]).sum(1) > 0).nonzero(as_tuple=True)[0]
                 if rows.numel() == 0:
                     assert torch.equal(got[k], sd0[k]), k
                     continue
-                a, b = a.reshape(-1, a.shape[-1])[rows], b.reshape(-1, b.shape[-1])[rows]
+                a, b, x = a.reshape(-1, a.shape[-1])[rows], b.reshape(-1, b.shape[-1])[rows], x.reshape(-1, x.shape[-1])[rows]
                 untouched = (moved_ref.reshape(-1, moved_ref.shape[-1]).sum(1) == 0)
                 assert float((got[k].double() - o).abs().reshape(-1, o.shape[-1])[untouched].max()) <= 3.5 * LR, k   # noise-level rows at most
             d = (a - b).abs()
             frac_close = float((d <= 1e-5 + 1e-3 * b.abs()).double().mean())
             assert float(d.max()) <= 2 * STEPS * LR * 1.01, (k, float(d.max()))  # never more than the steps can move an element
-            # (the deformer's gradients carry the pair term's fp32 conditioning, test_pair_term_gradient_float64_arbitration: more of
-            # its elements sit at rounding level, where eps = 1e-15 Adam steps by +-lr on the sign of noise)
-            # measured over runs: 0.67-0.83 for the deformer's first layer, >= 0.99 for every part tensor
-            assert frac_close >= (0.5 if k.startswith('tpose_deformer') else 0.97), (k, frac_close)
+            # The deformer's gradients carry the pair term's fp32 conditioning (test_pair_term_gradient_float64_arbitration): many of
+            # its elements have gradients at rounding level, where Adam with eps 1e-15 steps by +-lr on the SIGN of noise — two fp32
+            # evaluations of the same objective then disagree on those elements.  A float64 run of the oracle arbitrates: this
+            # build must agree with it as often as the oracle's own float32 run does (the round-3 form of this assertion was a flat
+            # floor on the fp32-vs-fp32 agreement, lowered from 0.75 to 0.5 when a run came in at 0.67: not shown to be noise).
+            close64 = lambda u: float(((u - x).abs() <= 1e-5 + 1e-3 * x.abs()).double().mean())
+            f_mine, f_ref = close64(a), close64(b)
+            if k.startswith('tpose_deformer'):
+                print('  %-40s agreement with the float64 oracle: HIP %.3f, float32 oracle %.3f; HIP vs float32 oracle %.3f' % (k, f_mine, f_ref, frac_close))
+                assert f_mine >= f_ref - 0.05, (k, f_mine, f_ref, frac_close)
+            else:
+                assert frac_close >= 0.97, (k, frac_close)
             checked += 1
         assert checked >= 60
     finally:
