@@ -82,10 +82,13 @@ __global__ __launch_bounds__(TR_BLOCK) void k_train_terms(Workspace w, TrainWs t
 }
 
 // ---- thread-per-point deformer (uv_deformer.py:31-38), forward with kept activations --------------------------------
-struct DeformAct { float feat[19]; float h1[32]; float h2[32]; float th[3]; };
+// (BWD: the backward's recompute — activations AND their derivative factors sigmoid(z) with relative accuracy, softplus_sigmoid_acc)
+template <bool BWD> struct DeformActT { float feat[19]; float h1[32]; float h2[32]; float th[3]; float s1[BWD ? 32 : 1]; float s2[BWD ? 32 : 1]; };
+typedef DeformActT<false> DeformAct;
 
+template <bool BWD>
 __device__ __forceinline__ void deform_fwd_act(const SceneDev& s, const GridDev& dg, const MlpDev& dm, const float* xb, float* uvt,
-                                               DeformAct& a) {
+                                               DeformActT<BWD>& a) {
     sample_volume_dev<2>(s.tuv, 0, xb[0], xb[1], xb[2], uvt);
     uvt[2] = s.frame_dim[0];
     grid_encode_concat<8, 2>(dg, uvt, a.feat);
@@ -97,14 +100,16 @@ __device__ __forceinline__ void deform_fwd_act(const SceneDev& s, const GridDev&
         float acc = B0[j];
 #pragma unroll
         for (int i = 0; i < 19; ++i) acc = fmaf(W0[j * 19 + i], a.feat[i], acc);
-        a.h1[j] = softplus_f(acc);
+        if (BWD) softplus_sigmoid_acc(acc, a.h1[j], a.s1[j]);
+        else a.h1[j] = softplus_f(acc);
     }
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
         float acc = B1[j];
 #pragma unroll
         for (int i = 0; i < 32; ++i) acc = fmaf(W1[j * 32 + i], a.h1[i], acc);
-        a.h2[j] = softplus_f(acc);
+        if (BWD) softplus_sigmoid_acc(acc, a.h2[j], a.s2[j]);
+        else a.h2[j] = softplus_f(acc);
     }
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -124,7 +129,7 @@ __global__ __launch_bounds__(128) void k_pair_term_fwd(SceneDev s, GridDev dg, M
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nsel; k += gridDim.x * blockDim.x) {
         float xb[3] = {t.nb_x[(int64_t)k * 3], t.nb_x[(int64_t)k * 3 + 1], t.nb_x[(int64_t)k * 3 + 2]}, uvt[3];
         DeformAct a;
-        deform_fwd_act(s, dg, dm, xb, uvt, a);
+        deform_fwd_act<false>(s, dg, dm, xb, uvt, a);
         float vn[3], vs[3];
         const int ref = t.nb_ref[k], p = ref >> 28, i = ref & 0x0FFFFFFF;
 #pragma unroll
@@ -403,8 +408,8 @@ __global__ __launch_bounds__(128) void k_deform_bwd(SceneDev s, GridDev dg, MlpD
     const float* __restrict__ W0 = dm.w[0]; const float* __restrict__ W1 = dm.w[1]; const float* __restrict__ W2 = dm.w[2];
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
         float xb[3] = {t.d_pts[(int64_t)e * 3], t.d_pts[(int64_t)e * 3 + 1], t.d_pts[(int64_t)e * 3 + 2]}, uvt[3];
-        DeformAct a;
-        deform_fwd_act(s, dg, dm, xb, uvt, a);
+        DeformActT<true> a;
+        deform_fwd_act<true>(s, dg, dm, xb, uvt, a);
         float gz3[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) gz3[c] = t.d_g[(int64_t)e * 3 + c] * 0.05f * (1.0f - a.th[c] * a.th[c]);
@@ -414,7 +419,7 @@ __global__ __launch_bounds__(128) void k_deform_bwd(SceneDev s, GridDev dg, MlpD
 #pragma unroll
         for (int j = 0; j < 32; ++j) {
             const float gh = W2[j] * gz3[0] + W2[32 + j] * gz3[1] + W2[64 + j] * gz3[2];
-            gz2[j] = gh * (1.0f - exp2_raw(-a.h2[j] * INVR_LOG2E));              // softplus'(z) = 1 - exp(-softplus(z))
+            gz2[j] = gh * a.s2[j];                                               // softplus'(z) = sigmoid(z)
             t.d_gz2[(int64_t)e * 32 + j] = gz2[j];
             t.d_a2[(int64_t)e * 32 + j] = a.h2[j];
         }
@@ -424,7 +429,7 @@ __global__ __launch_bounds__(128) void k_deform_bwd(SceneDev s, GridDev dg, MlpD
             float gh = 0.0f;
 #pragma unroll
             for (int j = 0; j < 32; ++j) gh = fmaf(W1[j * 32 + i], gz2[j], gh);
-            gz1[i] = gh * (1.0f - exp2_raw(-a.h1[i] * INVR_LOG2E));
+            gz1[i] = gh * a.s1[i];
             t.d_gz1[(int64_t)e * 32 + i] = gz1[i];
             t.d_a1[(int64_t)e * 32 + i] = a.h1[i];
         }

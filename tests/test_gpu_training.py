@@ -325,11 +325,14 @@ def test_configs3_real_shape_three_steps_vs_oracle_autograd(full_net):
             cur['k'] = k
             loss, _ = driver.train_step(wrap, opt, dict(gb), k + 2)
             mine.append(float(loss))
+            if k == 0:                  # the deformer after ONE step, for the float64 arbitration below
+                got1 = {kk: v.detach().cpu().double() for kk, v in net.state_dict().items() if kk.startswith('tpose_deformer')}
         torch.cuda.synchronize()
         got = {k: v.detach().cpu() for k, v in net.state_dict().items()}
-        # ---- the oracle's three steps on the CPU, in float32 (the reference's arithmetic) and in float64 (the arbiter, below)
+        # ---- the oracle's steps on the CPU: three in float32 (the reference's arithmetic), ONE in float64 (the arbiter of the first
+        # step, below: float64 over 286 M parameters is slow on the host)
         train_keys = [k for k, p in net.named_parameters() if p.requires_grad]
-        runs = {}
+        runs, first = {}, {}
         for dt in (torch.float32, torch.float64):
             sdt = {k: (v.clone().to(dt) if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
             for k in train_keys:
@@ -337,16 +340,17 @@ def test_configs3_real_shape_three_steps_vs_oracle_autograd(full_net):
             bdt = {k: (v.to(dt) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in bc.items()}
             ref_opt = torch.optim.Adam([{'params': [sdt[k]], 'lr': LR} for k in train_keys], LR, eps=1e-15)
             losses = []
-            for k in range(STEPS):
+            for k in range(STEPS if dt == torch.float32 else 1):
                 loss, _ = OT.train_loss(sdt, cfg, bdt, jit[k].to(dt), noi[k].to(dt), chunk=1024)
                 ref_opt.zero_grad(set_to_none=True)
                 loss.backward()
                 ref_opt.step()
                 losses.append(float(loss))
-            runs[dt] = ({k: sdt[k].detach().double() for k in train_keys}, losses)
+                if k == 0:
+                    first[dt] = {kk: sdt[kk].detach().double().clone() for kk in train_keys if kk.startswith('tpose_deformer')}
+            runs[dt] = ({k: sdt[k].detach().double() for k in train_keys} if dt == torch.float32 else None, losses)
             del ref_opt, sdt
-        sd, ref = {k: v for k, v in runs[torch.float32][0].items()}, runs[torch.float32][1]
-        sd64 = runs[torch.float64][0]
+        sd, ref = runs[torch.float32][0], runs[torch.float32][1]
         print('configs[3] real shape: losses', mine, 'oracle', ref)
         assert abs(mine[0] - ref[0]) < 2e-5 * max(1.0, abs(ref[0]))            # identical parameters: fp32 agreement of the objective
         for a, b in zip(mine, ref):
@@ -356,14 +360,13 @@ def test_configs3_real_shape_three_steps_vs_oracle_autograd(full_net):
         checked = 0
         for k in train_keys:
             a, b, o = got[k].double(), sd[k].detach().double(), sd0[k].double()
-            x = sd64[k]
             moved_ref = (b - o).abs()
             if a.numel() > (1 << 22):                                           # part tables: the rows the three steps touched
                 rows = (moved_ref.reshape(-1, a.shape[-1]).sum(1) > 0).nonzero(as_tuple=True)[0]
                 if rows.numel() == 0:
                     assert torch.equal(got[k], sd0[k]), k
                     continue
-                a, b, x = a.reshape(-1, a.shape[-1])[rows], b.reshape(-1, b.shape[-1])[rows], x.reshape(-1, x.shape[-1])[rows]
+                a, b = a.reshape(-1, a.shape[-1])[rows], b.reshape(-1, b.shape[-1])[rows]
                 untouched = (moved_ref.reshape(-1, moved_ref.shape[-1]).sum(1) == 0)
                 assert float((got[k].double() - o).abs().reshape(-1, o.shape[-1])[untouched].max()) <= 3.5 * LR, k   # noise-level rows at most
             d = (a - b).abs()
@@ -374,10 +377,12 @@ def test_configs3_real_shape_three_steps_vs_oracle_autograd(full_net):
             # evaluations of the same objective then disagree on those elements.  A float64 run of the oracle arbitrates: this
             # build must agree with it as often as the oracle's own float32 run does (the round-3 form of this assertion was a flat
             # floor on the fp32-vs-fp32 agreement, lowered from 0.75 to 0.5 when a run came in at 0.67: not shown to be noise).
-            close64 = lambda u: float(((u - x).abs() <= 1e-5 + 1e-3 * x.abs()).double().mean())
-            f_mine, f_ref = close64(a), close64(b)
             if k.startswith('tpose_deformer'):
-                print('  %-40s agreement with the float64 oracle: HIP %.3f, float32 oracle %.3f; HIP vs float32 oracle %.3f' % (k, f_mine, f_ref, frac_close))
+                x = first[torch.float64][k]                      # (after the FIRST step: one Adam step = -lr * sign-like(gradient))
+                close64 = lambda u: float(((u - x).abs() <= 1e-5 + 1e-3 * x.abs()).double().mean())
+                f_mine, f_ref = close64(got1[k]), close64(first[torch.float32][k])
+                print('  %-40s step 1, agreement with the float64 oracle: HIP %.3f, float32 oracle %.3f; 3 steps, HIP vs float32 oracle %.3f'
+                      % (k, f_mine, f_ref, frac_close))
                 assert f_mine >= f_ref - 0.05, (k, f_mine, f_ref, frac_close)
             else:
                 assert frac_close >= 0.97, (k, frac_close)
