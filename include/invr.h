@@ -419,6 +419,17 @@ int invr_train_bwd(const InvrScene* scene, const InvrModel* model, int64_t n_ray
  * grid's tables (every feature of a row takes the row's scalar); overwrites.  g_dense may be NULL for a non-separate table. */
 int invr_expand_row_grad(const InvrGrid* grid, const float* row_grad, float* g_dense, float* g_hash, void* stream);
 
+/* The training objective of NetworkWrapper.forward (lib/train/trainers/inb_trainer.py:40-98, 176-214 with the plain MSE image term,
+ * use_lpips False) on the outputs of invr_train_fwd, one launch each way:
+ *   loss = w_pair * pair + w_dist * mean(dist) + w_off * offset + mean((rgb_map - rgb_gt)^2)      (the wrapper's order of additions)
+ *   offset = terms[OFFSET_SUM] / max(terms[OFFSET_ROWS], 1), pair likewise (use_pair 0: no pair term); dist may be NULL.
+ * out8 = {loss, img_loss, psnr = -10 log10(img_loss), reg_dist, offset_loss, pair_loss, 0, 0}; err (n_rays) = sum_c |rgb - gt| or NULL.
+ * invr_train_loss_bwd: g_loss (1) -> g_rgb (n_rays,3), g_dist (n_rays) or NULL, g_terms (8) = the gradients invr_train_bwd takes. */
+int invr_train_loss_fwd(const float* rgb_map, const float* rgb_gt, const float* dist, const float* terms, int64_t n_rays,
+                        float w_pair, float w_dist, float w_off, int32_t use_pair, float* out8, float* err, void* stream);
+int invr_train_loss_bwd(const float* rgb_map, const float* rgb_gt, const float* terms, int64_t n_rays, float w_pair, float w_dist,
+                        float w_off, int32_t use_pair, const float* g_loss, float* g_rgb, float* g_dist, float* g_terms, void* stream);
+
 /* Backward of invr_composite_fwd: g_rgb_map (n_rays,3), g_acc_map (n_rays) or NULL, g_weights
  * (n_rays,n_samples) or NULL (e.g. from the distortion regulariser) -> g_raw (n_rays,n_samples,4). */
 int invr_composite_bwd(const float* raw, const float* g_rgb_map, const float* g_acc_map, const float* g_weights,

@@ -91,7 +91,7 @@ EXPORTS = ['invr_last_error', 'invr_version', 'invr_sizeof', 'invr_workspace_byt
            'invr_field_workspace_bytes', 'invr_field_fwd', 'invr_geometry_fwd', 'invr_generate_rays',
            'invr_rigid_transformation', 'invr_pack_parts', 'invr_grid_row_sums_len', 'invr_grid_row_sums', 'invr_adam_chunk_elems', 'invr_adam_step', 'invr_part_mlp_fwd', 'invr_part_mlp_bwd',
            'invr_knn_neighbors', 'invr_pose_points', 'invr_adam_advance', 'invr_train_workspace_bytes', 'invr_train_fwd',
-           'invr_train_bwd', 'invr_expand_row_grad']
+           'invr_train_bwd', 'invr_expand_row_grad', 'invr_train_loss_fwd', 'invr_train_loss_bwd']
 BWD_HEAD, BWD_DEFORMER, BWD_ALL = 1, 64, 127
 NUM_STAGES = 14
 STAGE_NAMES = ['cull', 'knn', 'warp'] + ['encode_%d' % p for p in range(5)] + ['mlp_%d' % p for p in range(5)] + ['composite']
@@ -136,6 +136,9 @@ def lib():
         L.invr_train_bwd.restype = C.c_int
         L.invr_expand_row_grad.argtypes = [C.POINTER(InvrGrid), vp, vp, vp, vp]
         L.invr_expand_row_grad.restype = C.c_int
+        L.invr_train_loss_fwd.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_int32, vp, vp, vp]
+        L.invr_train_loss_bwd.argtypes = [vp, vp, vp, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_int32, vp, vp, vp, vp, vp]
+        L.invr_train_loss_fwd.restype = L.invr_train_loss_bwd.restype = C.c_int
         L.invr_knn_neighbors.argtypes = [C.POINTER(InvrScene), vp, C.c_int64, vp, vp, vp, vp, vp]
         L.invr_knn_neighbors.restype = C.c_int
         L.invr_pose_points.argtypes = [C.POINTER(InvrScene), vp, vp, vp, vp, vp, C.c_int64, C.c_int32, vp, C.c_int64, vp, vp, vp]

@@ -549,25 +549,70 @@ class TrainRenderFn(torch.autograd.Function):
         return head + tuple(out)
 
 
+class TrainLossFn(torch.autograd.Function):
+    """NetworkWrapper's objective on the fused node's outputs as ONE node (invr_train_loss_fwd / _bwd): rgb_map (n,3), the target
+    (n,3), the distortion regulariser (n,) or None and the node's `terms` -> (out8 = [loss, img_loss, psnr, reg_dist, offset_loss,
+    pair_loss, 0, 0], err (n,)); only out8[0] carries a gradient.  As torch ops the same arithmetic was ~35 tiny kernels and as many
+    again in their backward, 1 ms of host-bound time per iteration."""
+
+    @staticmethod
+    def forward(ctx, rgb, gt, dist, terms, w_pair, w_dist, w_off, use_pair):
+        L = _abi.lib()
+        rgb, gt = rgb.contiguous(), gt.contiguous().to(torch.float32)
+        n = rgb.shape[0]
+        out = torch.empty(8, device=rgb.device)
+        err = torch.empty(n, device=rgb.device)
+        dist_c = dist.contiguous() if dist is not None else None
+        _abi.check(L.invr_train_loss_fwd(_abi.ptr(rgb), _abi.ptr(gt), _abi.ptr(dist_c), _abi.ptr(terms), n, w_pair, w_dist, w_off, int(use_pair),
+                                         _abi.ptr(out), _abi.ptr(err), _abi.stream_ptr()))
+        ctx.save_for_backward(rgb, gt, terms)
+        ctx.has_dist, ctx.w = dist is not None, (w_pair, w_dist, w_off, int(use_pair))
+        ctx.mark_non_differentiable(err)
+        return out, err
+
+    @staticmethod
+    def backward(ctx, g_out, _g_err):
+        L = _abi.lib()
+        rgb, gt, terms = ctx.saved_tensors
+        n = rgb.shape[0]
+        g_loss = g_out[:1].contiguous()
+        g_rgb = torch.empty_like(rgb)
+        g_dist = torch.empty(n, device=rgb.device) if ctx.has_dist else None
+        g_terms = torch.empty(TERM_LEN, device=rgb.device)
+        w_pair, w_dist, w_off, use_pair = ctx.w
+        _abi.check(L.invr_train_loss_bwd(_abi.ptr(rgb), _abi.ptr(gt), _abi.ptr(terms), n, w_pair, w_dist, w_off, use_pair, _abi.ptr(g_loss),
+                                         _abi.ptr(g_rgb), _abi.ptr(g_dist), _abi.ptr(g_terms), _abi.stream_ptr()))
+        return g_rgb, None, g_dist, g_terms, None, None, None, None
+
+
 class LazyTrainRet(dict):
     """The train-mode return dict of Renderer.render.  rgb_map / acc_map / raw / occ / reg_distortion_loss and the fused
     regulariser terms (offset_loss, pair_loss: differentiable scalars) are present; the reference's dynamic-shape tensors
     resd / tpts / tocc / oresd are materialised from the workspace on first access (that read-back synchronises with the
     device, like the reference's own nonzero()s; they are detached — the gradient flows through the fused terms)."""
-    def __init__(self, base, lazy_keys, materialise):
+    def __init__(self, base, lazy_keys, materialise, thunks=None):
         super().__init__(base)
         self._lazy, self._mat, self._done = tuple(lazy_keys), materialise, False
+        self._thunks = dict(thunks or {})       # cheap derived entries (a few torch ops, no synchronisation), built on first access:
+                                                # the trainer's fused objective never touches them (offset_loss / pair_loss)
+
+    def _thunk(self, k):
+        if k in self._thunks:
+            dict.__setitem__(self, k, self._thunks.pop(k)())
 
     def _fill(self):
+        for k in tuple(self._thunks):
+            self._thunk(k)
         if not self._done:
             self._done = True
             for k, v in self._mat().items():
                 dict.__setitem__(self, k, v)
 
     def __contains__(self, k):
-        return dict.__contains__(self, k) or (not self._done and k in self._lazy)
+        return dict.__contains__(self, k) or k in self._thunks or (not self._done and k in self._lazy)
 
     def __getitem__(self, k):
+        self._thunk(k)
         if not dict.__contains__(self, k) and k in self._lazy:
             self._fill()
         return dict.__getitem__(self, k)

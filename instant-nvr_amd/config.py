@@ -77,6 +77,7 @@ DEFAULTS = {
     'pair_loss_weight': 10.0,
     'reg_dist_weight': 0.1,
     'resd_loss_weight': 0.1,
+    'train_fused_loss': True,   # training: NetworkWrapper's objective on the fused node's outputs as one node (autograd.TrainLossFn); False: torch ops
     'train_fused': True,     # training: ONE differentiable node (invr_train_fwd / invr_train_bwd); False: op-by-op autograd graph (autograd.render_train)
     'train_hip_mlp': True,   # training: part MLPs forward + backward on the HIP kernels (False: torch ops, autograd.part_field)
     'eval_row_sums': True,   # eval-mode renders read the part grids through derived row-sum tables (invr_grid_row_sums)

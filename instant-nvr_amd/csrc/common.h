@@ -114,22 +114,6 @@ __device__ __forceinline__ float softplus_f(float x) {
     const float e = exp2_raw(-fabsf(x) * INVR_LOG2E);
     return fmaf(log2_raw(1.0f + e), INVR_LN2, fmaxf(x, 0.0f));
 }
-// softplus(x) and sigmoid(x) = softplus'(x) with RELATIVE accuracy (~3 ulp) over the whole range — for the backward kernels: the
-// gradient factor sigmoid(z) ~ e^z of a unit with a negative pre-activation must not carry the 6e-8 ABSOLUTE error of
-// 1 - exp(-softplus(z)) (a cancellation) on top of softplus_f's own absolute error; with Adam's eps = 1e-15 every extra bit of
-// gradient noise flips the sign of more rounding-level steps (tests/test_gpu_training.py, the float64 arbitration).
-//   e = exp(-|x|) with the rounding of |x| log2e carried into a first-order correction; log1p(e) = 2 atanh(e / (2 + e)) as an odd
-//   series in s = e / (2 + e) <= 1/3 (7 terms: truncation 2e-8 relative) — no hardware log near 1.
-__device__ __forceinline__ void softplus_sigmoid_acc(float x, float& sp, float& sg) {
-    const float ax = fabsf(x);
-    const float hi = -ax * INVR_LOG2E;
-    const float lo = fmaf(-ax, INVR_LOG2E, -hi) + -ax * 1.925963033500011e-8f;      // (log2e - float(log2e)) = 1.9259630335e-8
-    const float e = exp2_raw(hi) * fmaf(lo, INVR_LN2, 1.0f);
-    const float s = e / (2.0f + e), z = s * s;
-    const float series = fmaf(z, fmaf(z, fmaf(z, fmaf(z, fmaf(z, fmaf(z, 1.0f / 13.0f, 1.0f / 11.0f), 1.0f / 9.0f), 1.0f / 7.0f), 1.0f / 5.0f), 1.0f / 3.0f), 1.0f);
-    sp = fmaf(2.0f * s, series, fmaxf(x, 0.0f));
-    sg = (x >= 0.0f ? 1.0f : e) / (1.0f + e);
-}
 // 1 - exp(-s), s >= 0
 __device__ __forceinline__ float one_minus_exp_neg(float s) { return 1.0f - exp2_raw(-s * INVR_LOG2E); }
 __device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + exp2_raw(-x * INVR_LOG2E)); }

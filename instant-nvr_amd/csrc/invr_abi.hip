@@ -836,6 +836,20 @@ __global__ void k_expand_row_grad(const float* __restrict__ rg, int64_t rows, in
     if (i < rows * F) out[i] = rg[i / F];
 }
 
+extern "C" int invr_train_loss_fwd(const float* rgb_map, const float* rgb_gt, const float* dist, const float* terms, int64_t n_rays,
+                                   float w_pair, float w_dist, float w_off, int32_t use_pair, float* out8, float* err, void* stream) {
+    INVR_CHECK(rgb_map && rgb_gt && terms && out8 && n_rays >= 0, "invr_train_loss_fwd: null pointer");
+    return launch_train_loss(rgb_map, rgb_gt, dist, terms, n_rays, w_pair, w_dist, w_off, use_pair, out8, err, (hipStream_t)stream);
+}
+
+extern "C" int invr_train_loss_bwd(const float* rgb_map, const float* rgb_gt, const float* terms, int64_t n_rays, float w_pair, float w_dist,
+                                   float w_off, int32_t use_pair, const float* g_loss, float* g_rgb, float* g_dist, float* g_terms,
+                                   void* stream) {
+    INVR_CHECK(rgb_map && rgb_gt && terms && g_loss && g_rgb && g_terms && n_rays >= 0, "invr_train_loss_bwd: null pointer");
+    return launch_train_loss_bwd(rgb_map, rgb_gt, terms, n_rays, w_pair, w_dist, w_off, use_pair, g_loss, g_rgb, g_dist, g_terms,
+                                 (hipStream_t)stream);
+}
+
 extern "C" int invr_expand_row_grad(const InvrGrid* grid, const float* row_grad, float* g_dense, float* g_hash, void* stream) {
     INVR_CHECK(grid && row_grad && g_hash, "invr_expand_row_grad: null pointer");
     if (check_grid(grid, "grid")) return 1;

@@ -82,7 +82,11 @@ __global__ __launch_bounds__(TR_BLOCK) void k_train_terms(Workspace w, TrainWs t
 }
 
 // ---- thread-per-point deformer (uv_deformer.py:31-38), forward with kept activations --------------------------------
-// (BWD: the backward's recompute — activations AND their derivative factors sigmoid(z) with relative accuracy, softplus_sigmoid_acc)
+// (BWD: the backward's recompute — activations AND their derivative factors softplus'(z) = sigmoid(z) formed from the pre-activation
+// (sigmoid_f: ~3 ulp RELATIVE for every z).  The earlier form 1 - exp(-softplus(z)) is a cancellation for z < 0: 6e-8 ABSOLUTE error on a
+// factor ~e^z, and with Adam's eps = 1e-15 every extra bit of gradient noise flips the sign of more rounding-level steps — the
+// deformer's first layer agreed with the float32 oracle on 0.67-0.94 of its elements after three steps, 0.99 now
+// (tests/test_gpu_training.py::test_configs3_real_shape_three_steps_vs_oracle_autograd))
 template <bool BWD> struct DeformActT { float feat[19]; float h1[32]; float h2[32]; float th[3]; float s1[BWD ? 32 : 1]; float s2[BWD ? 32 : 1]; };
 typedef DeformActT<false> DeformAct;
 
@@ -100,16 +104,16 @@ __device__ __forceinline__ void deform_fwd_act(const SceneDev& s, const GridDev&
         float acc = B0[j];
 #pragma unroll
         for (int i = 0; i < 19; ++i) acc = fmaf(W0[j * 19 + i], a.feat[i], acc);
-        if (BWD) softplus_sigmoid_acc(acc, a.h1[j], a.s1[j]);
-        else a.h1[j] = softplus_f(acc);
+        a.h1[j] = softplus_f(acc);
+        if (BWD) a.s1[j] = sigmoid_f(acc);
     }
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
         float acc = B1[j];
 #pragma unroll
         for (int i = 0; i < 32; ++i) acc = fmaf(W1[j * 32 + i], a.h1[i], acc);
-        if (BWD) softplus_sigmoid_acc(acc, a.h2[j], a.s2[j]);
-        else a.h2[j] = softplus_f(acc);
+        a.h2[j] = softplus_f(acc);
+        if (BWD) a.s2[j] = sigmoid_f(acc);
     }
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -469,6 +473,79 @@ int launch_deform_bwd(const RenderArgs& a, const Workspace& w, const TrainWs& t,
     const int rc = launch_deform_slice_bwd(dg, a.scene.frame_dim, t.d_uvt, t.d_gfeat, t.DM, w.counters + CNT_DTOT, G.dense, G.hash, st);
     if (rc >= 0) return rc;
     return launch_grid_encode_bwd_generic(dg, t.d_uvt, t.d_gfeat, t.DM, G.dense, G.hash, nullptr, st, w.counters + CNT_DTOT);
+}
+
+// ---- the training objective of NetworkWrapper.forward (inb_trainer.py:40-98, 176-214 with the plain MSE image term) in ONE launch --------
+// loss = w_pair pair + w_dist mean(dist) + w_off offset + mean((rgb - gt)^2), in the wrapper's order of additions; also the per-ray
+// |rgb - gt| sum (ret['error']) and the psnr statistic.  As torch ops this was ~35 kernels of 2 us with ~10 us of host time between
+// them, and as many again in their autograd backward: 1 ms of a 4 ms iteration with an idle GPU (profiles/r4_training_step.md).
+// out[8] = {loss, img_loss, psnr, reg_dist, offset_loss, pair_loss, 0, 0}
+__global__ __launch_bounds__(1024) void k_train_loss(const float* __restrict__ rgb, const float* __restrict__ gt, const float* __restrict__ dist,
+                                                     const float* __restrict__ terms, int64_t n, float w_pair, float w_dist, float w_off,
+                                                     int use_pair, float* __restrict__ out, float* __restrict__ err) {
+    __shared__ double red[2][1024 / 64];
+    double s2 = 0.0, sd = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        float e = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { const float d = rgb[i * 3 + c] - gt[i * 3 + c]; s2 += (double)(d * d); e += fabsf(d); }
+        if (err) err[i] = e;
+        if (dist) sd += (double)dist[i];
+    }
+    for (int d = 32; d >= 1; d >>= 1) { s2 += __shfl_xor(s2, d); sd += __shfl_xor(sd, d); }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wv] = s2; red[1][wv] = sd; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s2 = sd = 0.0;
+        for (int k = 0; k < 1024 / 64; ++k) { s2 += red[0][k]; sd += red[1][k]; }
+        const float img = n > 0 ? (float)(s2 / (double)(3 * n)) : 0.0f;
+        const float rd = (dist && n > 0) ? (float)(sd / (double)n) : 0.0f;
+        const float off = terms[TERM_OFFSET_SUM] / fmaxf(terms[TERM_OFFSET_ROWS], 1.0f);
+        const float pair = use_pair ? terms[TERM_PAIR_SUM] / fmaxf(terms[TERM_PAIR_ROWS], 1.0f) : 0.0f;
+        float loss = 0.0f;
+        if (use_pair) loss = loss + w_pair * pair;
+        if (dist) loss = loss + w_dist * rd;
+        loss = loss + w_off * off;
+        loss = loss + img;
+        out[0] = loss; out[1] = img; out[2] = -10.0f * logf(img) / 2.302585092994046f; out[3] = rd; out[4] = off; out[5] = pair;
+        out[6] = out[7] = 0.0f;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_train_loss_bwd(const float* __restrict__ rgb, const float* __restrict__ gt, const float* __restrict__ terms,
+                                                        int64_t n, float w_pair, float w_dist, float w_off, int use_pair,
+                                                        const float* __restrict__ g_loss, float* __restrict__ g_rgb, float* __restrict__ g_dist,
+                                                        float* __restrict__ g_terms) {
+    const float gl = g_loss[0];
+    const float k_img = n > 0 ? gl * 2.0f / (float)(3 * n) : 0.0f, k_dist = n > 0 ? gl * w_dist / (float)n : 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) g_rgb[i * 3 + c] = k_img * (rgb[i * 3 + c] - gt[i * 3 + c]);
+        if (g_dist) g_dist[i] = k_dist;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < TERM_LEN) {
+        float g = 0.0f;
+        if (threadIdx.x == TERM_OFFSET_SUM) g = gl * w_off / fmaxf(terms[TERM_OFFSET_ROWS], 1.0f);
+        if (threadIdx.x == TERM_PAIR_SUM && use_pair) g = gl * w_pair / fmaxf(terms[TERM_PAIR_ROWS], 1.0f);
+        g_terms[threadIdx.x] = g;
+    }
+}
+
+int launch_train_loss(const float* rgb, const float* gt, const float* dist, const float* terms, int64_t n, float w_pair, float w_dist,
+                      float w_off, int use_pair, float* out, float* err, hipStream_t st) {
+    hipLaunchKernelGGL(k_train_loss, dim3(1), dim3(1024), 0, st, rgb, gt, dist, terms, n, w_pair, w_dist, w_off, use_pair, out, err);
+    INVR_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_train_loss_bwd(const float* rgb, const float* gt, const float* terms, int64_t n, float w_pair, float w_dist, float w_off,
+                          int use_pair, const float* g_loss, float* g_rgb, float* g_dist, float* g_terms, hipStream_t st) {
+    const int64_t tiles = cdiv(n > 0 ? n : 1, 256);
+    hipLaunchKernelGGL(k_train_loss_bwd, dim3((unsigned)(tiles < 256 ? tiles : 256)), dim3(256), 0, st, rgb, gt, terms, n, w_pair, w_dist, w_off,
+                       use_pair, g_loss, g_rgb, g_dist, g_terms);
+    INVR_LAUNCH_CHECK();
+    return 0;
 }
 
 int launch_distortion_bwd(const float* weights, const float* z, const float* g_dist, int64_t R, int S, float* g_w, hipStream_t st) {

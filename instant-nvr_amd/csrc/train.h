@@ -37,3 +37,7 @@ int launch_part_wgrad(const float* gz, const float* a, int64_t lcap, int n_rgb, 
                       const int32_t* count, hipStream_t st);
 int launch_deform_slice_bwd(const GridDev& dg, const float* frame_dim, const float* uvt, const float* gfeat, int64_t n_max,
                             const int32_t* count, float* g_dense, float* g_hash, hipStream_t st);
+int launch_train_loss(const float* rgb, const float* gt, const float* dist, const float* terms, int64_t n, float w_pair, float w_dist,
+                      float w_off, int use_pair, float* out, float* err, hipStream_t st);
+int launch_train_loss_bwd(const float* rgb, const float* gt, const float* terms, int64_t n, float w_pair, float w_dist, float w_off,
+                          int use_pair, const float* g_loss, float* g_rgb, float* g_dist, float* g_terms, hipStream_t st);

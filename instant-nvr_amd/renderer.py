@@ -228,11 +228,12 @@ class Renderer:
         base = {'rgb_map': rgb[None], 'acc_map': acc[None], 'raw': raw[None], 'occ': occ[None, :, None]}
         if cfg.use_reg_distortion:
             base['reg_distortion_loss'] = dist[None]
-        # inb_trainer.py:89-92 / :45-48 + crit.py:8-18 as differentiable scalars (sum / device-side count)
-        base['offset_loss'] = terms[ag.TERM_OFFSET_SUM] / terms[ag.TERM_OFFSET_ROWS].clamp(min=1.0)
+        # inb_trainer.py:89-92 / :45-48 + crit.py:8-18 as differentiable scalars (sum / device-side count) — built when somebody reads
+        # them: the trainer's fused objective (autograd.TrainLossFn) takes `terms` itself
+        thunks = {'offset_loss': lambda: terms[ag.TERM_OFFSET_SUM] / terms[ag.TERM_OFFSET_ROWS].clamp(min=1.0)}
         lazy = ['resd', 'tpts', 'tocc']
         if cfg.use_pair_reg:
-            base['pair_loss'] = terms[ag.TERM_PAIR_SUM] / terms[ag.TERM_PAIR_ROWS].clamp(min=1.0)
+            thunks['pair_loss'] = lambda: terms[ag.TERM_PAIR_SUM] / terms[ag.TERM_PAIR_ROWS].clamp(min=1.0)
             lazy.append('oresd')
         ws, ws_gen = net._ws, net._ws_gen
 
@@ -240,7 +241,7 @@ class Renderer:
             ag.check_workspace(net, ws, ws_gen, "forward's resd / tpts / tocc / oresd read-back")
             with torch.no_grad():
                 return self._train_extras(net, ctx, ws, stats, n, S, max_active, noise, (ray_o, ray_d, near, far), jitter)
-        return ag.LazyTrainRet(base, lazy, materialise)
+        return ag.LazyTrainRet(base, lazy, materialise, thunks)
 
     def _train_extras(self, net, ctx, ws, stats_dev, n, S, max_active, noise_dense, rays, jitter):
         """resd / tpts / tocc (dense (Na*P, .) layouts in the reference's row order) and oresd from the pair lists of the

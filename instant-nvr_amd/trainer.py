@@ -87,9 +87,33 @@ class NetworkWrapper(nn.Module):
                     raise RuntimeError('cfg.%s is set but %s.%s is only available inside the reference application' % (flag, mod, cls))
                 setattr(self, attr, host(window_size=11) if flag == 'use_ssim' else host())
 
+    def _fused_objective(self, ret, batch):
+        """split 'train' on the fused node with the plain MSE image term: the whole objective as ONE autograd node (autograd.TrainLossFn;
+        same terms, same order of additions as the op-by-op form below) -> (loss, scalar_stats) or None when it does not apply."""
+        cfg = self.cfg
+        last = getattr(self.renderer, 'last_train', None)
+        if (last is None or last.get('terms') is None or not cfg.get('train_fused_loss', True)
+                or cfg.get('use_lpips', False) or cfg.get('use_ssim', False) or cfg.get('use_fourier', False) or cfg.get('use_tv_image', False)):
+            return None
+        from .autograd import TrainLossFn
+        dist = ret['reg_distortion_loss'][0] if dict.__contains__(ret, 'reg_distortion_loss') else None
+        out, err = TrainLossFn.apply(ret['rgb_map'][0], batch['rgb'][0], dist, last['terms'], float(cfg.pair_loss_weight), float(cfg.reg_dist_weight),
+                                     float(cfg.resd_loss_weight), bool(cfg.use_pair_reg))
+        stats = {'loss': out[0], 'img_loss': out[1].detach(), 'psnr': out[2:3].detach(), 'offset_loss': out[4].detach()}
+        if dist is not None:
+            stats['reg_dist'] = out[3].detach()
+        if cfg.use_pair_reg:
+            stats['pair_loss'] = out[5].detach()
+        ret['error'] = err[None]
+        return out[0], stats
+
     def forward(self, batch, epoch=-1, split='train'):
         cfg = self.cfg
         ret = self.renderer.render(batch, test=False, epoch=epoch)
+        if split == 'train' and self.net.training:
+            fused = self._fused_objective(ret, batch)
+            if fused is not None:
+                return ret, fused[0], fused[1], {}
         scalar_stats = {}
         dev = batch['latent_index'].device
         loss = torch.tensor(0.0, device=dev)

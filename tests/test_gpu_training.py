@@ -141,7 +141,7 @@ def test_pair_term_gradient_float64_arbitration(small_setup, golden):
     tb = {k: v.to(DEV) for k, v in bc.items()}
     tb['iter_step'] = 2
     ret, loss, stats, _ = wrap(tb, split='train')
-    (cfg.pair_loss_weight * stats['pair_loss']).backward()
+    (cfg.pair_loss_weight * ret['pair_loss']).backward()          # (the differentiable scalar of the fused node; scalar_stats hold detached values)
     mine = {k: p.grad.detach().cpu().double() for k, p in net.named_parameters() if k.startswith('tpose_deformer') and p.grad is not None}
     grads = {}
     for dt in (torch.float32, torch.float64):

@@ -78,3 +78,24 @@ if args.prof:
             step(200 + i)
         torch.cuda.synchronize()
     print(prof.key_averages().table(sort_by='cuda_time_total', row_limit=40, max_name_column_width=70))
+if os.environ.get('HOSTPROF'):
+    # host side of the loop: time to ISSUE n iterations (no synchronisation inside) vs time until the GPU has finished them, and a cProfile
+    # of the issuing thread
+    import cProfile, pstats, io
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(40):
+        step(300 + i)
+    t_issue = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    t_done = time.perf_counter() - t0
+    print('40 iterations: issued in %.3f ms each, finished in %.3f ms each' % (t_issue / 40 * 1e3, t_done / 40 * 1e3))
+    pr = cProfile.Profile()
+    pr.enable()
+    for i in range(40):
+        step(400 + i)
+    pr.disable()
+    torch.cuda.synchronize()
+    s = io.StringIO()
+    pstats.Stats(pr, stream=s).sort_stats('cumulative').print_stats(45)
+    print(s.getvalue()[:9000])
