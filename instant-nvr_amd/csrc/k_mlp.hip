@@ -38,7 +38,41 @@ struct MlpCol {
     f32x4 feat;                 // occ features 1..16 (true scale)
     float occ;
     float k5[11];               // rgb layer-1 k-slots 5..15: sin/cos (6), d (1), feat (4)
+#if MLP_BF16
+    mlp_bf16x8 sh[2], sm[2], sl[2];   // the 16 inputs of the next 64-wide layer (k-slots s = 8 kb + j) as bf16 hi / mid / lo terms
+#endif
 };
+
+#if MLP_BF16
+// One 64 -> 64 (or 64-slot -> 64) layer of a column block on the bf16 matrix pipe: six products per (m-tile, k-block), smallest first.
+__device__ __forceinline__ void bf16x3_layer(const float* lds_w, const float* lds_b, int lane, int g, const MlpCol& c, f32x4* out) {
+    const mlp_bf16x8* w = reinterpret_cast<const mlp_bf16x8*>(lds_w);
+#pragma unroll
+    for (int mo = 0; mo < 4; ++mo) {
+        out[mo] = bias4(lds_b, mo, g);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const mlp_bf16x8 ah = w[(0 * 8 + mo * 2 + kb) * 64 + lane], am = w[(1 * 8 + mo * 2 + kb) * 64 + lane], al = w[(2 * 8 + mo * 2 + kb) * 64 + lane];
+            out[mo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, c.sm[kb], out[mo], 0, 0, 0);
+            out[mo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, c.sl[kb], out[mo], 0, 0, 0);
+            out[mo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, c.sh[kb], out[mo], 0, 0, 0);
+            out[mo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, c.sm[kb], out[mo], 0, 0, 0);
+            out[mo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, c.sh[kb], out[mo], 0, 0, 0);
+            out[mo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, c.sh[kb], out[mo], 0, 0, 0);
+        }
+    }
+}
+// the hidden activations c.h (k-slot s <-> h[s >> 2][s & 3]) as the split inputs of the next layer
+__device__ __forceinline__ void bf16x3_split_h(MlpCol& c) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = c.h[2 * kb + (j >> 2)][j & 3];
+        bf16_split3x8(v, c.sh[kb], c.sm[kb], c.sl[kb]);
+    }
+}
+#endif
 
 // The stages of the two MLPs for ONE column block.  mlp_part runs two column blocks per wave SKEWED by one stage, so that in
 // every scheduling region the matrix-core instructions of one block sit beside the vector instructions (activation, view-
@@ -57,6 +91,13 @@ __device__ __forceinline__ void st_occ1(const float* lds, int lane, int g, MlpCo
 __device__ __forceinline__ void st_act(MlpCol& c) {
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) c.h[mt] = softplus4_log2(c.h[mt]);
+}
+// activation of a colour-MLP layer whose output feeds another 64-wide layer (rgb1 of the three-layer nets): + the bf16 split
+__device__ __forceinline__ void st_act_split(MlpCol& c) {
+    st_act(c);
+#if MLP_BF16
+    bf16x3_split_h(c);
+#endif
 }
 __device__ __forceinline__ void st_occ2(const float* lds, int lane, int g, MlpCol& c) {       // features 1..16 on MFMA, logit 0 on VALU
     c.feat = bias4(lds + O_B_OCC2, 0, g);
@@ -80,8 +121,20 @@ __device__ __forceinline__ void st_rgb_in(MlpCol& c, int g, float fmul) {
     c.k5[6] = g == 0 ? c.dv[0] : (g == 1 ? c.dv[1] : (g == 2 ? c.dv[2] : 0.0f));
 #pragma unroll
     for (int r = 0; r < 4; ++r) c.k5[7 + r] = c.feat[r];
+#if MLP_BF16
+    {   // the 16 k-slots of rgb layer 1 (s < 5: embedding, s >= 5: k5) as split bf16 inputs
+        float v0[8] = {c.eb[0], c.eb[1], c.eb[2], c.eb[3], c.eb[4], c.k5[0], c.k5[1], c.k5[2]};
+        float v1[8] = {c.k5[3], c.k5[4], c.k5[5], c.k5[6], c.k5[7], c.k5[8], c.k5[9], c.k5[10]};
+        bf16_split3x8(v0, c.sh[0], c.sm[0], c.sl[0]);
+        bf16_split3x8(v1, c.sh[1], c.sm[1], c.sl[1]);
+    }
+#endif
 }
 __device__ __forceinline__ void st_rgb1(const float* lds, int lane, int g, MlpCol& c) {
+#if MLP_BF16
+    bf16x3_layer(lds + O_W_RGB1, lds + O_B_RGB1, lane, g, c, c.h);
+    return;
+#endif
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) c.h[mt] = bias4(lds + O_B_RGB1, mt, g);
 #pragma unroll
@@ -93,6 +146,15 @@ __device__ __forceinline__ void st_rgb1(const float* lds, int lane, int g, MlpCo
     }
 }
 __device__ __forceinline__ void st_rgb2(const float* lds, int lane, int g, MlpCol& c) {
+#if MLP_BF16
+    {
+        f32x4 o[4];
+        bf16x3_layer(lds + O_W_RGB2, lds + O_B_RGB2, lane, g, c, o);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) c.h[mt] = o[mt];
+        return;
+    }
+#endif
     f32x4 h2[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) h2[mt] = bias4(lds + O_B_RGB2, mt, g);
@@ -113,6 +175,18 @@ __device__ __forceinline__ float4 st_head(const float* lds, int g, const MlpCol&
     return make_float4(o[0], o[1], o[2], c.occ);
 }
 #define MLP_FENCE() __builtin_amdgcn_sched_barrier(0)
+// matrix / vector instruction mix of the colour-MLP regions below (bf16 x 3: 48 MFMAs of 16 cycles + the split of the next inputs)
+#if MLP_BF16
+#define RGB_MFMAS 48
+#define RGB_V 3
+#define RGB_MFMAS_IN 48
+#define RGB_V_IN 3
+#else
+#define RGB_MFMAS 64
+#define RGB_V 1
+#define RGB_MFMAS_IN 30
+#define RGB_V_IN 1
+#endif
 // Interleave directive for one scheduling region (between two MLP_FENCEs): N_MFMA groups of {1 matrix instruction, V vector
 // instructions} — the vector work of the other column block is issued in the shadows of this block's MFMAs (<= 5 single-issue
 // VALU fit beside a 32-cycle fp32 MFMA; MI355X_MICROARCH.md).  LDS reads of the weights float freely.
@@ -170,18 +244,19 @@ __device__ __forceinline__ void mlp_part(float* lds, const PartMlpDev& pm, const
         mlp_interleave<16, 4>();
         MLP_FENCE();
         st_rgb1(lds, lane, g, A); st_rgb_in(B, g, fmul);
-        mlp_interleave<30, 1>();
+        mlp_interleave<RGB_MFMAS_IN, RGB_V_IN>();
         MLP_FENCE();
-        st_rgb1(lds, lane, g, B); st_act(A);
-        mlp_interleave<64, 1>();
+        st_rgb1(lds, lane, g, B);
+        if (NRGB == 3) st_act_split(A); else st_act(A);
+        mlp_interleave<RGB_MFMAS, RGB_V>();
         MLP_FENCE();
         float4 rA, rB;
         if (NRGB == 3) {
-            st_rgb2(lds, lane, g, A); st_act(B);
-            mlp_interleave<64, 1>();
+            st_rgb2(lds, lane, g, A); st_act_split(B);
+            mlp_interleave<RGB_MFMAS, RGB_V>();
             MLP_FENCE();
             st_rgb2(lds, lane, g, B); st_act(A);
-            mlp_interleave<64, 1>();
+            mlp_interleave<RGB_MFMAS, 1>();
             MLP_FENCE();
             rA = st_head(lds, g, A); st_act(B);
             MLP_FENCE();
@@ -517,18 +592,19 @@ __device__ __forceinline__ void rgb_part(float* lds, const MlpAllArgs& a, const 
         st_rgb_in(A, g, fmul);
         MLP_FENCE();
         st_rgb1(lds, lane, g, A); st_rgb_in(B, g, fmul);
-        mlp_interleave<30, 1>();
+        mlp_interleave<RGB_MFMAS_IN, RGB_V_IN>();
         MLP_FENCE();
-        st_rgb1(lds, lane, g, B); st_act(A);
-        mlp_interleave<64, 1>();
+        st_rgb1(lds, lane, g, B);
+        if (NRGB == 3) st_act_split(A); else st_act(A);
+        mlp_interleave<RGB_MFMAS, RGB_V>();
         MLP_FENCE();
         float4 rA, rB;
         if (NRGB == 3) {
-            st_rgb2(lds, lane, g, A); st_act(B);
-            mlp_interleave<64, 1>();
+            st_rgb2(lds, lane, g, A); st_act_split(B);
+            mlp_interleave<RGB_MFMAS, RGB_V>();
             MLP_FENCE();
             st_rgb2(lds, lane, g, B); st_act(A);
-            mlp_interleave<64, 1>();
+            mlp_interleave<RGB_MFMAS, 1>();
             MLP_FENCE();
             rA = st_head(lds, g, A); st_act(B);
             MLP_FENCE();
@@ -549,7 +625,7 @@ __device__ __forceinline__ void rgb_part(float* lds, const MlpAllArgs& a, const 
 }
 
 #ifndef RGB_WPS
-#define RGB_WPS 3          // workgroups per CU the colour kernel is compiled / launched for
+#define RGB_WPS (MLP_BF16 ? 2 : 3)          // workgroups per CU the colour kernel is compiled / launched for (bf16 x 3: 59 KB of LDS each)
 #endif
 __global__ __launch_bounds__(MLP_BLOCK, RGB_WPS) void k_part_rgb_all(MlpAllArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];

@@ -12,16 +12,42 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define RGB1_STEPS 18            // 72 / 4
 #define RGB1F_STEPS 16           // forward kernels: the 8 latent inputs are constant per call and folded into the bias (64 / 4)
 
+// The colour MLP's two 64-wide layers (70 -> 64 and 64 -> 64) in the FORWARD kernels run on the bf16 matrix pipe at fp32 accuracy:
+// weights and activations are split into three bf16 terms (hi + mid + lo = the fp32 value exactly: 3 x 8 significand bits), and the six
+// leading products hi hi, hi mid, mid hi, hi lo, lo hi, mid mid (the dropped ones are <= 2^-24 relative) run as v_mfma_f32_16x16x32_bf16
+// with fp32 accumulation: 48 MFMAs of 16 cycles per 16-pair tile and layer instead of 64 fp32 MFMAs of 32 cycles.  Measured on the
+// layer alone (tools/mlp_layer_microbench.hip, splitting and activation included): 0.58x the time, error against float64 7.4e-7 (fp32
+// MFMA: 8.7e-7).  -DMLP_BF16=0 builds the fp32 form (the A/B switch of profiles/r4_bf16_mlp.md).
+#ifndef MLP_BF16
+#define MLP_BF16 1
+#endif
+typedef __bf16 mlp_bf16x8 __attribute__((ext_vector_type(8)));
+#define RGB_BF_FLOATS (3 * 4 * 2 * 64 * 4)           // [split 3][m-tile 4][k-block 2][lane 64] x 8 bf16 = 24 KB per layer
+#define RGB1_LDS (MLP_BF16 && RGB_BF_FLOATS > RGB1_STEPS * 4 * 64 ? RGB_BF_FLOATS : RGB1_STEPS * 4 * 64)
+#define RGB2_LDS (MLP_BF16 && RGB_BF_FLOATS > 16 * 4 * 64 ? RGB_BF_FLOATS : 16 * 4 * 64)
+
+// x = hi + mid + lo exactly (round-to-nearest conversions; the remainders are exact fp32 subtractions)
+__device__ __forceinline__ void bf16_split3(float x, __bf16& hi, __bf16& mid, __bf16& lo) {
+    hi = (__bf16)x;
+    const float r1 = x - (float)hi;
+    mid = (__bf16)r1;
+    lo = (__bf16)(r1 - (float)mid);
+}
+__device__ __forceinline__ void bf16_split3x8(const float* v, mlp_bf16x8& hi, mlp_bf16x8& mid, mlp_bf16x8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { __bf16 a, b, c; bf16_split3(v[j], a, b, c); hi[j] = a; mid[j] = b; lo[j] = c; }
+}
+
 // LDS carve (floats)
 #define O_W_OCC1 0                                   // 5*4*64
 #define O_B_OCC1 (O_W_OCC1 + EMB_STEPS * 4 * 64)     // 64
 #define O_W_OCC2 (O_B_OCC1 + 64)                     // 16*64   (feature rows 1..16)
 #define O_B_OCC2 (O_W_OCC2 + 16 * 64)                // 16
 #define O_V_OCC (O_B_OCC2 + 16)                      // 4*16    (row 0, slot order) + bias
-#define O_W_RGB1 (O_V_OCC + 64 + 4)                  // 18*4*64
-#define O_B_RGB1 (O_W_RGB1 + RGB1_STEPS * 4 * 64)    // 64
-#define O_W_RGB2 (O_B_RGB1 + 64)                     // 16*4*64
-#define O_B_RGB2 (O_W_RGB2 + 16 * 4 * 64)            // 64
+#define O_W_RGB1 (O_V_OCC + 64 + 4)                  // 18*4*64 floats (fp32 image) | RGB_BF_FLOATS (bf16 x 3 image); 16-byte aligned
+#define O_B_RGB1 (O_W_RGB1 + RGB1_LDS)               // 64
+#define O_W_RGB2 (O_B_RGB1 + 64)                     // 16*4*64 | RGB_BF_FLOATS
+#define O_B_RGB2 (O_W_RGB2 + RGB2_LDS)               // 64
 #define O_V_OUT (O_B_RGB2 + 64)                      // 3*4*16 + 3(+1)
 #define LDS_FLOATS (O_V_OUT + 3 * 64 + 4)
 
@@ -69,7 +95,26 @@ __device__ void stage_weights(const PartMlpDev& pm, float* lds) {
             lds[O_W_OCC2 + (LOG2DOM ? ((s >> 2) * 64 + ln) * 4 + (s & 3) : t)] = W1[(1 + i) * HID + hid_col(s, g)] * s_out;
         }
     }
-    if (WHAT & 2) {
+    if ((WHAT & 2) && LOG2DOM && MLP_BF16) {
+        // bf16 x 3 images: element j of (m-tile mo, k-block kb, lane (g, i)) = W[16 mo + i][column of k-slot (s = 8 kb + j, g)]
+        mlp_bf16x8* w1 = reinterpret_cast<mlp_bf16x8*>(lds + O_W_RGB1);
+        mlp_bf16x8* w2 = reinterpret_cast<mlp_bf16x8*>(lds + O_W_RGB2);
+        for (int t = threadIdx.x; t < (NRGB == 3 ? 2 : 1) * 4 * 2 * 64; t += MLP_BLOCK) {
+            const int layer = t >> 9, ln = t & 63, kb = (t >> 6) & 1, mo = (t >> 7) & 3, g = ln >> 4, i = ln & 15;
+            float w[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (layer == 0) { const int col = rgb1f_col(8 * kb + j, g); w[j] = col >= 0 ? R0[(16 * mo + i) * 70 + col] * s_in : 0.0f; }
+                else w[j] = R1[(16 * mo + i) * HID + hid_col(8 * kb + j, g)];
+            }
+            mlp_bf16x8 vh, vm, vl;
+            bf16_split3x8(w, vh, vm, vl);
+            mlp_bf16x8* dst = layer == 0 ? w1 : w2;
+            dst[(0 * 8 + mo * 2 + kb) * 64 + ln] = vh;
+            dst[(1 * 8 + mo * 2 + kb) * 64 + ln] = vm;
+            dst[(2 * 8 + mo * 2 + kb) * 64 + ln] = vl;
+        }
+    } else if (WHAT & 2) {
         for (int t = threadIdx.x; t < (LOG2DOM ? RGB1F_STEPS : RGB1_STEPS) * 4 * 64; t += MLP_BLOCK) {
             int ln = t & 63, mt = (t >> 6) & 3, s = t >> 8, g = ln >> 4, i = ln & 15;
             int col = LOG2DOM ? rgb1f_col(s, g) : rgb1_col(s, g);

@@ -74,13 +74,14 @@ template <class T> static inline hipError_t hipMemcpyToSymbol(T& sym, const void
 namespace hostsim {
 struct Ident { uint3 tid, bid; dim3 bdim, gdim; int lane; };
 extern Ident* cur;                                    // the running work-item
-enum Op { OP_BALLOT, OP_SHFL, OP_FIRST, OP_DPP, OP_MFMA16X16X4F32, OP_WAVE_BARRIER };
+enum Op { OP_BALLOT, OP_SHFL, OP_FIRST, OP_DPP, OP_MFMA16X16X4F32, OP_WAVE_BARRIER, OP_MFMA16X16X32BF16 };
 struct Post {                                          // what a lane hands to a wave-level operation, and what it gets back
     int op, tag;
     const void* site;
     uint64_t a, b;
     int i0, i1, i2, i3;
     float f[6];
+    const float* ext;                                  // wide operands (the bf16 MFMA: 8 + 8 values as floats), valid while the lane waits
     uint64_t res;
     float fres[4];
 };
@@ -147,6 +148,16 @@ __attribute__((noinline)) static hostsim_v4f hostsim_mfma16x16x4(float a, float 
     return hostsim_v4f{p.fres[0], p.fres[1], p.fres[2], p.fres[3]};
 }
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) hostsim_mfma16x16x4((a), (b), (c), __COUNTER__)
+typedef __bf16 hostsim_v8bf __attribute__((ext_vector_type(8)));
+__attribute__((noinline)) static hostsim_v4f hostsim_mfma16x16x32bf16(hostsim_v8bf a, hostsim_v8bf b, hostsim_v4f c, int tag) {
+    float ab[16];
+    for (int k = 0; k < 8; ++k) { ab[k] = (float)a[k]; ab[8 + k] = (float)b[k]; }
+    hostsim::Post p; p.op = hostsim::OP_MFMA16X16X32BF16; p.site = __builtin_return_address(0); p.tag = tag;
+    p.ext = ab; p.f[2] = c[0]; p.f[3] = c[1]; p.f[4] = c[2]; p.f[5] = c[3];
+    hostsim::rendezvous(p);
+    return hostsim_v4f{p.fres[0], p.fres[1], p.fres[2], p.fres[3]};
+}
+#define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) hostsim_mfma16x16x32bf16((a), (b), (c), __COUNTER__)
 // lanes of a wave that exchange data through memory without any other wave-level operation in between say so with a wave barrier
 // (no instruction on the device); here it is where the lanes — fibers that otherwise run one after the other — meet
 #define __builtin_amdgcn_wave_barrier() hostsim::wave_barrier_at(__COUNTER__)

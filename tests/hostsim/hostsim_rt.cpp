@@ -174,6 +174,21 @@ static void resolve(Fiber* w, uint64_t in) {
             }
         }
     } break;
+    case OP_MFMA16X16X32BF16: {
+        // v_mfma_f32_16x16x32_bf16: A[i][8 g + k] in element k of lane 16 g + i, B[8 g + k][j] in element k of lane 16 g + j,
+        // D[4 (l / 16) + r][l % 16] in register r of lane l; products of bf16 values are exact in fp32, the sum is formed in fp32
+        if (in != ~0ull) { fprintf(stderr, "hostsim: MFMA with EXEC != all ones\n"); abort(); }
+        for (int l = 0; l < 64; ++l) {
+            const int j = l & 15;
+            for (int r = 0; r < 4; ++r) {
+                const int i = 4 * (l >> 4) + r;
+                float acc = P[l]->f[2 + r];
+                for (int g = 0; g < 4; ++g)
+                    for (int k = 0; k < 8; ++k) acc = fmaf(P[16 * g + i]->ext[k], P[16 * g + j]->ext[8 + k], acc);
+                P[l]->fres[r] = acc;
+            }
+        }
+    } break;
     case OP_WAVE_BARRIER: break;
     default: abort();
     }
