@@ -55,6 +55,19 @@ ROW_BYTES = 64             # one 16-feature fp32 table row
 PAIR_TABLE_BYTES = 16 * 8 * ROW_BYTES      # 16 levels x 8 corners x 64 B = 8192 B per (point,part) pair
 
 
+def csrc_digest():
+    """sha256 over the kernel sources the library is built from: the PMC summaries under profiles/ record it (tools/prof_all.sh), and a
+    bench line that reads counters measured on OTHER sources says so (`counters_stale`)."""
+    import hashlib
+    d = os.path.join(ROOT, 'instant-nvr_amd', 'csrc')
+    h = hashlib.sha256()
+    for n in sorted(os.listdir(d)):
+        if n.endswith(('.hip', '.h')):
+            h.update(n.encode())
+            h.update(open(os.path.join(d, n), 'rb').read())
+    return h.hexdigest()[:16]
+
+
 def build_model(cfg, device, seed=0):
     # the MLPs take torch's default initialisation: seeded, because WHICH part wins a survivor's max-occupancy merge — and with it how
     # many pairs run the (larger) body / head colour MLP — depends on those weights; unseeded, the colour kernel's time moved between
@@ -645,7 +658,11 @@ def main():
             traffic = json.load(open(tf))
         if headline and os.path.exists(cf):
             counters = json.load(open(cf))
+        meta = counters.pop('_meta', {}) if isinstance(counters, dict) else {}
+        traffic.pop('_meta', None)
+        counters_stale = bool(traffic or counters) and meta.get('csrc_digest') != csrc_digest()
         src = ('profiles/ (rocprofv3 --pmc passes of this command, tools/prof_all.sh; counters cannot be collected inside the timed run)'
+               + (' — STALE: measured on other kernel sources (digest %s, now %s)' % (meta.get('csrc_digest'), csrc_digest()) if counters_stale else '')
                if traffic else None)
         mlp_kernels = ('k_part_occ_all', 'k_winner_lists', 'k_part_rgb_all')
         mlp_traffic = sum(traffic.get(k, 0) for k in mlp_kernels) if all(k in traffic for k in mlp_kernels) else None
@@ -727,6 +744,7 @@ def main():
                             'above the HBM peak'},
                 'note': 'the frame is issue-bound: KNN = VALU, part MLPs = MFMA + transcendental issue, encoder = VALU index math + L2-miss '
                         'latency; see roofline / roofline_other counters'},
+            'counters_stale': counters_stale, 'csrc_digest': csrc_digest(),
             'stage_ms_per_step': {k: v / per for k, v in stage_ms.items()},
             'stage_note': 'HIP-event stage times of frame 0 rendered ALONE (eager launches after the timed region); with %d frames in flight '
                           'the stages of different frames overlap, so their sum exceeds ms_per_step' % K,

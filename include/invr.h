@@ -108,6 +108,10 @@ typedef struct InvrScene {
     const int64_t* latent_index; /* dev (1)                                                        */
     float smpl_thresh;           /* cfg.smpl_thresh                                                */
     int32_t tpose_viewdir;       /* cfg.tpose_viewdir                                              */
+    float composite_eps;         /* the epsilon of render_weights (net_utils.py:12-15) as inb_renderer.py:72 calls it:
+                                  * volume_rendering(rgb, occ, cfg.random_bg) passes the bool as `epsilon`, so 0.0 for every INB
+                                  * yaml (random_bg False) and 1.0 with random_bg True                                      */
+    int32_t reserved0;
 } InvrScene;
 
 /* Device-side statistics block written by invr_render_fwd (int32[INVR_STATS_LEN]). */

@@ -70,7 +70,8 @@ class InvrScene(C.Structure):
                 ('pbounds', C.c_void_p), ('tuv', C.c_void_p), ('tuv_dims', C.c_int32 * 3),
                 ('tbounds', C.c_void_p), ('part_pts', C.c_void_p), ('part_pbw', C.c_void_p),
                 ('lengths2', C.c_void_p), ('part_stride', C.c_int32), ('frame_dim', C.c_void_p),
-                ('latent_index', C.c_void_p), ('smpl_thresh', C.c_float), ('tpose_viewdir', C.c_int32)]
+                ('latent_index', C.c_void_p), ('smpl_thresh', C.c_float), ('tpose_viewdir', C.c_int32),
+                ('composite_eps', C.c_float), ('reserved0', C.c_int32)]
 
 
 class InvrWsLayout(C.Structure):
@@ -337,4 +338,5 @@ def make_scene(batch, cfg, keep):
     li = batch['latent_index'].reshape(-1)[:1].to(torch.int64).contiguous(); keep.append(li)
     s.frame_dim, s.latent_index = fd.data_ptr(), li.data_ptr()
     s.smpl_thresh, s.tpose_viewdir = float(cfg.smpl_thresh), int(bool(cfg.tpose_viewdir))
+    s.composite_eps = float(bool(cfg.get('random_bg', False)))          # inb_renderer.py:72 passes cfg.random_bg as render_weights' epsilon
     return s

@@ -125,7 +125,6 @@ def make_cfg(**overrides):
 UNSUPPORTED = {
     'aggr': ('', "cfg.aggr in {'mean', 'dist', 'mindist'} (inb_part_network_multiassign.py:237-251): only the default max-occupancy merge is built"),
     'knn_k': (4, 'cfg.knn_k != 4 (blend_utils.py:732-763): the KNN / skinning kernels are built for K = 4'),
-    'random_bg': (False, 'cfg.random_bg (inb_renderer.py:72, net_utils.py:29-44): only the background-free compositing is built'),
     'part_deform': (False, 'cfg.part_deform (inb_part_network_multiassign.py:72,110): the reference itself asserts it off on this path'),
     'tpose_viewdir': (True, 'cfg.tpose_viewdir = False: TPoseHuman.forward indexes the (Na,P,3) view directions per part; the reference cannot run it either'),
     'use_knn': (True, 'cfg.use_knn = False: Network.__init__ of the reference asserts it'),
@@ -147,6 +146,12 @@ def validate(c):
             ok = have == want
         if not ok:
             raise ValueError('invr: unsupported configuration %s = %r — %s' % (k, have, why))
+    # cfg.random_bg True: inb_renderer.py:72 hands it to volume_rendering as render_weights' EPSILON (= 1.0; no background is ever added:
+    # net_utils.py:29-44's use_random_bg stays False) — built in the fused paths; the op-by-op training graph composites with epsilon 0
+    get = (lambda k, d: c.get(k, d)) if hasattr(c, 'get') else (lambda k, d: getattr(c, k, d))
+    if bool(get('random_bg', False)) and not bool(get('train_fused', True)):
+        raise ValueError('invr: unsupported configuration random_bg = True with train_fused = False — the op-by-op training graph is built '
+                         'for epsilon 0 only')
     return c
 
 

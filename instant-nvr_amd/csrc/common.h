@@ -85,6 +85,7 @@ struct SceneDev {
     // squared nearest-vertex distances between which a (point,part) pair is provably NOT flagged
     // (k_knn.hip header); near_hi2 = +inf disables the class
     float near_hi2, band_lo2;
+    float comp_eps;              // epsilon of render_weights (InvrScene::composite_eps): 0, or 1 with cfg.random_bg
 };
 
 struct MlpDev {
@@ -337,7 +338,7 @@ int launch_grid_encode_bwd_generic(const GridDev& g, const float* xyz, const flo
                                    float* g_hash, float* g_xyz, hipStream_t st, const int32_t* count = nullptr);
 int launch_part_encode_bwd_lists(const GridDev& g, const float* x_soa, const float* gout_soa, float* gx_soa, int64_t stride,
                                  int64_t n_max, const int32_t* count, float* rowgrad, hipStream_t st);
-int launch_composite_bwd(const float* raw, const float* g_rgb, const float* g_acc, const float* g_w, int64_t n_rays, int S,
+int launch_composite_bwd(const float* raw, const float* g_rgb, const float* g_acc, const float* g_w, int64_t n_rays, int S, float eps,
                          float* g_raw, hipStream_t st);
 int launch_sample_volume(const VolDev& v, int c0, int nc, const float* pts, int64_t n, float* out, hipStream_t st);
 int launch_knn_blend_dense(const SceneDev& s, const float* pose_pts, int64_t n, float* bw, float* dist, int32_t* nn, float* d2,
@@ -356,4 +357,4 @@ int launch_row_sums(const GridDev& g, float* out, hipStream_t st);
 int launch_rigid_transformation(const double* poses, const double* joints, const int32_t* parents, float* A, hipStream_t st);
 int launch_pack_parts(const float* ppts, const float* weights, const int64_t* parts, const float* tpose, int n_verts, int n_w,
                       int stride, float overlap, float* part_pts, float* part_pbw, int64_t* lengths2, float* bounds, hipStream_t st);
-int launch_composite(const float* raw, int64_t n_rays, int S, float* weights, float* rgb_map, float* acc_map, hipStream_t st);
+int launch_composite(const float* raw, int64_t n_rays, int S, float eps, float* weights, float* rgb_map, float* acc_map, hipStream_t st);

@@ -106,7 +106,7 @@ SceneDev make_scene_dev(const InvrScene* s) {
     d.tuv = VolDev{s->tuv, s->tbounds, s->tuv_dims[0], s->tuv_dims[1], s->tuv_dims[2], 2};
     d.part_pts = s->part_pts; d.part_pbw = s->part_pbw; d.lengths2 = s->lengths2; d.M = s->part_stride;
     d.frame_dim = s->frame_dim; d.latent_index = s->latent_index;
-    d.thresh = s->smpl_thresh; d.tpose_viewdir = s->tpose_viewdir;
+    d.thresh = s->smpl_thresh; d.tpose_viewdir = s->tpose_viewdir; d.comp_eps = s->composite_eps;
     // Unflagged band of the nearest-vertex distance d1 (k_knn.hip header): dist >= g(d1) with
     // g(d) = d*w/(w+1e-8), w = exp(-d^2/0.01125); g rises ~d then collapses near 0.48 m.
     auto g = [](double d) { double w = exp(-d * d / (2.0 * 0.075 * 0.075)); return d * w / (w + 1e-8); };
@@ -572,14 +572,14 @@ extern "C" int invr_composite_fwd(const float* raw, int64_t n_rays, int32_t n_sa
                                   float* rgb_map, float* acc_map, void* stream) {
     INVR_CHECK(n_rays == 0 || (raw && rgb_map && acc_map), "invr_composite_fwd: null pointer");
     INVR_CHECK(n_samples >= 1, "invr_composite_fwd: n_samples must be >= 1");
-    return launch_composite(raw, n_rays, n_samples, weights, rgb_map, acc_map, (hipStream_t)stream);
+    return launch_composite(raw, n_rays, n_samples, 0.0f, weights, rgb_map, acc_map, (hipStream_t)stream);      // (epsilon 0: the INB call)
 }
 
 extern "C" int invr_composite_bwd(const float* raw, const float* g_rgb_map, const float* g_acc_map, const float* g_weights,
                                   int64_t n_rays, int32_t n_samples, float* g_raw, void* stream) {
     INVR_CHECK(n_rays == 0 || (raw && g_rgb_map && g_raw), "invr_composite_bwd: null pointer");
     INVR_CHECK(n_samples >= 1, "invr_composite_bwd: n_samples must be >= 1");
-    return launch_composite_bwd(raw, g_rgb_map, g_acc_map, g_weights, n_rays, n_samples, g_raw, (hipStream_t)stream);
+    return launch_composite_bwd(raw, g_rgb_map, g_acc_map, g_weights, n_rays, n_samples, 0.0f, g_raw, (hipStream_t)stream);
 }
 
 extern "C" int invr_generate_rays(const double* k_inv, const double* R, const double* T, const double* cam_o,
@@ -770,7 +770,7 @@ extern "C" int invr_train_bwd(const InvrScene* scene, const InvrModel* model, in
     // distortion^T -> compositing^T (-> + direct gradient of raw) -> merge^T
     if (stages & INVR_BWD_HEAD) {
     if (g_dist_loss && launch_distortion_bwd(weights, z_vals, g_dist_loss, n_rays, n_samples, t.g_w, st)) return 1;
-    if (launch_composite_bwd(raw, g_rgb_map, g_acc_map, g_dist_loss ? t.g_w : nullptr, n_rays, n_samples, reinterpret_cast<float*>(t.g_rawfull), st)) return 1;
+    if (launch_composite_bwd(raw, g_rgb_map, g_acc_map, g_dist_loss ? t.g_w : nullptr, n_rays, n_samples, scene->composite_eps, reinterpret_cast<float*>(t.g_rawfull), st)) return 1;
     if (g_raw) {
         hipLaunchKernelGGL(k_add_inplace, dim3((unsigned)cdiv(N * 4, 256)), dim3(256), 0, st, reinterpret_cast<float*>(t.g_rawfull), g_raw, N * 4);
         INVR_LAUNCH_CHECK();

@@ -69,7 +69,7 @@ struct MergedRaw {     // merge per-part results of the survivor slot of sample 
 };
 
 template <class Src>
-__global__ __launch_bounds__(CMP_BLOCK) void k_composite(Src src, int64_t R, int S, float* __restrict__ weights,
+__global__ __launch_bounds__(CMP_BLOCK) void k_composite(Src src, int64_t R, int S, float eps, float* __restrict__ weights,
                                                          float* __restrict__ rgb_map, float* __restrict__ acc_map,
                                                          float4* __restrict__ raw_out, float* __restrict__ occ_out) {
     const int lane = threadIdx.x & 63;
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(CMP_BLOCK) void k_composite(Src src, int64_t R, int
             if (occ_out) occ_out[ray * S + s] = v.w;
         }
         const float alpha = v.w;
-        const float incl = wave_incl_prod(1.0f - alpha, lane);          // cumprod(1 - alpha + 0)
+        const float incl = wave_incl_prod(live ? 1.0f - alpha + eps : 1.0f, lane);      // cumprod(1 - alpha + epsilon); eps = 0 (1 with cfg.random_bg)
         const float excl = dpp_f<0x138, 0xF>(1.0f, incl);                // wave_shr:1 (lane 0 keeps the identity)
         const float wgt = alpha * (T_run * excl);                        // render_weights (:12-15)
         if (live && weights) weights[ray * S + s] = wgt;
@@ -100,11 +100,11 @@ __global__ __launch_bounds__(CMP_BLOCK) void k_composite(Src src, int64_t R, int
     }
 }
 
-int launch_composite(const float* raw, int64_t n_rays, int S, float* weights, float* rgb_map, float* acc_map, hipStream_t st) {
+int launch_composite(const float* raw, int64_t n_rays, int S, float eps, float* weights, float* rgb_map, float* acc_map, hipStream_t st) {
     if (n_rays == 0) return 0;
     DenseRaw src{reinterpret_cast<const float4*>(raw)};
     hipLaunchKernelGGL(k_composite<DenseRaw>, dim3((unsigned)cdiv(n_rays, CMP_BLOCK / 64)), dim3(CMP_BLOCK), 0, st,
-                       src, n_rays, S, weights, rgb_map, acc_map, (float4*)nullptr, (float*)nullptr);
+                       src, n_rays, S, eps, weights, rgb_map, acc_map, (float4*)nullptr, (float*)nullptr);
     INVR_LAUNCH_CHECK();
     return 0;
 }
@@ -114,7 +114,7 @@ int launch_merge_composite(const RenderArgs& a, const Workspace& w, float* rgb_m
     if (a.R == 0) return 0;
     MergedRaw src{w.mask, w.word_off, w.ord_rows > 0 ? w.byte_off : nullptr, w.wsel, w.rgbw, w.cap};
     hipLaunchKernelGGL(k_composite<MergedRaw>, dim3((unsigned)cdiv(a.R, CMP_BLOCK / 64)), dim3(CMP_BLOCK), 0, st,
-                       src, a.R, a.S, weights, rgb_map, acc_map, reinterpret_cast<float4*>(raw), occ);
+                       src, a.R, a.S, a.scene.comp_eps, weights, rgb_map, acc_map, reinterpret_cast<float4*>(raw), occ);
     INVR_LAUNCH_CHECK();
     return 0;
 }
@@ -153,6 +153,7 @@ int launch_distortion(const float* weights, const float* z, int64_t n_rays, int 
 }
 
 // ---- backward of the compositing (net_utils.py:12-44 under autograd) ------------------------------
+// (written for epsilon = 0; with the epsilon of render_weights every factor 1-a_j below is 1-a_j+eps.)
 // w_k = a_k T_k, T_k = prod_{j<k}(1-a_j).  With G_k = dL/dw_k (from rgb_map, acc_map and any direct
 // weight gradient):
 //     dL/da_i = T_i (G_i - Q_i),   Q_i = sum_{k>i} G_k a_k prod_{i<j<k}(1-a_j)
@@ -173,7 +174,7 @@ __device__ __forceinline__ Affine wave_suffix_compose(Affine f, int lane) {     
 
 __global__ __launch_bounds__(CMP_BLOCK) void k_composite_bwd(const float4* __restrict__ raw, const float* __restrict__ g_rgb,
                                                              const float* __restrict__ g_acc, const float* __restrict__ g_w,
-                                                             int64_t R, int S, float4* __restrict__ g_raw) {
+                                                             int64_t R, int S, float eps, float4* __restrict__ g_raw) {
     const int lane = threadIdx.x & 63;
     const int64_t ray = (int64_t)blockIdx.x * (CMP_BLOCK / 64) + (threadIdx.x >> 6);
     if (ray >= R) return;
@@ -187,19 +188,19 @@ __global__ __launch_bounds__(CMP_BLOCK) void k_composite_bwd(const float4* __res
         float T0 = 1.0f;
         for (int q = 0; q < ps; ++q) {
             const float aq = raw[ray * S + q * 64 + lane].w;
-            T0 *= __shfl(wave_incl_prod(1.0f - aq, lane), 63);
+            T0 *= __shfl(wave_incl_prod(1.0f - aq + eps, lane), 63);
         }
         const int s = ps * 64 + lane;
         const bool live = s < S;
         float4 v = live ? raw[ray * S + s] : make_float4(0.f, 0.f, 0.f, 0.f);
         const float a = v.w;
-        const float incl = wave_incl_prod(1.0f - a, lane);
+        const float incl = wave_incl_prod(live ? 1.0f - a + eps : 1.0f, lane);
         float excl = __shfl_up(incl, 1);
         if (lane == 0) excl = 1.0f;
         const float T = T0 * excl;
         const float wgt = a * T;
         const float G = live ? (gr * v.x + gg * v.y + gb * v.z + ga + (g_w ? g_w[ray * S + s] : 0.0f)) : 0.0f;
-        const Affine F = wave_suffix_compose(Affine{1.0f - a, G * a}, lane);       // dead lanes: identity map
+        const Affine F = wave_suffix_compose(Affine{live ? 1.0f - a + eps : 1.0f, G * a}, lane);       // dead lanes: identity map
         float Mn = __shfl_down(F.m, 1), Bn = __shfl_down(F.b, 1);
         if (lane == 63) { Mn = 1.0f; Bn = 0.0f; }
         const float Q = fmaf(Mn, carry, Bn);
@@ -213,11 +214,11 @@ __global__ __launch_bounds__(CMP_BLOCK) void k_composite_bwd(const float4* __res
     }
 }
 
-int launch_composite_bwd(const float* raw, const float* g_rgb, const float* g_acc, const float* g_w, int64_t n_rays, int S,
+int launch_composite_bwd(const float* raw, const float* g_rgb, const float* g_acc, const float* g_w, int64_t n_rays, int S, float eps,
                          float* g_raw, hipStream_t st) {
     if (n_rays == 0) return 0;
     hipLaunchKernelGGL(k_composite_bwd, dim3((unsigned)cdiv(n_rays, CMP_BLOCK / 64)), dim3(CMP_BLOCK), 0, st,
-                       reinterpret_cast<const float4*>(raw), g_rgb, g_acc, g_w, n_rays, S, reinterpret_cast<float4*>(g_raw));
+                       reinterpret_cast<const float4*>(raw), g_rgb, g_acc, g_w, n_rays, S, eps, reinterpret_cast<float4*>(g_raw));
     INVR_LAUNCH_CHECK();
     return 0;
 }

@@ -7,8 +7,7 @@ from invr import config
 from invr.network import Network
 
 
-BAD = [('aggr', 'mean'), ('aggr', 'dist'), ('aggr', 'mindist'), ('knn_k', 3), ('knn_k', 8), ('random_bg', True),
-       ('part_deform', True), ('tpose_viewdir', False), ('use_knn', False), ('use_amp', True)]
+BAD = [('aggr', 'mean'), ('aggr', 'dist'), ('aggr', 'mindist'), ('knn_k', 3), ('knn_k', 8), ('part_deform', True), ('tpose_viewdir', False), ('use_knn', False), ('use_amp', True)]
 
 
 @pytest.mark.parametrize('key,val', BAD)
@@ -28,6 +27,14 @@ def test_adopt_rejects_unsupported_switch(key, val):
             config.adopt(host)
     finally:
         config.set_cfg(config._node(saved))
+
+
+def test_random_bg_is_built_on_the_fused_paths_only():
+    # inb_renderer.py:72 hands cfg.random_bg to volume_rendering as render_weights' epsilon: built (fused forward / backward); the
+    # op-by-op training graph composites with epsilon 0 and must refuse
+    Network(cfg=config.make_cfg(table_log2=8, random_bg=True))
+    with pytest.raises(ValueError, match='random_bg'):
+        Network(cfg=config.make_cfg(table_log2=8, random_bg=True, train_fused=False))
 
 
 def test_defaults_and_ignored_keys_pass():

@@ -595,7 +595,8 @@ def test_network_forward_on_points(gpu_setup, golden):
 
 @pytest.mark.parametrize('over', [dict(smpl_thresh=0.1, N_samples=24),            # inb_lan.yaml threshold
                                   dict(smpl_thresh=1e9, N_samples=8),              # dense stress: every sample active
-                                  dict(smpl_thresh=0.02, N_samples=40)])
+                                  dict(smpl_thresh=0.02, N_samples=40),
+                                  dict(random_bg=True, N_samples=12)])             # inb_renderer.py:72: the flag becomes render_weights' epsilon (= 1)
 def test_render_config_variants_vs_oracle(small_setup, over):
     """Hot-path flags other than the inb_377 defaults, against the (reference-pinned) oracle."""
     from invr.config import make_cfg
@@ -628,8 +629,11 @@ def test_render_config_variants_vs_oracle(small_setup, over):
     exact = ref64['rgb_map'][0]
     err_gpu = (ret['rgb_map'][0].double() - exact).abs().max(1)[0]
     err_ref = pixel_noise(O, O.Model(sd64, cfg), b64, exact, int(cfg.N_samples), chunk=4096, ref32=ref['rgb_map'][0], trials=4)      # tests/conditioning.py
-    assert bool((err_gpu <= 1e-4 + 4 * err_ref).all()), (float(err_gpu.max()), float(err_ref.max()))
-    assert float(err_gpu.median()) < 5e-6
+    scale = max(1.0, float(exact.abs().max()))            # (epsilon = 1 lets the weights grow like 2^S: the bars scale with the image)
+    assert bool((err_gpu <= 1e-4 * scale + 4 * err_ref).all()), (float(err_gpu.max()), float(err_ref.max()), scale)
+    assert float(err_gpu.median()) < 5e-6 * scale
+    if over.get('random_bg'):
+        assert scale > 4.0                                # the epsilon did change the compositing
 
 
 def test_knn_fallback_when_vertex_sets_exceed_lds_index(small_setup):

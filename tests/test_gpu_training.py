@@ -230,6 +230,54 @@ def test_lan_config_training_loop_vs_oracle():
     assert torch.equal(b0, sd['tpose_human.part_networks.0.embedder.bounds'])
 
 
+def test_random_bg_epsilon_training_steps_vs_oracle():
+    """cfg.random_bg True: inb_renderer.py:72 passes the flag to volume_rendering as render_weights' epsilon (net_utils.py:12-15, 18:
+    weights = alpha * cumprod(1 - alpha + 1)); the fused forward / backward composite with that epsilon.  Three optimiser steps on a
+    small model against CPU autograd of the oracle + torch.optim.Adam: losses and parameters."""
+    cfg = make_cfg(table_log2=12, N_samples=12, random_bg=True)
+    sd0 = params.init_state_dict(cfg, seed=21)
+    bc = patch_batch(16, seed=2, frame=9, centre=(250, 262))
+    n, S, LR, STEPS = bc['ray_o'].shape[1], 12, 1e-3, 3
+    g = torch.Generator().manual_seed(3)
+    jit, noi = torch.rand(n, S, generator=g), torch.rand(n * S * 5, 3, generator=g)
+    net = Network(cfg=copy.deepcopy(cfg))
+    net.load_state_dict(sd0, strict=True)
+    net = net.to(DEV).train()
+    wrap = NetworkWrapper(net)
+    wrap.renderer._jitter = lambda shape, device: jit.to(device)
+    wrap.renderer._pair_noise_dense = lambda rows, device: noi.to(device)[:rows]
+    opt = driver.make_optimizer(net, lr=LR, eps=1e-15)
+    gb = {k: v.to(DEV) for k, v in bc.items()}
+    mine = [float(driver.train_step(wrap, opt, dict(gb), k + 2)[0]) for k in range(STEPS)]
+    sd = {k: v.clone() for k, v in sd0.items()}
+    keys = [k for k, p in net.named_parameters() if p.requires_grad]
+    for k in keys:
+        sd[k].requires_grad_()
+    ref_opt = torch.optim.Adam([{'params': [sd[k]], 'lr': LR} for k in keys], LR, eps=1e-15)
+    ref = []
+    for k in range(STEPS):
+        loss, _ = OT.train_loss(sd, cfg, bc, jit, noi)
+        ref_opt.zero_grad(set_to_none=True)
+        loss.backward()
+        ref_opt.step()
+        ref.append(float(loss))
+    # the epsilon is in play: the same first loss with epsilon 0 is a different number
+    cfg0 = copy.deepcopy(cfg)
+    cfg0.random_bg = False
+    with torch.no_grad():
+        l0, _ = OT.train_loss({k: v.detach() for k, v in sd0.items()}, cfg0, bc, jit, noi)
+    assert abs(float(l0) - ref[0]) > 1e-3 * abs(ref[0])
+    assert abs(mine[0] - ref[0]) < 2e-5 * max(1.0, abs(ref[0])), (mine, ref)
+    for a, b in zip(mine, ref):
+        assert abs(a - b) < 5e-3 * max(1e-3, abs(b)), (mine, ref)
+    got = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    for k in keys:
+        d = (got[k].double() - sd[k].detach().double()).abs()
+        assert float(d.max()) <= 2 * STEPS * LR * 1.01, (k, float(d.max()))
+        # (Adam with eps 1e-15 steps by +-lr on the sign of rounding-level gradients: the deformer's first layer on this tiny patch)
+        assert float((d <= 1e-5 + 1e-3 * sd[k].detach().double().abs()).double().mean()) >= (0.75 if k.startswith('tpose_deformer') else 0.9), k
+
+
 def test_reference_step_form_with_disabled_grad_scaler(small_setup):
     """The reference's optimisation step, literally (lib/train/trainers/trainer.py:116-149): forward under
     autocast(enabled=cfg.use_amp), `scaler.scale(loss).backward(); scaler.step(optimizer); scaler.update()` with

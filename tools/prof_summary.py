@@ -22,7 +22,7 @@ for r in rows[:24]:
     out.append('| %s | %s | %.3f | %.1f | %.1f | %.1f | %s |' % (short(r['Name']), r['Calls'], float(r['TotalDurationNs']) / 1e6, float(r['AverageNs']) / 1e3,
                                                               float(r['MinNs']) / 1e3, float(r['MaxNs']) / 1e3, r['Percentage']))
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(R + '/*/*_counter_collection.csv'):
+for f in [x for d in ('fetch', 'write', 'sq', 'mfma') for x in glob.glob(R + '/' + d + '/*_counter_collection.csv')]:
     for r in csv.DictReader(open(f)):
         agg[short(r['Kernel_Name'])][r['Counter_Name']].append(float(r['Counter_Value']))
 keys = sorted({c for k in agg for c in agg[k]})
@@ -54,7 +54,32 @@ for k in sel:
     counters[k] = {'avg_us': rnd(dur.get(k, float('nan')), 1), 'read_GB': rnd(fetch), 'write_GB': rnd(wr),
                    'l2_hit': rnd(hit / (hit + miss)) if hit + miss > 0 else None, 'valu_busy': rnd(valu / 100), 'mfma_busy': rnd(mfma / 100),
                    'wait_inst_any_of_wave_cycles': rnd(wait / 100), 'valu_instr_per_wave': rnd(avg(k, 'SQ_INSTS_VALU') / avg(k, 'SQ_WAVES'), 0)}
+# ---- the 64-byte-row encoder (bench.py --full-rows: what a training forward and eval_row_sums False read) ----
+if os.path.exists(R + '/fr_trace/trace_kernel_stats.csv'):
+    fr_rows = list(csv.DictReader(open(R + '/fr_trace/trace_kernel_stats.csv')))
+    fr_dur = {short(r['Name']): float(r['AverageNs']) / 1e3 for r in fr_rows}
+    fr = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(R + '/fr_fetch/*_counter_collection.csv') + glob.glob(R + '/fr_write/*_counter_collection.csv'):
+        for r in csv.DictReader(open(f)):
+            fr[short(r['Kernel_Name'])][r['Counter_Name']].append(float(r['Counter_Value']))
+    favg = lambda k, c: sum(fr[k][c]) / len(fr[k][c]) if c in fr[k] else float('nan')
+    out.append('\n## `--full-rows` frame (64-byte table rows: k_part_encode_rows_all / k_part_encode), per launch\n'
+               '| kernel | avg_us | read GB (FETCH_SIZE x2) | write GB | L2 hit % | VALU busy % | read GB/s |\n|---|---|---|---|---|---|---|')
+    for k in sorted(fr):
+        if 'encode' not in k:
+            continue
+        fetch = favg(k, 'FETCH_SIZE') * 1024 * 2 / 1e9
+        wr = favg(k, 'WRITE_SIZE') * 1024 / 1e9
+        hit, miss = favg(k, 'TCC_HIT_sum'), favg(k, 'TCC_MISS_sum')
+        gui = favg(k, 'GRBM_GUI_ACTIVE') / 8
+        valu = favg(k, 'SQ_ACTIVE_INST_VALU') * 4 / 1024 / gui * 100 if gui == gui and gui > 0 else float('nan')
+        d = fr_dur.get(k, float('nan'))
+        out.append('| %s | %.1f | %.3f | %.3f | %.0f | %.0f | %.0f |' % (k, d, fetch, wr, 100 * hit / (hit + miss) if hit + miss > 0 else float('nan'), valu, fetch / (d * 1e-6) if d == d else float('nan')))
+        counters['full_rows:' + k] = {'avg_us': round(d, 1) if d == d else None, 'read_GB': round(fetch, 3) if fetch == fetch else None,
+                                     'write_GB': round(wr, 3) if wr == wr else None}
 open(dst, 'w').write('\n'.join(out) + '\n')
+dg = open(R + '/csrc_digest.txt').read().strip() if os.path.exists(R + '/csrc_digest.txt') else None
+counters['_meta'] = {'csrc_digest': dg, 'source': R}          # bench.py flags counters measured on other kernel sources (counters_stale)
 json.dump(traffic, open(os.path.join(os.path.dirname(dst), 'hbm_traffic_per_launch.json'), 'w'), indent=1)
 json.dump(counters, open(os.path.join(os.path.dirname(dst), 'kernel_counters.json'), 'w'), indent=1)
 print('\n'.join(out[-20:]))
