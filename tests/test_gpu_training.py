@@ -232,25 +232,63 @@ def test_lan_config_training_loop_vs_oracle():
 
 def test_random_bg_epsilon_training_steps_vs_oracle():
     """cfg.random_bg True: inb_renderer.py:72 passes the flag to volume_rendering as render_weights' epsilon (net_utils.py:12-15, 18:
-    weights = alpha * cumprod(1 - alpha + 1)); the fused forward / backward composite with that epsilon.  Three optimiser steps on a
-    small model against CPU autograd of the oracle + torch.optim.Adam: losses and parameters."""
+    weights = alpha * cumprod(1 - alpha + 1)); the fused forward / backward composite with that epsilon.  On a small model: every
+    parameter gradient of one forward + backward against CPU autograd of the oracle, then three optimiser steps' losses against the
+    oracle + torch.optim.Adam."""
     cfg = make_cfg(table_log2=12, N_samples=12, random_bg=True)
     sd0 = params.init_state_dict(cfg, seed=21)
     bc = patch_batch(16, seed=2, frame=9, centre=(250, 262))
     n, S, LR, STEPS = bc['ray_o'].shape[1], 12, 1e-3, 3
     g = torch.Generator().manual_seed(3)
     jit, noi = torch.rand(n, S, generator=g), torch.rand(n * S * 5, 3, generator=g)
-    net = Network(cfg=copy.deepcopy(cfg))
-    net.load_state_dict(sd0, strict=True)
-    net = net.to(DEV).train()
-    wrap = NetworkWrapper(net)
-    wrap.renderer._jitter = lambda shape, device: jit.to(device)
-    wrap.renderer._pair_noise_dense = lambda rows, device: noi.to(device)[:rows]
-    opt = driver.make_optimizer(net, lr=LR, eps=1e-15)
     gb = {k: v.to(DEV) for k, v in bc.items()}
+
+    def fresh():
+        net = Network(cfg=copy.deepcopy(cfg))
+        net.load_state_dict(sd0, strict=True)
+        net = net.to(DEV).train()
+        wrap = NetworkWrapper(net)
+        wrap.renderer._jitter = lambda shape, device: jit.to(device)
+        wrap.renderer._pair_noise_dense = lambda rows, device: noi.to(device)[:rows]
+        return net, wrap
+    # ---- gradients of one forward + backward (no arena: ordinary dense gradients)
+    net, wrap = fresh()
+    b = dict(gb)
+    b['iter_step'] = 2
+    _, loss, _, _ = wrap(b, split='train')
+    loss.mean().backward()
+    mine_g = {k: p.grad.detach().cpu().double() for k, p in net.named_parameters() if p.grad is not None}
+    keys = [k for k, p in net.named_parameters() if p.requires_grad]
+    sd = {k: v.clone() for k, v in sd0.items()}
+    for k in keys:
+        sd[k].requires_grad_()
+    l_ref, _ = OT.train_loss(sd, cfg, bc, jit, noi)
+    l_ref.backward()
+    assert abs(float(loss) - float(l_ref)) < 2e-5 * max(1.0, abs(float(l_ref)))
+    cfg0 = copy.deepcopy(cfg)                                          # the epsilon is in play: with epsilon 0 the loss is a different number
+    cfg0.random_bg = False
+    with torch.no_grad():
+        l0, _ = OT.train_loss({k: v.detach() for k, v in sd0.items()}, cfg0, bc, jit, noi)
+    assert abs(float(l0) - float(l_ref)) > 1e-3 * abs(float(l_ref))
+    checked = 0
+    for k in keys:
+        gr = sd[k].grad
+        if gr is None or k not in mine_g:
+            continue
+        scale = float(gr.abs().max())
+        if scale == 0.0:
+            assert float(mine_g[k].abs().max()) == 0.0, k
+            continue
+        err = float((mine_g[k] - gr.double()).abs().max())
+        # (with epsilon = 1 the weights grow like 2^S and cancel in the sums: looser than the 2e-4 of the epsilon-0 golden gradients)
+        assert err <= (3e-3 if k.startswith('tpose_deformer') else 1e-3) * scale + 1e-12, (k, err, scale)
+        checked += 1
+    assert checked >= 40
+    # ---- three optimiser steps: the loss trajectory
+    net, wrap = fresh()
+    opt = driver.make_optimizer(net, lr=LR, eps=1e-15)
     mine = [float(driver.train_step(wrap, opt, dict(gb), k + 2)[0]) for k in range(STEPS)]
     sd = {k: v.clone() for k, v in sd0.items()}
-    keys = [k for k, p in net.named_parameters() if p.requires_grad]
     for k in keys:
         sd[k].requires_grad_()
     ref_opt = torch.optim.Adam([{'params': [sd[k]], 'lr': LR} for k in keys], LR, eps=1e-15)
@@ -261,21 +299,8 @@ def test_random_bg_epsilon_training_steps_vs_oracle():
         loss.backward()
         ref_opt.step()
         ref.append(float(loss))
-    # the epsilon is in play: the same first loss with epsilon 0 is a different number
-    cfg0 = copy.deepcopy(cfg)
-    cfg0.random_bg = False
-    with torch.no_grad():
-        l0, _ = OT.train_loss({k: v.detach() for k, v in sd0.items()}, cfg0, bc, jit, noi)
-    assert abs(float(l0) - ref[0]) > 1e-3 * abs(ref[0])
-    assert abs(mine[0] - ref[0]) < 2e-5 * max(1.0, abs(ref[0])), (mine, ref)
-    for a, b in zip(mine, ref):
-        assert abs(a - b) < 5e-3 * max(1e-3, abs(b)), (mine, ref)
-    got = {k: v.detach().cpu() for k, v in net.state_dict().items()}
-    for k in keys:
-        d = (got[k].double() - sd[k].detach().double()).abs()
-        assert float(d.max()) <= 2 * STEPS * LR * 1.01, (k, float(d.max()))
-        # (Adam with eps 1e-15 steps by +-lr on the sign of rounding-level gradients: the deformer's first layer on this tiny patch)
-        assert float((d <= 1e-5 + 1e-3 * sd[k].detach().double().abs()).double().mean()) >= (0.75 if k.startswith('tpose_deformer') else 0.9), k
+    for a_, b_ in zip(mine, ref):
+        assert abs(a_ - b_) < 5e-3 * max(1e-3, abs(b_)), (mine, ref)
 
 
 def test_reference_step_form_with_disabled_grad_scaler(small_setup):
