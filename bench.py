@@ -7,24 +7,31 @@ Renderer-level code through libinvr.so with the full-size inb_377 model (285,993
 Inputs (rays, scene tensors, parameters) are resident in HBM before the timed region; the step ends
 with rgb_map/acc_map (and the reference's raw/occ outputs) in HBM.
 
-N GPUs (python -m torch.distributed.run ... bench.py --gpus N): the frame's rays are dealt to the
-ranks tile-cyclically, every rank renders its tiles with a full model replica and ONE RCCL
-all-gather assembles [r,g,b,acc]; total work is fixed -> "scaling": "strong".
+Frames in flight: the timed frames are K (--in-flight, default 4; a divisor of --steps) frames of a synthetic sequence — the same body
+in K poses — rendered side by side by ONE hipGraph replay (invr.frames.FrameSet: K parallel branches of one captured graph).  A step is
+one frame; every frame does all of its per-frame work.
+
+N GPUs (python -m torch.distributed.run ... bench.py --gpus N): every frame's rays are dealt to the ranks tile-cyclically, every rank
+renders its tiles of the K frames with a full model replica, and ONE RCCL all-gather of the K frames' [r,g,b,acc] tiles — captured in
+the same graph — assembles them on every rank; total work is fixed -> "scaling": "strong".
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with these extra objects:
-  roofline      — the dominant roofline-bound stage: the part MLPs on the fp32 matrix cores (k_part_occ_all + k_winner_lists +
-                  k_part_rgb_all): algorithmic FLOPs = 4.6 k x listed pairs + 17.5 k / 9.3 k x winning pairs (SURVEY.md §8d's 22.1 k /
-                  14.0 k per pair split into its two MLPs) / the stage's HIP-event time, vs 157.3 TFLOP/s; measured HBM bytes and
-                  busy counters of the same command from profiles/ (PMC passes cannot run inside the timed region)
+  roofline      — the dominant roofline-bound stage: the part MLPs (k_part_occ_all + k_winner_lists + k_part_rgb_all): algorithmic
+                  FLOPs = 4.6 k x listed pairs + 17.5 k / 9.3 k x winning pairs (SURVEY.md §8d's 22.1 k / 14.0 k per pair split into
+                  its two MLPs) / the stage's HIP-event time, vs the 157.3 TFLOP/s of fp32-in MFMA; measured HBM bytes and busy
+                  counters of the same command from profiles/ (PMC passes cannot run inside the timed region; `counters_stale` says
+                  whether they were measured on the kernel sources this line ran)
   roofline_other— the KNN (VALU-issue bound, no roofline fraction) and the encoder (measured bytes primary, the byte model secondary)
   path_roofline — the WHOLE frame: measured HBM / Infinity-Cache bytes per frame primary, SURVEY §8d's byte model labelled secondary
-  shard_projection, samples_64, full_rows, dense_stress, api_frame — variants of the headline frame (N=1 only): rank 0's shard of a
-                  W-way split (W = 1, 2, 4, 8) on this one GPU, the yaml-default 64 samples/ray, the 64-byte-row encoder, the dense
+  shard_projection, samples_64, mid_density, full_rows, dense_stress, api_frame — variants of the headline frames (N=1 only): rank 0's
+                  shard of a W-way split (W = 1, 2, 4, 8) on this one GPU with the headline's frames in flight and with one frame at a
+                  time, the yaml-default 64 samples/ray, smpl_thresh 0.1 (3x the survivors), the 64-byte-row encoder, the dense
                   stress frame (every sample survives), and the wall clock of Renderer.render(batch) with and without the reference's
                   move-everything-to-the-host contract
   cpu_baseline  — the oracle (CPU PyTorch port of the reference path) timed on the host cores on a
                   bounded sample of the same workload (N=1 only): one 4096-ray chunk + BASELINE configs[0]
-  train_step    — informational: a few configs[4]-shaped training iterations (N=1 only)
+  train_step, api_train_step — informational: configs[4]-shaped training iterations with the build's fused optimizer and with the
+                  optimizer exactly as the reference's train_net.py builds it (N=1 only)
 The timed region is blocks of exactly --steps frames between fences, repeated until >= --min-time seconds.
 
 `--train [--train-config 377|lan] [--gpus N]` benches the training iteration instead (BASELINE configs[4] / configs[3]:
@@ -700,7 +707,8 @@ def main():
             # dominant roofline-bound stage: the tiny MLPs of all five parts on the fp32 matrix cores
             'roofline': {
                 'kernel': 'part MLPs = k_part_occ_all (19-64-17 for every listed pair) + k_winner_lists + k_part_rgb_all (70-64(-64)-3 for the '
-                          'pair that wins each survivor\'s max-occupancy merge), v_mfma_f32_16x16x4_f32', 'bound': 'mfma',
+                          'pair that wins each survivor\'s max-occupancy merge); occupancy MLP on v_mfma_f32_16x16x4_f32, the colour MLP\'s two '
+                          '64-wide layers on v_mfma_f32_16x16x32_bf16 as 3-way bf16 splits (6 products, fp32 accumulation: fp32 accuracy)', 'bound': 'mfma',
                 'achieved': tfl(mlp_flops, mlp_ms), 'peak': 157.3, 'unit': 'TFLOP/s', 'frac': tfl(mlp_flops, mlp_ms) / 157.3,
                 'traffic': mlp_traffic, 'traffic_source': src,
                 'algorithmic_flops_per_launch': int(mlp_flops), 'kernel_ms_per_launch': mlp_ms,
@@ -708,8 +716,10 @@ def main():
                 'counters': {k: binding(k) for k in mlp_kernels} if counters else None,
                 'note': 'algorithmic = 4.6 kFLOP x listed pairs + 17.5 k (body, head) / 9.3 kFLOP (leg, arms) x winning pairs on rank 0 '
                         '(SURVEY 8d\'s 22.1 k / 14.0 k split into its two MLPs; the reference evaluates both for every pair and discards the '
-                        'colour of all but the arg-max part, inb_part_network_multiassign.py:253-256); fp32-in MFMA peak = fp32 vector peak on '
-                        'gfx950; time = HIP events on the launch stream around the three launches of the stage',
+                        'colour of all but the arg-max part, inb_part_network_multiassign.py:253-256); peak = the fp32-in MFMA peak (= fp32 vector peak '
+                        'on gfx950), kept as the yardstick for the ALGORITHMIC fp32 FLOPs although the colour layers now execute each algorithmic '
+                        'product as 6 bf16 products at 16x the fp32 MFMA rate (an fp32-accurate ceiling of 2.5 PFLOP/s / 6 = 417 TFLOP/s for those '
+                        'layers); time = HIP events on the launch stream around the three launches of the stage',
             },
             'roofline_other': [
                 {'kernel': 'k_knn_pairs (largest single kernel; exact per-part 4-NN)', 'bound': 'valu-issue (no HBM / MFMA roofline applies)',

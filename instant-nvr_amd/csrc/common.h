@@ -118,6 +118,15 @@ __device__ __forceinline__ float softplus_f(float x) {
 // 1 - exp(-s), s >= 0
 __device__ __forceinline__ float one_minus_exp_neg(float s) { return 1.0f - exp2_raw(-s * INVR_LOG2E); }
 __device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + exp2_raw(-x * INVR_LOG2E)); }
+// sigmoid(x) with ~3 ulp RELATIVE accuracy for every x (the backward kernels' softplus'(z)): e = exp(-|x|) with the rounding of
+// |x| log2e carried into a first-order correction (plain exp2(x log2e) is off by |x| 1e-7 relative), then 1 / (1 + e) or e / (1 + e)
+__device__ __forceinline__ float sigmoid_acc(float x) {
+    const float ax = fabsf(x);
+    const float hi = -ax * INVR_LOG2E;
+    const float lo = fmaf(-ax, INVR_LOG2E, -hi) + -ax * 1.925963033500011e-8f;      // log2e - float(log2e) = 1.9259630335e-8
+    const float e = exp2_raw(hi) * fmaf(lo, INVR_LN2, 1.0f);
+    return (x >= 0.0f ? 1.0f : e) * __builtin_amdgcn_rcpf(1.0f + e);
+}
 
 // sin and cos of a moderate argument (|a| < ~100): Cody-Waite reduction to [-pi/4, pi/4] by
 // multiples of pi/2 (two-term constant, FMA), Cephes sinf/cosf minimax polynomials; |error| < 2e-7.

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_train_terms(Workspace w, TrainWs t
 
 // ---- thread-per-point deformer (uv_deformer.py:31-38), forward with kept activations --------------------------------
 // (BWD: the backward's recompute — activations AND their derivative factors softplus'(z) = sigmoid(z) formed from the pre-activation
-// (sigmoid_f: ~3 ulp RELATIVE for every z).  The earlier form 1 - exp(-softplus(z)) is a cancellation for z < 0: 6e-8 ABSOLUTE error on a
+// (sigmoid_acc: ~3 ulp RELATIVE for every z).  The earlier form 1 - exp(-softplus(z)) is a cancellation for z < 0: 6e-8 ABSOLUTE error on a
 // factor ~e^z, and with Adam's eps = 1e-15 every extra bit of gradient noise flips the sign of more rounding-level steps — the
 // deformer's first layer agreed with the float32 oracle on 0.67-0.94 of its elements after three steps, 0.99 now
 // (tests/test_gpu_training.py::test_configs3_real_shape_three_steps_vs_oracle_autograd))
@@ -105,7 +105,7 @@ __device__ __forceinline__ void deform_fwd_act(const SceneDev& s, const GridDev&
 #pragma unroll
         for (int i = 0; i < 19; ++i) acc = fmaf(W0[j * 19 + i], a.feat[i], acc);
         a.h1[j] = softplus_f(acc);
-        if (BWD) a.s1[j] = sigmoid_f(acc);
+        if (BWD) a.s1[j] = sigmoid_acc(acc);
     }
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
@@ -113,7 +113,7 @@ __device__ __forceinline__ void deform_fwd_act(const SceneDev& s, const GridDev&
 #pragma unroll
         for (int i = 0; i < 32; ++i) acc = fmaf(W1[j * 32 + i], a.h1[i], acc);
         a.h2[j] = softplus_f(acc);
-        if (BWD) a.s2[j] = sigmoid_f(acc);
+        if (BWD) a.s2[j] = sigmoid_acc(acc);
     }
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
