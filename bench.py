@@ -218,12 +218,12 @@ def frame_batches(res, cam_dist, K, dev):
     return cpu, gpu
 
 
-def frame_set(net, batches, S, rank, world, shard_of=0, want_raw=True, capture=True):
+def frame_set(net, batches, S, rank, world, shard_of=0, want_raw=True, capture=True, capture_exchange=True):
     """invr.frames.FrameSet over this rank's shards of `batches`: one hipGraph replay renders all of them side by side (and, world > 1,
     exchanges their tiles with one captured all-gather).  shard_of = W renders rank 0's shard of a W-way split without any exchange."""
     fns, n_rays, keep = iframes.shard_render_fns(net, batches, S, 0 if shard_of else rank, shard_of or world, want_raw=want_raw)
     fs = iframes.FrameSet(fns, n_rays, rank=0 if shard_of else rank, world=1 if shard_of else world, device=batches[0]['ray_o'].device,
-                          capture=capture)
+                          capture=capture, capture_exchange=capture_exchange)
     fs._keep = keep
     return fs
 
@@ -572,6 +572,17 @@ def main():
         except Exception as e:                       # keep the bench alive: eager launches measure the same work
             sys.stderr.write('hipGraph capture failed (%s); falling back to eager launches\n' % e)
             use_graph = False
+    if fs is not None and world > 1:
+        # the captured exchange must reproduce this rank's own rows on every rank; otherwise (a runtime that mis-replays captured
+        # collectives) the renders stay captured and the exchange is issued from the host, once per K frames
+        fs.replay()
+        ok = torch.tensor([1 if fs.own_rows_match() else 0], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            sys.stderr.write('captured all-gather did not reproduce the local rows; exchanging from the host behind every replay\n')
+            del fs
+            torch.cuda.empty_cache()
+            fs = frame_set(net, batches, S, rank, world, shard_of=args.shard_of, want_raw=want_raw, capture_exchange=False)
     if fs is None:
         fs = frame_set(net, batches, S, rank, world, shard_of=args.shard_of, want_raw=want_raw, capture=False)
     for _ in range(max(1, -(-args.warmup // K))):
@@ -603,6 +614,7 @@ def main():
     frame_stats = [o['stats'].cpu().numpy().astype('int64') for o in fs.local]
     # the exchange alone (N > 1): the captured all-gather + index_selects replayed without the renders
     exchange_ms = None
+    exchange_captured = bool(fs.exchange and fs.exchange_captured)
     if world > 1 and fs.exchange and fs.exchange_captured:
         try:
             gx = torch.cuda.CUDAGraph()
@@ -698,7 +710,7 @@ def main():
                           'round-1..3 lines) rendered side by side by ONE hipGraph replay (parallel branches, invr.frames.FrameSet); a step is '
                           'one frame, every frame does all of its per-frame scene work' % (K, K),
                 'parallelism': 'tile-cyclic ray shards x%d, full replicas, 1 all-gather per %d frames inside the same graph replay' % (world, K),
-                'exchange_only_ms_per_replay': exchange_ms,
+                'exchange_only_ms_per_replay': exchange_ms, 'exchange_captured_in_graph': exchange_captured,
                 'rays_per_sec': mean_rays * args.steps / dt,
                 'note': 'value counts every ray-sample of the frames; %.1f %% of them survive the near-surface cull (the camera sits at %.1f m so '
                         'that the body fills the frame) — survivors_per_sec is the rate of the samples that reach the networks; mid_density is '

@@ -36,15 +36,27 @@ class FrameSet:
     """K frames per replay.  `render_fns[k]()` renders this rank's rays of frame k on the CURRENT stream and returns either the
     (n_local_k, 4) [r, g, b, acc] rows or a dict with 'rgb_map' (n,3) and 'acc_map' (n,); `n_rays[k]` = rays of the whole frame k.
     After `replay()`: `local[k]` = what render_fns[k] returned, `full[k]` = the (n_rays[k], 4) map of the whole frame on every rank
-    (`local` rows for a group of one).  capture=False runs the same steps eagerly (CPU / gloo tests, debugging)."""
+    (`local` rows for a group of one).  capture=False runs the same steps eagerly (CPU / gloo tests, debugging); capture_exchange=False
+    captures the renders only and issues the all-gather + index_selects from the host behind every replay (one per K frames)."""
 
-    def __init__(self, render_fns, n_rays, rank=0, world=1, device='cuda', tile=DEFAULT_TILE, group=None, capture=True):
+    def own_rows_match(self):
+        """Sanity check of an exchange: the rows of every full map that THIS rank rendered equal its local rows (synchronises)."""
+        from .dist import tile_indices
+        for k in range(self.K):
+            if self.full[k] is None or self.local[k] is None:
+                return False
+            idx = tile_indices(self.n_rays[k], self.rank, self.world, self.tile, device=self.full[k].device)
+            if not torch.equal(self.full[k][idx], self._rgba(self.local[k])):
+                return False
+        return True
+
+    def __init__(self, render_fns, n_rays, rank=0, world=1, device='cuda', tile=DEFAULT_TILE, group=None, capture=True, capture_exchange=True):
         self.fns, self.n_rays, self.rank, self.world = list(render_fns), [int(n) for n in n_rays], rank, world
         self.device, self.tile, self.group, self.capture = torch.device(device), tile, group, capture
         self.K = len(self.fns)
         self.exchange = world > 1 or (FORCE_COLLECTIVES() and dist.is_initialized())
         self.plan = exchange_plan(self.n_rays, world, tile, self.device) if self.exchange else None
-        self.graph, self.exchange_captured = None, False
+        self.graph, self.exchange_captured, self.want_exchange_captured = None, False, capture_exchange
         self.local, self.full = [None] * self.K, [None] * self.K
         if self.exchange:
             self.send = torch.zeros(self.plan['rows'], 4, device=self.device)
@@ -82,7 +94,7 @@ class FrameSet:
     def _capture(self):
         assert self.device.type == 'cuda', 'graph capture needs a GPU (capture=False runs eagerly)'
         # the exchange is part of the graph on RCCL; any other backend (gloo in 1-GPU debugging runs) exchanges eagerly behind the replay
-        self.exchange_captured = self.exchange and dist.get_backend(self.group) == 'nccl'
+        self.exchange_captured = self.exchange and self.want_exchange_captured and dist.get_backend(self.group) == 'nccl'
         # warm-up outside the capture (workspace allocation, lazy module state, RCCL communicator set-up)
         side = torch.cuda.Stream(self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))

@@ -114,6 +114,7 @@ def _frameset_worker(rank, world, port, sizes, tile, ret):
         ok = fs.exchange and fs.plan['rows'] == sum(max(idist.shard_counts(n, world, tile)) for n in sizes)
         for _ in range(2):                                           # a second replay reuses the buffers
             fs.replay()
+            ok = ok and fs.own_rows_match()
             for b, full in zip(frames, fs.full):
                 ref_rgb, ref_acc = fake_render(b['ray_o'][0], b['ray_d'][0], b['near'][0], b['far'][0])
                 ok = ok and torch.equal(full[:, :3], ref_rgb) and torch.equal(full[:, 3], ref_acc)

@@ -97,7 +97,7 @@ def _worker(port, out_path):
         for _ in range(3):
             fs.replay()
         torch.cuda.synchronize()
-        res['frameset_equal'] = all(bool(torch.equal(f, s_)) for f, s_ in zip(fs.full, singles)) and iframes.check_overflow(fs)
+        res['frameset_equal'] = all(bool(torch.equal(f, s_)) for f, s_ in zip(fs.full, singles)) and iframes.check_overflow(fs) and fs.own_rows_match()
         res['frameset_poses_differ'] = singles[0].shape != singles[1].shape or not bool(torch.equal(singles[0], singles[1]))
         torch.save(res, out_path)
         # training: averaged gradients through the reducer (AVG over one rank = identity)
