@@ -16,6 +16,17 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
+MODES = os.path.join(ROOT, 'tests', 'golden', 'modes_small.npz')
+
+
+@pytest.fixture(scope='session')
+def golden_modes():
+    """tests/golden/make_golden_modes.py: the imported reference with cfg.aggr = 'mean' / cfg.random_bg = True (same scene / parameters)"""
+    import numpy as np
+    g = np.load(MODES)
+    return {k: g[k] for k in g.files}
+
+
 @pytest.fixture(scope='session')
 def golden():
     import numpy as np

@@ -151,6 +151,66 @@ def test_train_mode_forward(golden, small_setup):
     close(O.distortion_loss(r['weights'], r['z'])[None], golden['train_reg_distortion_loss'], 5e-6)
 
 
+MODE_CFG = {'mean': dict(aggr='mean'), 'rbg': dict(random_bg=True)}
+
+
+def mode_train_loss(r, rgb):
+    """the loss make_golden_modes.py differentiates: mse + 0.1 mean(distortion) + 0.1 mean |resd|"""
+    return ((r['rgb_map'] - rgb) ** 2).mean() + 0.1 * O.distortion_loss(r['weights'], r['z']).mean() \
+        + 0.1 * torch.norm(r['resd'].reshape(1, -1, 3), dim=2).mean()
+
+
+def test_non_default_modes_vs_reference(golden, golden_modes, small_setup):
+    """cfg.aggr = 'mean' (inb_part_network_multiassign.py:236-239) and cfg.random_bg = True (= render_weights' epsilon,
+    inb_renderer.py:72) against the imported reference (tests/golden/make_golden_modes.py): eval render, train-mode forward, loss and
+    every parameter gradient.  (aggr = 'dist' / 'mindist' stay unsupported: config.validate.)"""
+    cfg0, sd, batch, _ = small_setup
+    import copy
+    tsel = torch.from_numpy(golden['train_rays'].astype(np.int64))
+    for tag, over in MODE_CFG.items():
+        cfg = copy.deepcopy(cfg0)
+        cfg.update(over)
+        scale = max(1.0, float(np.abs(golden_modes[tag + '_rgb_map']).max()))
+        with torch.no_grad():
+            r = O.render(O.Model(sd, cfg), batch)
+        close(r['rgb_map'], golden_modes[tag + '_rgb_map'], 5e-6 * scale)
+        close(r['acc_map'], golden_modes[tag + '_acc_map'], 5e-6 * scale)
+        raw = r['raw'][0].numpy()
+        nz = golden_modes[tag + '_raw_nz_idx']
+        assert np.abs(raw[nz] - golden_modes[tag + '_raw_nz']).max() < 5e-6
+        mask = np.ones(raw.shape[0], bool)
+        mask[nz] = False
+        assert np.abs(raw[mask]).max() == 0.0
+        assert np.abs(golden_modes[tag + '_rgb_map'] - golden['render_rgb_map']).max() > 1e-3       # the switch does change the image
+        # train mode: forward, loss, gradients
+        leaves = {k: (v.clone().requires_grad_() if v.is_floating_point() and ('entries' not in k and 'offsets' not in k and 'bounds' not in k) else v)
+                  for k, v in sd.items()}
+        tb = dict(batch)
+        for k in ('ray_o', 'ray_d', 'near', 'far', 'rgb'):
+            tb[k] = batch[k][:, tsel]
+        rt = O.render(O.Model(leaves, cfg), tb, jitter=torch.from_numpy(golden['train_jitter']), want_train=True)
+        close(rt['rgb_map'], golden_modes[tag + '_train_rgb_map'], 5e-6 * scale)
+        close(rt['tocc'].reshape(1, -1, 1), golden_modes[tag + '_train_tocc'], 5e-6)
+        loss = mode_train_loss(rt, tb['rgb'])
+        assert abs(float(loss) - float(golden_modes[tag + '_train_loss'])) < 1e-6 * max(1.0, abs(float(loss)))
+        loss.backward()
+        n = 0
+        for k, v in leaves.items():
+            if not (torch.is_tensor(v) and v.requires_grad) or v.grad is None:
+                continue
+            if (tag + '_grad::' + k) in golden_modes:
+                g = golden_modes[tag + '_grad::' + k]
+                assert np.abs(v.grad.numpy() - g).max() <= 2e-4 * max(np.abs(g).max(), 1e-12) + 1e-9, (tag, k)
+                n += 1
+            elif (tag + '_grad_rows::' + k) in golden_modes:
+                rows = golden_modes[tag + '_grad_rows::' + k]
+                flat = v.grad.numpy().reshape(-1, v.shape[-1])
+                g = golden_modes[tag + '_grad_vals::' + k]
+                assert np.abs(flat[rows][:, :1] - g).max() <= 2e-4 * max(np.abs(g).max(), 1e-12) + 1e-9, (tag, k)
+                n += 1
+        assert n >= 60, n
+
+
 def parts_inputs(seed):
     """Inputs of tests/golden/make_golden_parts.py, regenerated from the seed."""
     from invr import scene
