@@ -111,8 +111,12 @@ typedef struct InvrScene {
     float composite_eps;         /* the epsilon of render_weights (net_utils.py:12-15) as inb_renderer.py:72 calls it:
                                   * volume_rendering(rgb, occ, cfg.random_bg) passes the bool as `epsilon`, so 0.0 for every INB
                                   * yaml (random_bg False) and 1.0 with random_bg True                                      */
-    int32_t reserved0;
+    int32_t aggr;                /* cfg.aggr, how TPoseHuman.forward merges the five parts' (rgb, occ) of a survivor
+                                  * (inb_part_network_multiassign.py:236-256): INVR_AGGR_MAX = '' (the part of largest occupancy, every
+                                  * INB yaml), INVR_AGGR_MEAN = 'mean' (mean over the five parts, zeros for unflagged parts)            */
 } InvrScene;
+#define INVR_AGGR_MAX 0
+#define INVR_AGGR_MEAN 1
 
 /* Device-side statistics block written by invr_render_fwd (int32[INVR_STATS_LEN]). */
 #define INVR_STATS_LEN 16

@@ -71,7 +71,7 @@ class InvrScene(C.Structure):
                 ('tbounds', C.c_void_p), ('part_pts', C.c_void_p), ('part_pbw', C.c_void_p),
                 ('lengths2', C.c_void_p), ('part_stride', C.c_int32), ('frame_dim', C.c_void_p),
                 ('latent_index', C.c_void_p), ('smpl_thresh', C.c_float), ('tpose_viewdir', C.c_int32),
-                ('composite_eps', C.c_float), ('reserved0', C.c_int32)]
+                ('composite_eps', C.c_float), ('aggr', C.c_int32)]
 
 
 class InvrWsLayout(C.Structure):
@@ -338,5 +338,6 @@ def make_scene(batch, cfg, keep):
     li = batch['latent_index'].reshape(-1)[:1].to(torch.int64).contiguous(); keep.append(li)
     s.frame_dim, s.latent_index = fd.data_ptr(), li.data_ptr()
     s.smpl_thresh, s.tpose_viewdir = float(cfg.smpl_thresh), int(bool(cfg.tpose_viewdir))
+    s.aggr = {'': 0, 'mean': 1}[cfg.get('aggr', '') or '']                 # inb_part_network_multiassign.py:236-256 (config.validate rejects the rest)
     s.composite_eps = float(bool(cfg.get('random_bg', False)))          # inb_renderer.py:72 passes cfg.random_bg as render_weights' epsilon
     return s

@@ -338,8 +338,11 @@ def render_train(net, batch, geo, views, stats, n_rays, S, pair_noise, ctx=None,
             known = (((views['pflags'][:Na].to(torch.int32) | far)[:, None] >> torch.arange(P, device=dev)[None]) & 1).bool()
         tpts = torch.where(known[..., None], tpts, tp)
     tocc = raws[..., 3]
-    ind = tocc.argmax(dim=1)                                                             # :253
-    merged = raws[torch.arange(Na, device=dev), ind]
+    if (cfg.get('aggr', '') or '') == 'mean':
+        merged = raws.mean(dim=1)                                                        # :236-239
+    else:
+        ind = tocc.argmax(dim=1)                                                         # :253
+        merged = raws[torch.arange(Na, device=dev), ind]
     act = views['active_idx'][:Na].long()
     raw_full = torch.zeros(n_rays * S, 4, device=dev).index_copy(0, act, merged)        # :156-159
     weights, rgb_map, acc_map = CompositeFn.apply(raw_full.view(n_rays, S, 4))

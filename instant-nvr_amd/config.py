@@ -123,7 +123,6 @@ def make_cfg(**overrides):
 # background, shared deformer) under a config that asks for something else.  (cfg.N_importance — 128 in inb_377.yaml — is read by
 # nothing in the reference's lib/: it is ignored here as it is there.)
 UNSUPPORTED = {
-    'aggr': ('', "cfg.aggr in {'mean', 'dist', 'mindist'} (inb_part_network_multiassign.py:237-251): only the default max-occupancy merge is built"),
     'knn_k': (4, 'cfg.knn_k != 4 (blend_utils.py:732-763): the KNN / skinning kernels are built for K = 4'),
     'part_deform': (False, 'cfg.part_deform (inb_part_network_multiassign.py:72,110): the reference itself asserts it off on this path'),
     'tpose_viewdir': (True, 'cfg.tpose_viewdir = False: TPoseHuman.forward indexes the (Na,P,3) view directions per part; the reference cannot run it either'),
@@ -149,6 +148,12 @@ def validate(c):
     # cfg.random_bg True: inb_renderer.py:72 hands it to volume_rendering as render_weights' EPSILON (= 1.0; no background is ever added:
     # net_utils.py:29-44's use_random_bg stays False) — built in the fused paths; the op-by-op training graph composites with epsilon 0
     get = (lambda k, d: c.get(k, d)) if hasattr(c, 'get') else (lambda k, d: getattr(c, k, d))
+    # cfg.aggr (inb_part_network_multiassign.py:236-256): '' = the part of largest occupancy (every INB yaml) and 'mean' are built.
+    # 'dist' weights part p by normalize(1 / (part_dist + 1e-5)) where part_dist is the eps-normalised KNN distance, ~0 for FAR parts
+    # (so parts far from the point dominate), and 'mindist' stops at a breakpoint() in the reference itself: both raise.
+    if (get('aggr', '') or '') not in ('', 'mean'):
+        raise ValueError("invr: unsupported configuration aggr = %r — cfg.aggr in {'dist', 'mindist'} (inb_part_network_multiassign.py:240-251): "
+                         "the merges built are '' (max occupancy) and 'mean'" % (get('aggr', ''),))
     if bool(get('random_bg', False)) and not bool(get('train_fused', True)):
         raise ValueError('invr: unsupported configuration random_bg = True with train_fused = False — the op-by-op training graph is built '
                          'for epsilon 0 only')

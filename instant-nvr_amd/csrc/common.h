@@ -86,6 +86,7 @@ struct SceneDev {
     // (k_knn.hip header); near_hi2 = +inf disables the class
     float near_hi2, band_lo2;
     float comp_eps;              // epsilon of render_weights (InvrScene::composite_eps): 0, or 1 with cfg.random_bg
+    int aggr;                    // InvrScene::aggr: 0 = max-occupancy merge, 1 = mean over the parts
 };
 
 struct MlpDev {

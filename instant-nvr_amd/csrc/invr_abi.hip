@@ -106,7 +106,7 @@ SceneDev make_scene_dev(const InvrScene* s) {
     d.tuv = VolDev{s->tuv, s->tbounds, s->tuv_dims[0], s->tuv_dims[1], s->tuv_dims[2], 2};
     d.part_pts = s->part_pts; d.part_pbw = s->part_pbw; d.lengths2 = s->lengths2; d.M = s->part_stride;
     d.frame_dim = s->frame_dim; d.latent_index = s->latent_index;
-    d.thresh = s->smpl_thresh; d.tpose_viewdir = s->tpose_viewdir; d.comp_eps = s->composite_eps;
+    d.thresh = s->smpl_thresh; d.tpose_viewdir = s->tpose_viewdir; d.comp_eps = s->composite_eps; d.aggr = s->aggr;
     // Unflagged band of the nearest-vertex distance d1 (k_knn.hip header): dist >= g(d1) with
     // g(d) = d*w/(w+1e-8), w = exp(-d^2/0.01125); g rises ~d then collapses near 0.48 m.
     auto g = [](double d) { double w = exp(-d * d / (2.0 * 0.075 * 0.075)); return d * w / (w + 1e-8); };
@@ -342,6 +342,7 @@ static int render_impl(const InvrScene* scene, const InvrModel* model,
     INVR_CHECK(scene->pbw_channels >= 1 && scene->part_stride >= 1, "invr_render_fwd: bad scene dims");
     INVR_CHECK(scene->tpose_viewdir, "invr_render_fwd: tpose_viewdir=False is not supported (the reference cannot run it either: "
                "TPoseHuman.forward indexes the (Na,3) view directions per part)");
+    INVR_CHECK(scene->aggr == INVR_AGGR_MAX || scene->aggr == INVR_AGGR_MEAN, "invr_render_fwd: InvrScene::aggr %d (0 = max-occupancy merge, 1 = mean)", scene->aggr);
     INVR_CHECK(scene->part_stride <= KNN_MAX_PART, "invr_render_fwd: part_stride %d > %d vertices per part", scene->part_stride, KNN_MAX_PART);
 
     // survivor order of the frame: ray-major, or (eval frames with a power-of-two sample count) depth-windowed inside
@@ -405,7 +406,7 @@ static int render_impl(const InvrScene* scene, const InvrModel* model,
         }
         ea.counts = ma.counts = w.counters + CNT_PAIRS;
         ea.stride = ma.stride = w.lcap; ea.cap = ma.cap = w.lcap;
-        ma.wcnt = w.wcnt; ma.gcount = w.gcount; ma.n_active = w.counters + CNT_ACTIVE; ma.rgbw = w.rgbw;
+        ma.wcnt = w.wcnt; ma.gcount = w.gcount; ma.n_active = w.counters + CNT_ACTIVE; ma.rgbw = w.rgbw; ma.aggr = scene->aggr;
         if (no_merge || (g_prof_on && !row_sums)) {
             for (int p = 0; p < INVR_NUM_PARTS; ++p) {
                 ProfStage ps(INVR_STAGE_ENCODE + p, st);
@@ -775,7 +776,7 @@ extern "C" int invr_train_bwd(const InvrScene* scene, const InvrModel* model, in
         hipLaunchKernelGGL(k_add_inplace, dim3((unsigned)cdiv(N * 4, 256)), dim3(256), 0, st, reinterpret_cast<float*>(t.g_rawfull), g_raw, N * 4);
         INVR_LAUNCH_CHECK();
     }
-    if (launch_merge_bwd(w, t.g_rawfull, t.g_raws, st)) return 1;
+    if (launch_merge_bwd(w, scene->aggr, t.g_rawfull, t.g_raws, st)) return 1;
     if (grads->part_active) {
         hipLaunchKernelGGL(k_part_active, dim3(1), dim3(64), 0, st, w.counters, grads->part_active);
         INVR_LAUNCH_CHECK();

@@ -373,8 +373,15 @@ __global__ __launch_bounds__(MLP_BLOCK, 4) void k_part_occ_all(MlpAllArgs a) {
 // layout of k_pair_lists: the pairs of group g sit at [off_g, off_g + gcount[g][p]) of part p's list, off_g = the counts of the
 // groups before it — which writes its winners, ascending, to wl[p][off_g ...) and their number to wcnt[g][p]: no global offsets,
 // no atomics; k_part_rgb_all walks the segments.  The last group appends the far-constant pair of every part.
+//
+// cfg.aggr == 'mean' (:236-239; InvrScene::aggr = INVR_AGGR_MEAN): the merged raw is the mean over the five parts of (rgb, occ), zeros
+// for unflagged parts, so every listed pair needs its colour.  The phases then run as
+//   k_part_occ_all -> k_all_lists (wl = identity, wcnt = gcount: every pair "wins") -> k_part_rgb_all ([rgb, occ] per PAIR to
+//   feat[p][pair * 4]) -> k_winner_lists<true>: the same rank walk as the arg-max merge, but it sums the listed / far-constant
+//   values of a survivor in part order, divides by 5 and writes rgbw[slot] (wsel = 0: "read rgbw[slot]").
 #define WL_BLOCK 512         // x WL_PER = PAIR_GROUP: one pass per group (the kernel is a chain of dependent round trips)
 #define WL_PER 8
+template <bool MEAN>
 __global__ __launch_bounds__(WL_BLOCK) void k_winner_lists(Workspace w) {
     __shared__ int s_cnt[WL_BLOCK / 64][INVR_NUM_PARTS];
     __shared__ int s_red[WL_BLOCK / 64][INVR_NUM_PARTS];
@@ -440,6 +447,26 @@ __global__ __launch_bounds__(WL_BLOCK) void k_winner_lists(Workspace w) {
                 pidx[k][p] = listed ? pos[p] : cidx[p];
                 pos[p] += listed ? 1 : 0;
             }
+        if (MEAN) {
+            // raws.mean(dim=1) over (Na, P, 4) with zeros for unflagged parts: the per-pair values in part order, / P
+#pragma unroll 2
+            for (int k = 0; k < WL_PER; ++k) {
+                const unsigned fl = (unsigned)(fb >> (8 * k)) & 0xffu, ff = (unsigned)(ffb >> (8 * k)) & 0xffu;
+                float4 v[INVR_NUM_PARTS];
+#pragma unroll
+                for (int p = 0; p < INVR_NUM_PARTS; ++p) v[p] = w.feat[p][(int64_t)pidx[k][p] * 4];      // (unflagged: the part's far constant, dropped below)
+                float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int p = 0; p < INVR_NUM_PARTS; ++p)
+                    if ((fl | ff) & (1u << p)) { sum.x += v[p].x; sum.y += v[p].y; sum.z += v[p].z; sum.w += v[p].w; }
+                const float np = (float)INVR_NUM_PARTS;
+                if (s0 + k < na) {
+                    w.rgbw[s0 + k] = make_float4(sum.x / np, sum.y / np, sum.z / np, sum.w / np);
+                    w.wsel[s0 + k] = ((fl | ff) & 0x1fu) ? (uint8_t)0 : (uint8_t)255;
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int k = 0; k < WL_PER; ++k)
 #pragma unroll
@@ -484,7 +511,7 @@ __global__ __launch_bounds__(WL_BLOCK) void k_winner_lists(Workspace w) {
         }
         __syncthreads();                 // s_cnt is reused by the next tile
     }
-    if (threadIdx.x < INVR_NUM_PARTS) {
+    if (!MEAN && threadIdx.x < INVR_NUM_PARTS) {
         const int p = threadIdx.x;
         int nw = 0, off = 0, ci = 0;
 #pragma unroll
@@ -492,6 +519,20 @@ __global__ __launch_bounds__(WL_BLOCK) void k_winner_lists(Workspace w) {
         if (g == g_last) w.wl[p][off + nw++] = ci;               // the far-constant pair: always evaluated
         w.wcnt[g * INVR_NUM_PARTS + p] = nw;
     }
+}
+
+// cfg.aggr == 'mean': every listed pair (and the far-constant pair that ends a part's list) goes through the colour MLP.
+__global__ __launch_bounds__(256) void k_all_lists(Workspace w) {
+    const int na = w.counters[CNT_ACTIVE];
+    const int g_last = (max(na, 1) - 1) / PAIR_GROUP;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (int64_t)gridDim.x * blockDim.x;
+#pragma unroll
+    for (int p = 0; p < INVR_NUM_PARTS; ++p) {
+        const int n = w.counters[CNT_PAIRS + p];
+        for (int64_t i = t; i < n; i += nt) w.wl[p][i] = (int)i;
+    }
+    for (int64_t i = t; i < (int64_t)(g_last + 1) * INVR_NUM_PARTS; i += nt)
+        w.wcnt[i] = w.gcount[i] + (i / INVR_NUM_PARTS == g_last ? 1 : 0);
 }
 
 // Phase 2.  A wave's unit of work is a tile of 32 winners (two 16-pair column blocks) of ONE segment (slot group); tile t of a
@@ -529,7 +570,7 @@ __device__ __forceinline__ void seg_locate(SegCursor& c, int T, const int32_t* _
 
 struct RgbIn { float eb[EMB_STEPS]; float dv[3]; float4 ft; };
 
-template <int NRGB>
+template <int NRGB, bool MEAN>
 __device__ __forceinline__ void rgb_part(float* lds, const MlpAllArgs& a, const int part, const int g_last, const int total_tiles,
                                          const int vblock, const int nblocks) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, col = lane & 15;
@@ -541,6 +582,8 @@ __device__ __forceinline__ void rgb_part(float* lds, const MlpAllArgs& a, const 
     const float* __restrict__ emb = a.emb[part];
     const float* __restrict__ ds = a.ds[part];
     const float4* __restrict__ feat = a.feat[part];
+    float4* featw = a.feat[part];                                // (aggr 'mean' writes the pair's result back into the pair's first float4:
+                                                                 //  read by this wave a tile earlier, by no other wave)
     const float* __restrict__ occp = a.occp[part];
     const int32_t* __restrict__ l_slot = a.l_slot[part];
     const int32_t* __restrict__ wl = a.wl[part];
@@ -615,8 +658,13 @@ __device__ __forceinline__ void rgb_part(float* lds, const MlpAllArgs& a, const 
             rB = st_head(lds, g, B);
         }
         if (g == 0) {
-            if (va) a.rgbw[slotA == (int)(cap - 1) ? cap + part : (int64_t)slotA] = rA;
-            if (vb) a.rgbw[slotB == (int)(cap - 1) ? cap + part : (int64_t)slotB] = rB;
+            if (MEAN) {                                           // 'mean': per pair (k_winner_lists<true> sums them per survivor)
+                if (va) featw[(int64_t)ia * 4] = rA;
+                if (vb) featw[(int64_t)ib * 4] = rB;
+            } else {
+                if (va) a.rgbw[slotA == (int)(cap - 1) ? cap + part : (int64_t)slotA] = rA;
+                if (vb) a.rgbw[slotB == (int)(cap - 1) ? cap + part : (int64_t)slotB] = rB;
+            }
         }
         inA = nA; inB = nB;
         ia = n_ia; ib = n_ib; va = n_va; vb = n_vb;
@@ -627,6 +675,7 @@ __device__ __forceinline__ void rgb_part(float* lds, const MlpAllArgs& a, const 
 #ifndef RGB_WPS
 #define RGB_WPS (MLP_BF16 ? 2 : 3)          // workgroups per CU the colour kernel is compiled / launched for (bf16 x 3: 59 KB of LDS each)
 #endif
+template <bool MEAN>
 __global__ __launch_bounds__(MLP_BLOCK, RGB_WPS) void k_part_rgb_all(MlpAllArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     __shared__ int s_tot[INVR_NUM_PARTS];
@@ -657,8 +706,8 @@ __global__ __launch_bounds__(MLP_BLOCK, RGB_WPS) void k_part_rgb_all(MlpAllArgs 
     for (int p = 0; p < INVR_NUM_PARTS; ++p) {
         int vb, nb;
         if (!part_range(tiles, total, p, b, G, vb, nb)) continue;
-        if (a.pm[p].rgb.n_linear == 3) rgb_part<3>(lds, a, p, g_last, ntile[p], vb, nb);
-        else rgb_part<2>(lds, a, p, g_last, ntile[p], vb, nb);
+        if (a.pm[p].rgb.n_linear == 3) rgb_part<3, MEAN>(lds, a, p, g_last, ntile[p], vb, nb);
+        else rgb_part<2, MEAN>(lds, a, p, g_last, ntile[p], vb, nb);
     }
 }
 
@@ -683,9 +732,19 @@ int launch_part_mlp_all(const MlpAllArgs& a, const Workspace& w, hipStream_t st)
     unsigned grid_rgb = (unsigned)(tiles < 256 * RGB_WPS ? (tiles > 0 ? tiles : 1) : 256 * RGB_WPS);
     hipLaunchKernelGGL(k_part_occ_all, dim3(grid_occ), dim3(MLP_BLOCK), 0, st, a);
     INVR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_winner_lists, dim3((unsigned)w.n_groups), dim3(WL_BLOCK), 0, st, w);
+    if (a.aggr == INVR_AGGR_MEAN) {
+        int64_t lt = cdiv(a.cap, 256);
+        hipLaunchKernelGGL(k_all_lists, dim3((unsigned)(lt < 1024 ? (lt > 0 ? lt : 1) : 1024)), dim3(256), 0, st, w);
+        INVR_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_part_rgb_all<true>, dim3(grid_rgb), dim3(MLP_BLOCK), 0, st, a);
+        INVR_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_winner_lists<true>, dim3((unsigned)w.n_groups), dim3(WL_BLOCK), 0, st, w);
+        INVR_LAUNCH_CHECK();
+        return 0;
+    }
+    hipLaunchKernelGGL(k_winner_lists<false>, dim3((unsigned)w.n_groups), dim3(WL_BLOCK), 0, st, w);
     INVR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_part_rgb_all, dim3(grid_rgb), dim3(MLP_BLOCK), 0, st, a);
+    hipLaunchKernelGGL(k_part_rgb_all<false>, dim3(grid_rgb), dim3(MLP_BLOCK), 0, st, a);
     INVR_LAUNCH_CHECK();
     return 0;
 }

@@ -200,14 +200,31 @@ __global__ __launch_bounds__(256) void k_distortion_bwd(const float* __restrict_
 // ---- max-occupancy merge, backward (inb_part_network_multiassign.py:229-256 + the scatter of :156-159) ---------------
 // The merged raw of a survivor is the (rgb, occ) of its first-maximum-occupancy part; its gradient goes to that (slot, part)
 // entry — for a far pair to the part's constant entry (slot = cap), where the contributions of all its far pairs add up.
+template <bool MEAN>
 __global__ __launch_bounds__(256) void k_merge_bwd(Workspace w, const float4* __restrict__ g_rawfull, float4* __restrict__ g_raws) {
     const int na = w.counters[CNT_ACTIVE];
     for (int slot = blockIdx.x * blockDim.x + threadIdx.x; slot < na; slot += gridDim.x * blockDim.x) {
+        const float4 g = g_rawfull[w.active_idx[slot]];
+        if (MEAN) {
+            // cfg.aggr == 'mean' (:236-239): raws.mean(dim=1) hands g / P to every part's entry; listed pairs keep theirs, the far
+            // pairs of a part add up in its constant entry, the zeros of unflagged parts have no producer
+            const unsigned fl = w.pflags[slot], ff = w.farflags[slot];
+            const float s = 1.0f / (float)INVR_NUM_PARTS;
+            const float4 gp = make_float4(g.x * s, g.y * s, g.z * s, g.w * s);
+#pragma unroll
+            for (int p = 0; p < INVR_NUM_PARTS; ++p) {
+                g_raws[(int64_t)slot * INVR_NUM_PARTS + p] = (fl & (1u << p)) ? gp : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!(fl & (1u << p)) && (ff & (1u << p))) {
+                    float* c = reinterpret_cast<float*>(g_raws + w.cap * INVR_NUM_PARTS + p);
+                    unsafeAtomicAdd(c, gp.x); unsafeAtomicAdd(c + 1, gp.y); unsafeAtomicAdd(c + 2, gp.z); unsafeAtomicAdd(c + 3, gp.w);
+                }
+            }
+            continue;
+        }
         // the forward's merge (k_winner_lists): p = the listed pair of part p, 8 + p = the far constant of part p, 255 = zeros
         const unsigned sel = w.wsel[slot];
         const int best_p = sel < 16u ? (int)(sel & 7u) : -1;
         const bool best_far = sel >= 8u && sel < 16u;
-        const float4 g = g_rawfull[w.active_idx[slot]];
 #pragma unroll
         for (int p = 0; p < INVR_NUM_PARTS; ++p)
             g_raws[(int64_t)slot * INVR_NUM_PARTS + p] = (p == best_p && !best_far) ? g : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -555,10 +572,12 @@ int launch_distortion_bwd(const float* weights, const float* z, const float* g_d
     return 0;
 }
 
-int launch_merge_bwd(const Workspace& w, const float4* g_rawfull, float4* g_raws, hipStream_t st) {
+int launch_merge_bwd(const Workspace& w, int aggr, const float4* g_rawfull, float4* g_raws, hipStream_t st) {
     INVR_HIP(hipMemsetAsync(g_raws + w.cap * INVR_NUM_PARTS, 0, INVR_NUM_PARTS * sizeof(float4), st));      // far-constant row
     int64_t tiles = cdiv(w.cap, 256);
-    hipLaunchKernelGGL(k_merge_bwd, dim3((unsigned)(tiles < 1024 ? (tiles > 0 ? tiles : 1) : 1024)), dim3(256), 0, st, w, g_rawfull, g_raws);
+    const dim3 grid((unsigned)(tiles < 1024 ? (tiles > 0 ? tiles : 1) : 1024));
+    if (aggr == INVR_AGGR_MEAN) hipLaunchKernelGGL(k_merge_bwd<true>, grid, dim3(256), 0, st, w, g_rawfull, g_raws);
+    else hipLaunchKernelGGL(k_merge_bwd<false>, grid, dim3(256), 0, st, w, g_rawfull, g_raws);
     INVR_LAUNCH_CHECK();
     return 0;
 }

@@ -187,6 +187,7 @@ struct MlpAllArgs {               // k_part_mlp_all
     const int32_t* gcount;
     const int32_t* n_active;      // counters + CNT_ACTIVE
     float4* rgbw;                 // [slot]; far constants at [cap + p] (cap = the list capacity lcap here)
+    int32_t aggr;                 // InvrScene::aggr
 };
 // occ phase over every listed pair -> k_winner_lists -> rgb phase over the winners
 int launch_part_mlp_all(const MlpAllArgs& a, const Workspace& w, hipStream_t st);

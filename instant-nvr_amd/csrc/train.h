@@ -28,7 +28,7 @@ struct DeformGrads { float* w[3]; float* b[3]; float* dense; float* hash; };
 int launch_train_terms(const RenderArgs& a, const Workspace& w, const TrainWs& t, const GridDev& dg, const MlpDev& dm,
                        const float* noise, hipStream_t st);
 int launch_distortion_bwd(const float* weights, const float* z, const float* g_dist, int64_t R, int S, float* g_w, hipStream_t st);
-int launch_merge_bwd(const Workspace& w, const float4* g_rawfull, float4* g_raws, hipStream_t st);
+int launch_merge_bwd(const Workspace& w, int aggr, const float4* g_rawfull, float4* g_raws, hipStream_t st);
 int launch_deform_bwd(const RenderArgs& a, const Workspace& w, const TrainWs& t, const GridDev& dg, const MlpDev& dm,
                       const float* g_off_sum, const float* g_pair_sum, const DeformGrads& G, hipStream_t st);
 struct WgradJob;

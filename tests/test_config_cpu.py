@@ -1,13 +1,13 @@
 """Reference switches this build does not implement must RAISE, not silently render the default behaviour
-(VERDICT r2 'what's missing' #3): cfg.aggr in {mean, dist, mindist} (inb_part_network_multiassign.py:237-251), knn_k != 4,
-random_bg, part_deform, tpose_viewdir False, use_knn False — in make/adopt and in Network.__init__."""
+(VERDICT r2 'what's missing' #3): cfg.aggr in {dist, mindist} (inb_part_network_multiassign.py:240-251), knn_k != 4,
+part_deform, tpose_viewdir False, use_knn False — in make/adopt and in Network.__init__.  (aggr = 'mean' and random_bg are built.)"""
 import pytest
 
 from invr import config
 from invr.network import Network
 
 
-BAD = [('aggr', 'mean'), ('aggr', 'dist'), ('aggr', 'mindist'), ('knn_k', 3), ('knn_k', 8), ('part_deform', True), ('tpose_viewdir', False), ('use_knn', False), ('use_amp', True)]
+BAD = [('aggr', 'dist'), ('aggr', 'mindist'), ('knn_k', 3), ('knn_k', 8), ('part_deform', True), ('tpose_viewdir', False), ('use_knn', False), ('use_amp', True)]
 
 
 @pytest.mark.parametrize('key,val', BAD)
@@ -35,6 +35,11 @@ def test_random_bg_is_built_on_the_fused_paths_only():
     Network(cfg=config.make_cfg(table_log2=8, random_bg=True))
     with pytest.raises(ValueError, match='random_bg'):
         Network(cfg=config.make_cfg(table_log2=8, random_bg=True, train_fused=False))
+
+
+def test_aggr_mean_is_built():
+    Network(cfg=config.make_cfg(table_log2=8, aggr='mean'))
+    Network(cfg=config.make_cfg(table_log2=8, aggr='mean', train_fused=False))
 
 
 def test_defaults_and_ignored_keys_pass():

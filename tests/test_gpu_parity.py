@@ -467,6 +467,85 @@ def test_train_step_gradients_vs_reference_golden(gpu_setup, golden, mode):
     _check_golden_grads(dict(net.named_parameters()), golden)
 
 
+def _mode_net(net0, cfg0, **over):
+    import copy
+    net = copy.deepcopy(net0)
+    net.cfg = copy.deepcopy(cfg0)
+    net.cfg.update(over)
+    return net
+
+
+def test_aggr_mean_render_vs_reference_golden(gpu_setup, golden, golden_modes):
+    """cfg.aggr = 'mean' (inb_part_network_multiassign.py:236-239: raw = the mean over the five parts, zeros for unflagged parts)
+    through Renderer.render against the IMPORTED reference (tests/golden/make_golden_modes.py), both encoder paths."""
+    cfg0, sd, batch, gb, net0 = gpu_setup
+    net = _mode_net(net0, cfg0, aggr='mean').eval()
+    for row_sums in (True, False):
+        r = Renderer(net)
+        with encoder_mode(net.cfg, row_sums):
+            ret = r.render(dict(gb))
+        assert r.last_stats.cpu().numpy()[6] == 0
+        err = np.abs(ret['rgb_map'].numpy() - golden_modes['mean_rgb_map']).max(-1)[0]
+        assert int((err > 1e-4).sum()) == 0, float(err.max())
+        assert maxerr(ret['acc_map'], golden_modes['mean_acc_map']) < 1e-4
+        raw = ret['raw'][0].numpy()
+        nz = golden_modes['mean_raw_nz_idx']
+        assert np.abs(raw[nz] - golden_modes['mean_raw_nz']).max() < 1e-4
+        mask = np.ones(raw.shape[0], bool)
+        mask[nz] = False
+        assert np.abs(raw[mask]).max() == 0.0
+        assert maxerr(ret['occ'][0, :, 0], raw[:, 3]) == 0.0
+    assert np.abs(golden_modes['mean_rgb_map'] - golden['render_rgb_map']).max() > 1e-3          # (the switch does change the image)
+
+
+@pytest.mark.parametrize('mode', ['fused', 'graph'])
+def test_aggr_mean_train_step_gradients_vs_reference_golden(gpu_setup, golden, golden_modes, mode):
+    """cfg.aggr = 'mean' in train mode: forward, loss and every parameter gradient of the reference's autograd (256 rays, fixed jitter)
+    through the fused node (k_merge_bwd<MEAN>: g / 5 to every flagged part) and through the op-by-op graph."""
+    cfg0, sd, batch, gb, net0 = gpu_setup
+    net = _mode_net(net0, cfg0, aggr='mean', train_fused=(mode != 'graph'))
+    cfg = net.cfg
+    tb = _train_batch(gb, golden)
+    net.train()
+    r = Renderer(net)
+    r._jitter = lambda shape, device: cu(golden['train_jitter'][0])
+    r._pair_noise = lambda like: cu(golden_modes['mean_train_pair_u'])
+    if mode != 'graph':
+        sub = {'train_jitter': golden['train_jitter'], 'train_pair_u': golden_modes['mean_train_pair_u']}
+        dense = _dense_pair_noise(net, tb, sub, cfg)
+        r._pair_noise_dense = lambda rows, device: dense[:rows]
+    net.zero_grad(set_to_none=True)
+    ret = r.render(tb)
+    assert maxerr(ret['rgb_map'], golden_modes['mean_train_rgb_map']) < 1e-4
+    offset = torch.norm(ret['resd'], dim=2).mean() if mode == 'graph' else ret['offset_loss']
+    loss = ((ret['rgb_map'] - tb['rgb']) ** 2).mean() + 0.1 * ret['reg_distortion_loss'].mean() + 0.1 * offset   # make_golden_modes.py's loss
+    assert abs(float(loss.detach()) - float(golden_modes['mean_train_loss'])) < 1e-5
+    loss.backward()
+    assert ret['tocc'].shape == golden_modes['mean_train_tocc'].shape
+    np.testing.assert_array_equal(golden_modes['mean_train_tocc'], golden['train_tocc'])           # the occupancies do not depend on the merge
+    params_, checked = dict(net.named_parameters()), 0
+    for key in golden_modes:
+        if key.startswith('mean_grad::'):
+            name, want = key[len('mean_grad::'):], golden_modes[key]
+            g = params_[name].grad.detach().cpu().numpy()
+            scale = max(float(np.abs(want).max()), 1e-6)
+            assert np.abs(g - want).max() <= 2e-4 * scale + 2e-7, (name, float(np.abs(g - want).max()), scale)
+        elif key.startswith('mean_grad_rows::'):
+            name = key[len('mean_grad_rows::'):]
+            rows, vals = golden_modes[key], golden_modes['mean_grad_vals::' + name]
+            g = params_[name].grad.detach().cpu().numpy()
+            flat = g.reshape(-1, g.shape[-1])
+            scale = max(float(np.abs(vals).max()), 1e-6)
+            assert np.abs(flat[rows][:, :1] - vals).max() <= 2e-4 * scale + 2e-7, (name, float(np.abs(flat[rows][:, :1] - vals).max()), scale)
+            mask = np.ones(flat.shape[0], bool)
+            mask[rows] = False
+            assert not mask.any() or np.abs(flat[mask]).max() <= 1e-6 * scale + 1e-9, name
+        else:
+            continue
+        checked += 1
+    assert checked >= 60, checked
+
+
 def test_train_pair_and_offset_term_gradients_fused_vs_graph(gpu_setup, golden):
     """The regulariser terms the goldens' loss does not contain (pair regulariser: neighbour deformer evaluations and
     crit.reg_raw_crit) — gradients of the fused node against torch autograd of the reference formulas on the op-by-op graph."""
@@ -596,7 +675,9 @@ def test_network_forward_on_points(gpu_setup, golden):
 @pytest.mark.parametrize('over', [dict(smpl_thresh=0.1, N_samples=24),            # inb_lan.yaml threshold
                                   dict(smpl_thresh=1e9, N_samples=8),              # dense stress: every sample active
                                   dict(smpl_thresh=0.02, N_samples=40),
-                                  dict(random_bg=True, N_samples=12)])             # inb_renderer.py:72: the flag becomes render_weights' epsilon (= 1)
+                                  dict(random_bg=True, N_samples=12),              # inb_renderer.py:72: the flag becomes render_weights' epsilon (= 1)
+                                  dict(aggr='mean', N_samples=16),                 # inb_part_network_multiassign.py:236-239
+                                  dict(aggr='mean', smpl_thresh=0.1, N_samples=12)])
 def test_render_config_variants_vs_oracle(small_setup, over):
     """Hot-path flags other than the inb_377 defaults, against the (reference-pinned) oracle."""
     from invr.config import make_cfg
