@@ -23,7 +23,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with these extra
                   whether they were measured on the kernel sources this line ran)
   roofline_other— the KNN (VALU-issue bound, no roofline fraction) and the encoder (measured bytes primary, the byte model secondary)
   path_roofline — the WHOLE frame: measured HBM / Infinity-Cache bytes per frame primary, SURVEY §8d's byte model labelled secondary
-  shard_projection, samples_64, mid_density, full_rows, dense_stress, api_frame — variants of the headline frames (N=1 only): rank 0's
+  shard_projection, samples_64, mid_density, aggr_mean, full_rows, dense_stress, api_frame — variants of the headline frames (N=1 only): rank 0's
                   shard of a W-way split (W = 1, 2, 4, 8) on this one GPU with the headline's frames in flight and with one frame at a
                   time, the yaml-default 64 samples/ray, smpl_thresh 0.1 (3x the survivors), the 64-byte-row encoder, the dense
                   stress frame (every sample survives), and the wall clock of Renderer.render(batch) with and without the reference's
@@ -295,6 +295,16 @@ def variant_lines(net, cfg, batches, dev, S, in_flight=1):
     out['mid_density'] = {'ms_per_frame': ms, 'ray_samples_per_sec': mean_rays * S / (ms * 1e-3), 'smpl_thresh': 0.1,
                           'active_fraction': float(sum(int(s[0]) for s in st)) / (mean_rays * S * len(st)),
                           'pairs_per_active_sample': float(sum(int(s[1:6].sum()) for s in st)) / max(1, sum(int(s[0]) for s in st))}
+    # (3b) cfg.aggr = 'mean' (inb_part_network_multiassign.py:236-239): every listed pair needs its colour, not only each survivor's winner
+    acfg = copy.deepcopy(cfg)
+    acfg['aggr'] = 'mean'
+    net.cfg = acfg
+    try:
+        ms, _ = frames_ms(S, 12)
+    finally:
+        net.cfg = cfg
+    out['aggr_mean'] = {'ms_per_frame': ms, 'ray_samples_per_sec': mean_rays * S / (ms * 1e-3),
+                        'note': 'the mean merge: k_part_rgb_all over all listed pairs (about twice the winners) + k_winner_lists<MEAN>'}
     # (4) the 64-byte trainable rows (what a training-mode forward reads) instead of the derived row-sum tables
     old = cfg.get('eval_row_sums', True)
     cfg['eval_row_sums'] = False

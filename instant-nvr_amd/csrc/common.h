@@ -5,6 +5,11 @@
 #include "../../include/invr.h"
 
 #define INVR_WAVE 64
+// The wave scans (wave_incl_sum_i, wave_or_u32, k_composite.hip's products) use the GFX9 DPP controls wave_shr:1 / row_bcast:15 / row_bcast:31
+// and 64-lane waves with every lane active; the MFMA / LDS tilings assume CDNA4.  There is no other target and no fallback path.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libinvr is written for gfx950 (MI355X) only: build with --offload-arch=gfx950"
+#endif
 #define HASH_P1 19349663ull
 #define HASH_P2 83492791ull
 

@@ -58,7 +58,9 @@ GridDev make_grid_dev(const InvrGrid* g) {
             d.mod24 = d.mod32 && c < (1u << 24) && ((1ull << 41) >> k) < (1ull << 24) && (y1 >> k) < (1ull << 24) && (y2 >> k) < (1ull << 24);
             // x-corner delta fold (k_encode.hip:level_rowsum): resolutions are <= 8192, so |delta| < 2^13 < T / 2; its c0x corners take
             // the TWO-round reduction (common.h:hash_mod24_2r), valid when the second fold already lands below 2^k (h2 = 0)
-            d.xdelta = d.mod24 && d.T > (1ll << 14) && y2 < (1ull << k);
+            int64_t max_res = 0;
+            for (int l = 0; l < g->n_levels && l < INVR_MAX_LEVELS; ++l) max_res = g->res[l] > max_res ? g->res[l] : max_res;
+            d.xdelta = d.mod24 && d.T > (1ll << 14) && y2 < (1ull << k) && 2 * max_res <= d.T;      // (one +/- T fix-up: |delta| < 2 res <= T)
         }
     }
     for (int l = 0; l < INVR_MAX_LEVELS; ++l) {

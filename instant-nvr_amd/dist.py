@@ -52,7 +52,7 @@ def gather_plan(n_rays, world, tile, device):
 def gather_maps(local_rgba, n_rays, rank, world, tile=DEFAULT_TILE, group=None):
     """All-gather the per-rank [r,g,b,acc] rows (n_local,4) into the full (n_rays,4) map:
     one padded all_gather_into_tensor + one index_select."""
-    if world == 1 and not FORCE_COLLECTIVES():
+    if world == 1 and not (FORCE_COLLECTIVES() and dist.is_initialized()):
         return local_rgba
     dev = local_rgba.device
     mx, src = gather_plan(n_rays, world, tile, dev)
@@ -88,12 +88,12 @@ def gather_maps_async(local_rgba, n_rays, rank, world, tile=DEFAULT_TILE, group=
     """gather_maps with the collective left in flight: the caller renders the next frame beside it and calls `.result()` when it needs
     the full map (a frame server keeps one gather pending: the 4 MB exchange of frame f overlaps the kernels of frame f+1).  The send
     buffer is kept alive by the returned object."""
-    if world == 1 and not FORCE_COLLECTIVES():
+    if world == 1 and not (FORCE_COLLECTIVES() and dist.is_initialized()):
         return PendingFrame(None, local_rgba, None, None)
     dev = local_rgba.device
     mx, src = gather_plan(n_rays, world, tile, dev)
     if local_rgba.shape[0] == mx:
-        send = local_rgba.contiguous()
+        send = local_rgba.clone()              # a private buffer: the caller may overwrite its rows (a graph's output) before result()
     else:
         send = torch.zeros(mx, 4, device=dev, dtype=local_rgba.dtype)
         send[:local_rgba.shape[0]] = local_rgba
