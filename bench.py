@@ -715,7 +715,7 @@ def main():
                 'pairs_per_part': [int(v) for v in stats_all[1:6]],
                 'pairs_per_active_sample': float(stats_all[1:6].sum()) / max(int(stats_all[0]), 1),
                 'colour_mlp_pairs_per_part_rank0': winners,
-                'parameters': int(n_params), 'raw_occ_materialised': want_raw, 'hip_graph': use_graph, 'frames_in_flight': K,
+                'parameters': int(n_params), 'raw_occ_materialised': want_raw, 'occ_is_raw_channel_3_view': True, 'hip_graph': use_graph, 'frames_in_flight': K,
                 'frames': '%d frames of a synthetic sequence (same body, %d poses / orientations / latent codes; frame 0 = the frame of the '
                           'round-1..3 lines) rendered side by side by ONE hipGraph replay (parallel branches, invr.frames.FrameSet); a step is '
                           'one frame, every frame does all of its per-frame scene work' % (K, K),

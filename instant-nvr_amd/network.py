@@ -337,7 +337,6 @@ class Network(nn.Module):
                'stats': (torch.empty if n else torch.zeros)(_abi.STATS_LEN, dtype=torch.int32, device=dev)}
         if want_raw:
             out['raw'] = torch.empty(n * S, 4, device=dev)
-            out['occ'] = torch.empty(n * S, device=dev)
         if want_weights:
             out['weights'] = torch.empty(n, S, device=dev)
             out['z_vals'] = torch.empty(n, S, device=dev)
@@ -348,9 +347,12 @@ class Network(nn.Module):
         _abi.check(L.invr_render_fwd(
             C.byref(scene), C.byref(model), _abi.ptr(ray_o), _abi.ptr(ray_d), _abi.ptr(near), _abi.ptr(far),
             _abi.ptr(jitter), n, S, _abi.ptr(out['rgb_map']), _abi.ptr(out['acc_map']),
-            _abi.ptr(out.get('raw')), _abi.ptr(out.get('occ')), _abi.ptr(out.get('weights')),
+            _abi.ptr(out.get('raw')), _abi.ptr(None), _abi.ptr(out.get('weights')),
             _abi.ptr(out.get('z_vals')), _abi.ptr(out['stats'], torch.int32),
             C.c_void_p(ws.data_ptr()), nbytes, max_active, _abi.stream_ptr()))
+        if want_raw:
+            out['occ'] = out['raw'][:, 3]          # occ IS raw's fourth channel (inb_part_network_multiassign.py:229-256 returns both from the
+                                                   # same rows): a view, not a second 4 B / sample write of the compositing kernel
         out['_keep'] = keep
         out['_ws'] = (ws, n, S, max_active)
         return out
