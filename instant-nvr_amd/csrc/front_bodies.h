@@ -57,10 +57,27 @@ __device__ __forceinline__ void cull_cells_body(const VolDev& v, float thresh_hi
 
 // distance channel of the pose-space volume at (px,py,pz): sample_volume_dev<1> (same arithmetic, bit for bit)
 // with the cell-mask early-out; returns +inf for samples in masked-out cells (they fail pn < thresh either way)
-template <typename IDX>        // IDX = uint32_t when dx*dy*dz*c < 2^31 (host-checked): 64-bit index multiplies are quarter rate
-__device__ __forceinline__ float cull_distance(const VolDev& v, const uint8_t* __restrict__ mask, float px, float py, float pz, const float* rext) {
-    const float b0x = v.bounds[0], b0y = v.bounds[1], b0z = v.bounds[2];
-    const float b1x = v.bounds[3], b1y = v.bounds[4], b1z = v.bounds[5];
+// PRE (the frame path): a sample whose cell is masked out — 92 % of the bench frame's — leaves before the three exact quotients.  Its
+// cell comes from ONE multiply per axis by pre[c] = RN(1 / extent) x (d - 1): within 3e-7 x d of the exact lattice coordinate
+// (the exact form rounds five times, this one three), so unless the coordinate lies within CULL_PRE_DELTA of a lattice plane (or was
+// clamped: fraction 0) the cell IS the exact path's cell and a clear mask byte rejects the sample as the exact path would; the
+// others (~1.2 %) and every sample of a live cell take the exact path below.  Results are identical by construction.
+#define CULL_PRE_DELTA 2e-3f            // >> 3e-7 x 1024 (the host admits d <= 1024 per axis for PRE)
+template <typename IDX, bool PRE>        // IDX = uint32_t when dx*dy*dz*c < 2^31 (host-checked): 64-bit index multiplies are quarter rate
+__device__ __forceinline__ float cull_distance(const VolDev& v, const uint8_t* __restrict__ mask, float px, float py, float pz, const float* rext,
+                                               const float* pre, const float* bnd) {
+    const float b0x = bnd[0], b0y = bnd[1], b0z = bnd[2];          // v.bounds, read once per thread by the caller
+    const float b1x = bnd[3], b1y = bnd[4], b1z = bnd[5];
+    if (PRE) {
+        const float ax = fminf(fmaxf((px - b0x) * pre[0], 0.0f), (float)(v.dx - 1));        // (NaN -> 0 -> fraction 0 -> exact path)
+        const float ay = fminf(fmaxf((py - b0y) * pre[1], 0.0f), (float)(v.dy - 1));
+        const float az = fminf(fmaxf((pz - b0z) * pre[2], 0.0f), (float)(v.dz - 1));
+        const float cx = floorf(ax), cy = floorf(ay), cz = floorf(az);
+        const bool sure = fabsf((ax - cx) - 0.5f) < 0.5f - CULL_PRE_DELTA && fabsf((ay - cy) - 0.5f) < 0.5f - CULL_PRE_DELTA &&
+                          fabsf((az - cz) - 0.5f) < 0.5f - CULL_PRE_DELTA;
+        const float cell = fmaf(fmaf(cx, (float)v.dy, cy), (float)v.dz, cz);               // exact: cells <= CULL_MASK_MAX = 2^22
+        if (sure && !mask[(IDX)(int)cell]) return __builtin_inff();
+    }
     // (p - b0) / (b1 - b0): the IEEE quotients through the per-thread reciprocals of the three extents (common.h:div_exact)
     float gx = div_exact(px - b0x, b1x - b0x, rext[0]) * 2.0f - 1.0f;
     float gy = div_exact(py - b0y, b1y - b0y, rext[1]) * 2.0f - 1.0f;
@@ -95,12 +112,28 @@ template <bool MASKED, bool FAST>
 __device__ __forceinline__ void cull_flag_body(const RenderArgs& a, const Workspace& w, double inv_S, float lin_step, const int64_t tile) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     __shared__ int cnt[CULL_PER * (CULL_BLOCK / 64)];
-    float rext[3] = {0.f, 0.f, 0.f};
+    float rext[3] = {0.f, 0.f, 0.f}, pre[3] = {0.f, 0.f, 0.f}, bnd[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    constexpr bool PRE = MASKED && FAST;
     if (MASKED) {
         const float* pb = a.scene.pbw.bounds;
+        const int dd[3] = {a.scene.pbw.dx, a.scene.pbw.dy, a.scene.pbw.dz};
 #pragma unroll
-        for (int c = 0; c < 3; ++c) rext[c] = rcp_for_div(pb[3 + c] - pb[c]);
+        for (int c = 0; c < 6; ++c) bnd[c] = pb[c];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            rext[c] = rcp_for_div(bnd[3 + c] - bnd[c]);
+            pre[c] = rext[c] * (float)(dd[c] - 1);             // (rext = 0: the pre-test never decides)
+        }
     }
+    float R[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, Th[3] = {0.f, 0.f, 0.f};
+    if (FAST) {          // read before the first store of the kernel: scalar loads, SGPR-resident for all CULL_PER samples
+#pragma unroll
+        for (int c = 0; c < 9; ++c) R[c] = a.scene.R[c];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Th[c] = a.scene.Th[c];
+    }
+    unsigned f_ray = 0u, f_s = 0u;
+    const unsigned blk_q = FAST ? (unsigned)CULL_BLOCK / (unsigned)a.S : 0u, blk_r = FAST ? (unsigned)CULL_BLOCK % (unsigned)a.S : 0u;   // (scalar unit)
 #pragma unroll
     for (int k = 0; k < CULL_PER; ++k) {
         const int64_t i = tile * CULL_TILE + k * CULL_BLOCK + threadIdx.x;
@@ -108,18 +141,24 @@ __device__ __forceinline__ void cull_flag_body(const RenderArgs& a, const Worksp
         if (i < a.N) {
             float px, py, pz, z;
             if (FAST) {
-                const unsigned iu = (unsigned)i, S = (unsigned)a.S;
-                unsigned ray = (unsigned)((double)iu * inv_S);            // floor(i / S), possibly one too small
-                unsigned s = iu - ray * S;
-                if (s >= S) { ++ray; s -= S; }
+                const unsigned S = (unsigned)a.S;
+                if (k == 0) {
+                    const unsigned iu = (unsigned)i;
+                    f_ray = (unsigned)((double)iu * inv_S);               // floor(i / S), possibly one too small
+                    f_s = iu - f_ray * S;
+                    if (f_s >= S) { ++f_ray; f_s -= S; }
+                } else {                                                  // sample i + CULL_BLOCK: (ray, s) advance by a wave-uniform step
+                    f_ray += blk_q; f_s += blk_r;
+                    if (f_s >= S) { ++f_ray; f_s -= S; }
+                }
+                const unsigned ray = f_ray, s = f_s;
                 const float near = a.near[ray], far = a.far[ray];
                 const float t = ((int)s < a.S / 2) ? lin_step * (float)(int)s : 1.0f - lin_step * (float)(a.S - 1 - (int)s);   // linspace01
                 z = near * (1.0f - t) + far * t;                          // sample_z
-                const unsigned r3 = ray * 3u;
-                const float dx = a.ray_d[r3], dy = a.ray_d[r3 + 1], dz = a.ray_d[r3 + 2];
-                const float wx = a.ray_o[r3] + dx * z, wy = a.ray_o[r3 + 1] + dy * z, wz = a.ray_o[r3 + 2] + dz * z;   // pts = o + d*z
-                const float* R = a.scene.R;
-                const float* Th = a.scene.Th;
+                const float* __restrict__ rd = a.ray_d + (size_t)ray * 3u;        // (one address + immediate offsets per array)
+                const float* __restrict__ ro = a.ray_o + (size_t)ray * 3u;
+                const float dx = rd[0], dy = rd[1], dz = rd[2];
+                const float wx = ro[0] + dx * z, wy = ro[1] + dy * z, wz = ro[2] + dz * z;   // pts = o + d*z
                 const float qx = wx - Th[0], qy = wy - Th[1], qz = wz - Th[2];                                         // (p - Th) @ R
                 px = qx * R[0] + qy * R[3] + qz * R[6];
                 py = qx * R[1] + qy * R[4] + qz * R[7];
@@ -129,7 +168,8 @@ __device__ __forceinline__ void cull_flag_body(const RenderArgs& a, const Worksp
             }
             if (a.z_vals) a.z_vals[i] = z;
             float pn;
-            if (MASKED) pn = FAST ? cull_distance<uint32_t>(a.scene.pbw, w.cullmask, px, py, pz, rext) : cull_distance<int64_t>(a.scene.pbw, w.cullmask, px, py, pz, rext);
+            if (MASKED) pn = FAST ? cull_distance<uint32_t, PRE>(a.scene.pbw, w.cullmask, px, py, pz, rext, pre, bnd)
+                                  : cull_distance<int64_t, false>(a.scene.pbw, w.cullmask, px, py, pz, rext, pre, bnd);
             else sample_volume_dev<1>(a.scene.pbw, a.scene.pbw.c - 1, px, py, pz, &pn);   // distance channel
             keep = pn < a.scene.thresh;                                               // :135
         }

@@ -192,7 +192,8 @@ int launch_cull(const RenderArgs& a, const Workspace& w, int64_t max_active, boo
     const float lin_step = 1.0f / (float)(a.S - 1);                // linspace01's step, the same IEEE division
     if (flags_done) {
     } else if (have_cells && a.N >= 4 * cells) {        // the mask pays for itself on full frames only
-        const bool fast = !a.wpts && !a.jitter && a.N < (1ll << 31) && cells * v.c < (1ll << 31) && a.S >= 2;
+        const bool fast = !a.wpts && !a.jitter && a.N < (1ll << 31) && cells * v.c < (1ll << 31) && a.S >= 2 &&
+                      v.dx <= 1024 && v.dy <= 1024 && v.dz <= 1024;      // (front_bodies.h: the pre-test's error bound)
         if (fast) hipLaunchKernelGGL((k_cull_flag<true, true>), dim3((unsigned)nb), dim3(CULL_BLOCK), 0, st, a, w, inv_S, lin_step);
         else hipLaunchKernelGGL((k_cull_flag<true, false>), dim3((unsigned)nb), dim3(CULL_BLOCK), 0, st, a, w, inv_S, lin_step);
     } else {

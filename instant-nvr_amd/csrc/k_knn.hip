@@ -1123,7 +1123,8 @@ int launch_front_cull(const RenderArgs& a, const Workspace& w, int* done, hipStr
     const unsigned gx = voxel_class_grid(v);
     const double inv_S = 1.0 / (double)a.S;
     const float lin_step = 1.0f / (float)(a.S - 1);
-    const bool fast = !a.wpts && !a.jitter && a.N < (1ll << 31) && cells * v.c < (1ll << 31) && a.S >= 2;
+    const bool fast = !a.wpts && !a.jitter && a.N < (1ll << 31) && cells * v.c < (1ll << 31) && a.S >= 2 &&
+                      v.dx <= 1024 && v.dy <= 1024 && v.dz <= 1024;      // (front_bodies.h: the pre-test's error bound)
     const unsigned grid = gx * INVR_NUM_PARTS + (unsigned)nb;
     if (fast) hipLaunchKernelGGL((k_front_cull<true>), dim3(grid), dim3(CULL_BLOCK), 0, st, a, w, inv_S, lin_step, (int)gx);
     else hipLaunchKernelGGL((k_front_cull<false>), dim3(grid), dim3(CULL_BLOCK), 0, st, a, w, inv_S, lin_step, (int)gx);

@@ -81,6 +81,29 @@ def ulp_diff(a, b):
     return (a.view(torch.int32).long() - b.view(torch.int32).long()).abs()
 
 
+def test_cull_survivor_set_exact_whole_frame(fr):
+    """The near-surface cull of the frame path (k_front_cull: cell mask + the one-multiply pre-test, csrc/front_bodies.h) keeps EXACTLY
+    the samples whose pose-space distance — the dense stage kernels, the reference's arithmetic bit for bit (inb_renderer.py:15-31 +
+    blend_utils.py sample of the distance channel, :135's `pnorm < smpl_thresh`) — is below the threshold: every ray-sample of the
+    frame, no sample more, none less."""
+    from invr.autograd import sample_volume
+    f = fr
+    gb, thresh = f['gb'], f['thresh']
+    ro, rd, nr, fa = (gb[k_][0] for k_ in ('ray_o', 'ray_d', 'near', 'far'))
+    n = ro.shape[0]
+    vol, bounds = gb['pbw'][0].contiguous(), gb['pbounds'][0].contiguous()
+    keep = torch.zeros(n * S, dtype=torch.bool, device=ro.device)
+    step = max(1, (1 << 22) // S)                                          # rays per slab (4 M samples)
+    for r0 in range(0, n, step):
+        r1 = min(n, r0 + step)
+        pts, _ = stages.pose_points(f['ctx'].scene, ro[r0:r1], rd[r0:r1], nr[r0:r1], fa[r0:r1], S, want_dirs=False)
+        pn = sample_volume(vol, bounds, pts, vol.shape[3] - 1, 1)[:, 0]
+        keep[r0 * S:r1 * S] = pn < thresh
+    want = keep.nonzero(as_tuple=True)[0]
+    got = f['act'].long().sort()[0]
+    assert want.numel() == f['Na'] and torch.equal(got, want), (want.numel(), f['Na'])
+
+
 def test_knn_pairs_vs_brute_force_whole_frame(fr):
     f, k = fr, fr['k']
     v, st, Na, thresh = f['v'], f['st'], f['Na'], f['thresh']
