@@ -7,7 +7,7 @@ Renderer-level code through libinvr.so with the full-size inb_377 model (285,993
 Inputs (rays, scene tensors, parameters) are resident in HBM before the timed region; the step ends
 with rgb_map/acc_map (and the reference's raw/occ outputs) in HBM.
 
-Frames in flight: the timed frames are K (--in-flight, default 4; a divisor of --steps) frames of a synthetic sequence — the same body
+Frames in flight: the timed frames are K (--in-flight, default 10; a divisor of --steps) frames of a synthetic sequence — the same body
 in K poses — rendered side by side by ONE hipGraph replay (invr.frames.FrameSet: K parallel branches of one captured graph).  A step is
 one frame; every frame does all of its per-frame work.
 
@@ -509,7 +509,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--train-iters', type=int, default=10, help='iterations of the informational training-step probe (0 = skip; N=1 only)')
     ap.add_argument('--no-graph', action='store_true', help='launch the ~25 kernels of a frame eagerly instead of replaying one captured hipGraph')
-    ap.add_argument('--in-flight', type=int, default=4, help='frames of the sequence rendered side by side by one hipGraph replay (invr.frames); reduced to a divisor of --steps; 1 = strictly one frame at a time')
+    ap.add_argument('--in-flight', type=int, default=10, help='frames of the sequence rendered side by side by one hipGraph replay (invr.frames); reduced to a divisor of --steps; 1 = strictly one frame at a time')
     ap.add_argument('--no-variants', action='store_true', help='skip the S=64 / dense / full-row / shard-projection / API-frame variants of the default line')
     ap.add_argument('--shard-of', type=int, default=0, help='debug (1 GPU): render only rank 0\'s ray shard of a W-way split')
     args = ap.parse_args()
@@ -797,7 +797,8 @@ def main():
                 torch.cuda.empty_cache()
                 line['api_train_step'] = train_probe(net, dev, S, args.train_iters, fused=False)
                 line['api_train_step']['note'] = ('NetworkWrapper + the reference\'s own optimizer construction (torch.optim.Adam, 186 one-tensor '
-                                                  'groups) + its step form: the drop-in training call; train_step = the same with driver.make_optimizer (FusedAdam)')
+                                                  'groups) + its step form: the drop-in training call; train_step = the same with driver.make_optimizer (FusedAdam) — what one added line, '
+                                                  '`optimizer = invr.optim.fuse(optimizer, network)` after the reference\'s make_optimizer, turns the first into')
             except Exception as e:
                 line['api_train_step'] = {'error': repr(e)}
         if world == 1 and not args.no_cpu_baseline:

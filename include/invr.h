@@ -342,9 +342,10 @@ int32_t invr_adam_chunk_elems(void);
 /* step += 1 and bc1 / bc2_sqrt = 1 - beta1^step / sqrt(1 - beta2^step) (in double, as torch's host code) for the n entries of a
  * DEVICE tensor table: a training loop uploads the table once and replays {invr_adam_advance, invr_adam_step} every iteration
  * without touching the host (torch.optim.Adam computes the corrections on the host per step and per group). */
-int invr_adam_advance(InvrAdamTensor* tensors, int32_t n, float beta1, float beta2, void* stream);
+int invr_adam_advance(InvrAdamTensor* tensors, int32_t n, double beta1, double beta2, void* stream);
 int invr_adam_step(const InvrAdamTensor* tensors, const int32_t* chunk_tensor, const int32_t* chunk_index,
-                   int64_t n_chunks, float beta1, float beta2, float eps, void* stream);
+                   int64_t n_chunks, double beta1, double beta2, float eps, void* stream);
+/* (the betas are doubles: torch forms 1 - beta in double before the update runs in float — 1 - 0.999f is 1.3e-5 off 0.001) */
 
 /* batch_rodrigues + get_rigid_transformation (lib/utils/if_nerf/if_nerf_data_utils.py:523-577): DEVICE inputs
  * poses (24,3) float64 axis-angle, joints (24,3) float64, parents (24) int32 -> DEVICE A (24,4,4) float32. */

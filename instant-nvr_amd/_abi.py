@@ -125,7 +125,7 @@ def lib():
         L.invr_grid_encode_fwd.argtypes = [C.POINTER(InvrGrid), vp, C.c_int64, vp, vp]
         L.invr_sample_volume.argtypes = [vp, C.c_int32 * 3, C.c_int32, C.c_int32, C.c_int32, vp, vp, C.c_int64, vp, vp]
         L.invr_knn_blend.argtypes = [C.POINTER(InvrScene), vp, C.c_int64, vp, vp, vp]
-        L.invr_adam_advance.argtypes = [vp, C.c_int32, C.c_float, C.c_float, vp]
+        L.invr_adam_advance.argtypes = [vp, C.c_int32, C.c_double, C.c_double, vp]
         L.invr_adam_advance.restype = C.c_int
         L.invr_train_workspace_bytes.restype = C.c_size_t
         L.invr_train_workspace_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int64]
@@ -169,7 +169,7 @@ def lib():
         L.invr_part_mlp_bwd.argtypes = [C.POINTER(InvrModel), C.c_int32, vp, vp, vp, C.c_int64, vp, C.POINTER(InvrMlpBwdOut), vp]
         L.invr_part_mlp_bwd.restype = C.c_int
         L.invr_adam_chunk_elems.restype = C.c_int32
-        L.invr_adam_step.argtypes = [vp, vp, vp, C.c_int64, C.c_float, C.c_float, C.c_float, vp]
+        L.invr_adam_step.argtypes = [vp, vp, vp, C.c_int64, C.c_double, C.c_double, C.c_float, vp]
         L.invr_adam_step.restype = C.c_int
         L.invr_rigid_transformation.argtypes = [vp, vp, vp, vp, vp]
         L.invr_rigid_transformation.restype = C.c_int

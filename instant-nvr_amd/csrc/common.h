@@ -365,8 +365,8 @@ int launch_deform_points(const SceneDev& s, const GridDev& dg, const MlpDev& dm,
 int launch_distortion(const float* weights, const float* z, int64_t n_rays, int S, float* out, hipStream_t st);
 int launch_generate_rays(const double* kinv, const double* r, const double* t, const double* o, const float* bounds,
                          int H, int W, float* ray_d, float* near, float* far, uint8_t* mask, hipStream_t st);
-int launch_adam_advance(void* tensors, int n, float b1, float b2, hipStream_t st);
-int launch_adam(const void* tensors, const int32_t* chunk_tensor, const int32_t* chunk_index, int64_t n_chunks, float b1, float b2,
+int launch_adam_advance(void* tensors, int n, double b1, double b2, hipStream_t st);
+int launch_adam(const void* tensors, const int32_t* chunk_tensor, const int32_t* chunk_index, int64_t n_chunks, double b1, double b2,
                 float eps, hipStream_t st);
 int launch_row_sums(const GridDev& g, float* out, hipStream_t st);
 int launch_rigid_transformation(const double* poses, const double* joints, const int32_t* parents, float* A, hipStream_t st);

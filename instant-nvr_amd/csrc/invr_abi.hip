@@ -623,13 +623,13 @@ extern "C" int invr_grid_row_sums(const InvrGrid* grid, float* out, void* stream
 
 extern "C" int32_t invr_adam_chunk_elems(void) { return 16384; }
 
-extern "C" int invr_adam_advance(InvrAdamTensor* tensors, int32_t n, float beta1, float beta2, void* stream) {
+extern "C" int invr_adam_advance(InvrAdamTensor* tensors, int32_t n, double beta1, double beta2, void* stream) {
     INVR_CHECK(n == 0 || tensors, "invr_adam_advance: null pointer");
     return launch_adam_advance(tensors, n, beta1, beta2, (hipStream_t)stream);
 }
 
 extern "C" int invr_adam_step(const InvrAdamTensor* tensors, const int32_t* chunk_tensor, const int32_t* chunk_index,
-                              int64_t n_chunks, float beta1, float beta2, float eps, void* stream) {
+                              int64_t n_chunks, double beta1, double beta2, float eps, void* stream) {
     INVR_CHECK(n_chunks == 0 || (tensors && chunk_tensor && chunk_index), "invr_adam_step: null pointer");
     INVR_CHECK(n_chunks >= 0 && n_chunks < (1ll << 31), "invr_adam_step: bad chunk count");
     return launch_adam(tensors, chunk_tensor, chunk_index, n_chunks, beta1, beta2, eps, (hipStream_t)stream);

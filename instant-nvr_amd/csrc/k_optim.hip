@@ -35,12 +35,12 @@ __global__ void k_adam_advance(AdamTensor* tensors, int n, double b1, double b2)
 }
 
 __global__ __launch_bounds__(ADAM_BLOCK) void k_adam(const AdamTensor* __restrict__ tensors, const int32_t* __restrict__ chunk_tensor,
-                                                     const int32_t* __restrict__ chunk_index, float b1, float b2, float eps) {
+                                                     const int32_t* __restrict__ chunk_index, float b1, float b2, float w1, float w2, float eps) {
     const AdamTensor t = tensors[chunk_tensor[blockIdx.x]];
     if (t.active && t.active[0] == 0.0f) return;
     const int64_t base = (int64_t)chunk_index[blockIdx.x] * ADAM_CHUNK;
     const int64_t end = min(base + ADAM_CHUNK, t.n);
-    const float w1 = 1.0f - b1, w2 = 1.0f - b2, step_size = t.lr / t.bc1;
+    const float step_size = t.lr / t.bc1;                         // (w1 = 1 - beta1, w2 = 1 - beta2: formed in double by the host)
     auto upd = [&](float& p, float g, float& m, float& v) {
         if (t.wd != 0.0f) g = fmaf(t.wd, p, g);
         m = m + w1 * (g - m);                                     // torch.lerp, weight < 0.5
@@ -80,18 +80,18 @@ __global__ __launch_bounds__(ADAM_BLOCK) void k_adam(const AdamTensor* __restric
 
 static_assert(sizeof(AdamTensor) == sizeof(InvrAdamTensor), "AdamTensor mirrors InvrAdamTensor");
 
-int launch_adam_advance(void* tensors, int n, float b1, float b2, hipStream_t st) {
+int launch_adam_advance(void* tensors, int n, double b1, double b2, hipStream_t st) {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(k_adam_advance, dim3((unsigned)cdiv(n, 64)), dim3(64), 0, st, reinterpret_cast<AdamTensor*>(tensors), n, (double)b1, (double)b2);
+    hipLaunchKernelGGL(k_adam_advance, dim3((unsigned)cdiv(n, 64)), dim3(64), 0, st, reinterpret_cast<AdamTensor*>(tensors), n, b1, b2);
     INVR_LAUNCH_CHECK();
     return 0;
 }
 
-int launch_adam(const void* tensors, const int32_t* chunk_tensor, const int32_t* chunk_index, int64_t n_chunks, float b1, float b2,
+int launch_adam(const void* tensors, const int32_t* chunk_tensor, const int32_t* chunk_index, int64_t n_chunks, double b1, double b2,
                 float eps, hipStream_t st) {
     if (n_chunks == 0) return 0;
     hipLaunchKernelGGL(k_adam, dim3((unsigned)n_chunks), dim3(ADAM_BLOCK), 0, st, reinterpret_cast<const AdamTensor*>(tensors), chunk_tensor,
-                       chunk_index, b1, b2, eps);
+                       chunk_index, (float)b1, (float)b2, (float)(1.0 - b1), (float)(1.0 - b2), eps);      // 1 - beta in double, as torch/optim/adam.py
     INVR_LAUNCH_CHECK();
     return 0;
 }

@@ -148,3 +148,36 @@ class FusedAdam(torch.optim.Optimizer):
         # the kernel wrote through raw pointers: tell autograd / version-keyed caches (Embedder.row_sums)
         torch.autograd.graph.increment_version(self._plan_params)
         return loss
+
+
+def fuse(optimizer, net=None):
+    """One line for a host that builds its optimiser the reference's way (lib/train/optimizer.py:13-31 -> torch.optim.Adam, one
+    group per tensor):  `optimizer = invr.optim.fuse(optimizer, network)`  after make_optimizer.  Returns a FusedAdam over the SAME
+    parameter groups (per-group lr / weight_decay, betas, eps) that continues from the optimiser's state (step counts, moments:
+    state_dict layouts are identical), attached to `net`'s fused training path when it has one.  Anything that is not a plain
+    torch.optim.Adam (amsgrad, maximize, capturable, a different class) is returned unchanged."""
+    if isinstance(optimizer, FusedAdam) or type(optimizer) is not torch.optim.Adam:
+        return optimizer
+    groups = optimizer.param_groups
+    if any(g.get('amsgrad') or g.get('maximize') or g.get('capturable') or g.get('differentiable') for g in groups):
+        return optimizer
+    if len({(tuple(g['betas']), g['eps']) for g in groups}) != 1:
+        return optimizer
+    try:                                        # (the binding's own checks: device tensors, float32, contiguous)
+        for g in groups:
+            for p in g['params']:
+                _abi.ptr(p)
+    except AssertionError:
+        return optimizer
+    d = optimizer.defaults
+    new = FusedAdam([{'params': list(g['params']), 'lr': g['lr'], 'weight_decay': g['weight_decay'], 'betas': g['betas'], 'eps': g['eps']}
+                     for g in groups], d['lr'], betas=d['betas'], eps=d['eps'], weight_decay=d['weight_decay'])
+    for g_new, g_old in zip(new.param_groups, groups):          # scheduler bookkeeping (initial_lr, ...) travels with the groups
+        for k, v in g_old.items():
+            if k != 'params' and k not in g_new:
+                g_new[k] = v
+    if optimizer.state:
+        new.load_state_dict(optimizer.state_dict())
+    if net is not None and hasattr(net, 'tpose_human') and getattr(net, 'cfg', {}).get('train_fused', True):
+        new.attach(net)
+    return new

@@ -879,8 +879,44 @@ def test_fused_adam_matches_torch_adam():
     for k in sa['state']:
         assert float(sa['state'][k]['step']) == float(sb['state'][k]['step'])
         assert maxerr(sa['state'][k]['exp_avg'], sb['state'][k]['exp_avg']) <= 1e-6 * float(sa['state'][k]['exp_avg'].abs().max()) + 1e-12
+        # (1 - beta2 is formed in double: 1 - 0.999f is 1.3e-5 off 0.001 — what this line caught)
+        assert maxerr(sa['state'][k]['exp_avg_sq'], sb['state'][k]['exp_avg_sq']) <= 1e-6 * float(sa['state'][k]['exp_avg_sq'].abs().max()) + 1e-12
     ref2 = torch.optim.Adam(mk([p.detach().clone().requires_grad_() for p in my_p]), 5e-4, eps=1e-15)
     ref2.load_state_dict(mine.state_dict())             # checkpoints interchange
+
+
+def test_fuse_continues_a_reference_built_adam():
+    """invr.optim.fuse: an Adam built the reference's way (lib/train/optimizer.py:13-31) that has already taken steps is replaced by
+    a FusedAdam over the same groups and state; both continue for three steps from the same gradients and must agree."""
+    from invr.optim import FusedAdam, fuse
+    g = torch.Generator().manual_seed(12)
+    shapes = [(3,), (64, 70), (5, 4099, 16), (33, 7)]
+    ref_p = [torch.randn(s, generator=g).to(DEV).requires_grad_() for s in shapes]
+    my_p = [p.detach().clone().requires_grad_() for p in ref_p]
+    mk = lambda ps: [{'params': [p], 'lr': 5e-4 * (1 + k), 'weight_decay': 0.0} for k, p in enumerate(ps)]
+    ref, mine = torch.optim.Adam(mk(ref_p), 5e-4, eps=1e-15), torch.optim.Adam(mk(my_p), 5e-4, eps=1e-15)
+    sched = torch.optim.lr_scheduler.ExponentialLR(mine, 0.9)             # (adds initial_lr to the groups)
+
+    def grads():
+        for a, b in zip(ref_p, my_p):
+            gr = torch.randn(a.shape, generator=g).to(DEV) * 0.1
+            a.grad, b.grad = gr.clone(), gr.clone()
+    for _ in range(2):
+        grads(); ref.step(); mine.step()
+    fused = fuse(mine)
+    assert isinstance(fused, FusedAdam) and fuse(fused) is fused
+    assert [grp['lr'] for grp in fused.param_groups] == [grp['lr'] for grp in mine.param_groups]
+    assert all('initial_lr' in grp for grp in fused.param_groups) and sched is not None
+    assert fuse(torch.optim.SGD(mk(my_p), 0.1)).__class__ is torch.optim.SGD                          # not an Adam: unchanged
+    assert fuse(torch.optim.Adam(mk(my_p), 5e-4, amsgrad=True)).__class__ is torch.optim.Adam         # unsupported variant: unchanged
+    for _ in range(3):
+        grads(); ref.step(); fused.step()
+    for a, b in zip(ref_p, my_p):
+        assert maxerr(a, b) <= 2e-6 * float(a.detach().abs().max()) + 1e-9
+    sa, sb = ref.state_dict(), fused.state_dict()
+    for k in sa['state']:
+        assert float(sa['state'][k]['step']) == float(sb['state'][k]['step']) == 5.0
+        assert maxerr(sa['state'][k]['exp_avg_sq'], sb['state'][k]['exp_avg_sq']) <= 1e-6 * float(sa['state'][k]['exp_avg_sq'].abs().max()) + 1e-12
 
 
 def test_part_mlp_hip_backward_vs_torch_autograd(gpu_setup):
