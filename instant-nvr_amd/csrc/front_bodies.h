@@ -57,27 +57,29 @@ __device__ __forceinline__ void cull_cells_body(const VolDev& v, float thresh_hi
 
 // distance channel of the pose-space volume at (px,py,pz): sample_volume_dev<1> (same arithmetic, bit for bit)
 // with the cell-mask early-out; returns +inf for samples in masked-out cells (they fail pn < thresh either way)
-// PRE (the frame path): a sample whose cell is masked out — 92 % of the bench frame's — leaves before the three exact quotients.  Its
-// cell comes from ONE multiply per axis by pre[c] = RN(1 / extent) x (d - 1): within 3e-7 x d of the exact lattice coordinate
-// (the exact form rounds five times, this one three), so unless the coordinate lies within CULL_PRE_DELTA of a lattice plane (or was
-// clamped: fraction 0) the cell IS the exact path's cell and a clear mask byte rejects the sample as the exact path would; the
-// others (~1.2 %) and every sample of a live cell take the exact path below.  Results are identical by construction.
-#define CULL_PRE_DELTA 2e-3f            // >> 3e-7 x 1024 (the host admits d <= 1024 per axis for PRE)
-template <typename IDX, bool PRE>        // IDX = uint32_t when dx*dy*dz*c < 2^31 (host-checked): 64-bit index multiplies are quarter rate
+// The frame path's pre-test: a sample whose cell is masked out — 92 % of the bench frame's — is recognised ahead of the three exact
+// quotients.  Its cell comes from ONE multiply per axis by pre[c] = RN(1 / extent) x (d - 1): within 3e-7 x d of the exact lattice
+// coordinate (the exact form rounds five times, this one three), so unless the coordinate lies within CULL_PRE_DELTA of a lattice plane
+// (or was clamped: fraction 0) the cell IS the exact path's cell and a clear mask byte rejects the sample as the exact path would; the
+// others (~1.2 %) and every sample of a live cell are CANDIDATES for the exact path.  -> true: certainly not a survivor.
+#define CULL_PRE_DELTA 2e-3f            // >> 3e-7 x 1024 (the host admits d <= 1024 per axis for the pre-test)
+__device__ __forceinline__ bool cull_pre_reject(const VolDev& v, const uint8_t* __restrict__ mask, float px, float py, float pz,
+                                                const float* pre, const float* bnd) {
+    const float ax = fminf(fmaxf((px - bnd[0]) * pre[0], 0.0f), (float)(v.dx - 1));        // (NaN -> 0 -> fraction 0 -> candidate)
+    const float ay = fminf(fmaxf((py - bnd[1]) * pre[1], 0.0f), (float)(v.dy - 1));
+    const float az = fminf(fmaxf((pz - bnd[2]) * pre[2], 0.0f), (float)(v.dz - 1));
+    const float cx = floorf(ax), cy = floorf(ay), cz = floorf(az);
+    const bool sure = fabsf((ax - cx) - 0.5f) < 0.5f - CULL_PRE_DELTA && fabsf((ay - cy) - 0.5f) < 0.5f - CULL_PRE_DELTA &&
+                      fabsf((az - cz) - 0.5f) < 0.5f - CULL_PRE_DELTA;
+    const float cell = fmaf(fmaf(cx, (float)v.dy, cy), (float)v.dz, cz);                   // exact: cells <= CULL_MASK_MAX = 2^22
+    return sure && !mask[(unsigned)(int)cell];
+}
+
+template <typename IDX>        // IDX = uint32_t when dx*dy*dz*c < 2^31 (host-checked): 64-bit index multiplies are quarter rate
 __device__ __forceinline__ float cull_distance(const VolDev& v, const uint8_t* __restrict__ mask, float px, float py, float pz, const float* rext,
-                                               const float* pre, const float* bnd) {
+                                               const float* bnd) {
     const float b0x = bnd[0], b0y = bnd[1], b0z = bnd[2];          // v.bounds, read once per thread by the caller
     const float b1x = bnd[3], b1y = bnd[4], b1z = bnd[5];
-    if (PRE) {
-        const float ax = fminf(fmaxf((px - b0x) * pre[0], 0.0f), (float)(v.dx - 1));        // (NaN -> 0 -> fraction 0 -> exact path)
-        const float ay = fminf(fmaxf((py - b0y) * pre[1], 0.0f), (float)(v.dy - 1));
-        const float az = fminf(fmaxf((pz - b0z) * pre[2], 0.0f), (float)(v.dz - 1));
-        const float cx = floorf(ax), cy = floorf(ay), cz = floorf(az);
-        const bool sure = fabsf((ax - cx) - 0.5f) < 0.5f - CULL_PRE_DELTA && fabsf((ay - cy) - 0.5f) < 0.5f - CULL_PRE_DELTA &&
-                          fabsf((az - cz) - 0.5f) < 0.5f - CULL_PRE_DELTA;
-        const float cell = fmaf(fmaf(cx, (float)v.dy, cy), (float)v.dz, cz);               // exact: cells <= CULL_MASK_MAX = 2^22
-        if (sure && !mask[(IDX)(int)cell]) return __builtin_inff();
-    }
     // (p - b0) / (b1 - b0): the IEEE quotients through the per-thread reciprocals of the three extents (common.h:div_exact)
     float gx = div_exact(px - b0x, b1x - b0x, rext[0]) * 2.0f - 1.0f;
     float gy = div_exact(py - b0y, b1y - b0y, rext[1]) * 2.0f - 1.0f;
@@ -132,8 +134,81 @@ __device__ __forceinline__ void cull_flag_body(const RenderArgs& a, const Worksp
 #pragma unroll
         for (int c = 0; c < 3; ++c) Th[c] = a.scene.Th[c];
     }
+    // FAST: pose-space point of sample s of ray `ray` — the op sequence of sample_pose_point / sample_z / linspace01, bit for bit
+    auto fast_point = [&](unsigned ray, unsigned s, float& px, float& py, float& pz, float& z) {
+        const float near = a.near[ray], far = a.far[ray];
+        const float t = ((int)s < a.S / 2) ? lin_step * (float)(int)s : 1.0f - lin_step * (float)(a.S - 1 - (int)s);   // linspace01
+        z = near * (1.0f - t) + far * t;                          // sample_z
+        const float* __restrict__ rd = a.ray_d + (size_t)ray * 3u;        // (one address + immediate offsets per array)
+        const float* __restrict__ ro = a.ray_o + (size_t)ray * 3u;
+        const float dx = rd[0], dy = rd[1], dz = rd[2];
+        const float wx = ro[0] + dx * z, wy = ro[1] + dy * z, wz = ro[2] + dz * z;   // pts = o + d*z
+        const float qx = wx - Th[0], qy = wy - Th[1], qz = wz - Th[2];                                         // (p - Th) @ R
+        px = qx * R[0] + qy * R[3] + qz * R[6];
+        py = qx * R[1] + qy * R[4] + qz * R[7];
+        pz = qx * R[2] + qy * R[5] + qz * R[8];
+    };
+    auto ray_of = [&](unsigned iu, unsigned& ray, unsigned& s) {
+        const unsigned S = (unsigned)a.S;
+        ray = (unsigned)((double)iu * inv_S);                     // floor(i / S), possibly one too small
+        s = iu - ray * S;
+        if (s >= S) { ++ray; s -= S; }
+    };
     unsigned f_ray = 0u, f_s = 0u;
     const unsigned blk_q = FAST ? (unsigned)CULL_BLOCK / (unsigned)a.S : 0u, blk_r = FAST ? (unsigned)CULL_BLOCK % (unsigned)a.S : 0u;   // (scalar unit)
+    if (PRE) {
+        // Two phases.  A wave holds 64 consecutive samples of a ray: if one of them needs the exact path (three exact quotients, 8
+        // taps) the whole wave walks it — with the exact path inside the sample loop nearly every wave of a frame that shows the body
+        // paid it four times.  So: (1) every sample: point + pre-test, the candidates (8 % + the ambiguous 1 %) appended to a list of the
+        // workgroup; (2) the list, densely: one lane per candidate, its survivor bit ORed into the tile's 16 mask words in LDS.
+        __shared__ unsigned long long s_mask[CULL_TILE / 64];
+        __shared__ unsigned short s_cand[CULL_TILE];
+        __shared__ int s_ncand;
+        if (threadIdx.x < CULL_TILE / 64) s_mask[threadIdx.x] = 0ull;
+        if (threadIdx.x == 0) s_ncand = 0;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < CULL_PER; ++k) {
+            const int64_t i = tile * CULL_TILE + k * CULL_BLOCK + threadIdx.x;
+            bool cand = false;
+            if (i < a.N) {
+                if (k == 0) ray_of((unsigned)i, f_ray, f_s);
+                else {                                                    // sample i + CULL_BLOCK: (ray, s) advance by a wave-uniform step
+                    f_ray += blk_q; f_s += blk_r;
+                    if (f_s >= (unsigned)a.S) { ++f_ray; f_s -= (unsigned)a.S; }
+                }
+                float px, py, pz, z;
+                fast_point(f_ray, f_s, px, py, pz, z);
+                if (a.z_vals) a.z_vals[i] = z;
+                cand = !cull_pre_reject(a.scene.pbw, w.cullmask, px, py, pz, pre, bnd);
+            }
+            const unsigned long long m = __ballot(cand);
+            if (m) {
+                const int first = __ffsll((long long)m) - 1;
+                int base = 0;
+                if (lane == first) base = atomicAdd(&s_ncand, __popcll(m));
+                base = __shfl(base, first);
+                if (cand) s_cand[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)(k * CULL_BLOCK + threadIdx.x);
+            }
+        }
+        __syncthreads();
+        const int n_cand = s_ncand;
+        for (int c = threadIdx.x; c < n_cand; c += CULL_BLOCK) {
+            const unsigned loc = s_cand[c];
+            unsigned ray, sm;
+            ray_of((unsigned)(tile * CULL_TILE) + loc, ray, sm);
+            float px, py, pz, z;
+            fast_point(ray, sm, px, py, pz, z);
+            const float pn = cull_distance<uint32_t>(a.scene.pbw, w.cullmask, px, py, pz, rext, bnd);
+            if (pn < a.scene.thresh) atomicOr(&s_mask[loc >> 6], 1ull << (loc & 63u));               // :135
+        }
+        __syncthreads();
+        if (threadIdx.x < CULL_TILE / 64) {
+            const unsigned long long m = s_mask[threadIdx.x];
+            w.mask[tile * (CULL_TILE / 64) + threadIdx.x] = m;            // word k * 4 + wave: the lanes of that wave's k-th sample
+            cnt[threadIdx.x] = __popcll(m);
+        }
+    } else {
 #pragma unroll
     for (int k = 0; k < CULL_PER; ++k) {
         const int64_t i = tile * CULL_TILE + k * CULL_BLOCK + threadIdx.x;
@@ -141,35 +216,19 @@ __device__ __forceinline__ void cull_flag_body(const RenderArgs& a, const Worksp
         if (i < a.N) {
             float px, py, pz, z;
             if (FAST) {
-                const unsigned S = (unsigned)a.S;
-                if (k == 0) {
-                    const unsigned iu = (unsigned)i;
-                    f_ray = (unsigned)((double)iu * inv_S);               // floor(i / S), possibly one too small
-                    f_s = iu - f_ray * S;
-                    if (f_s >= S) { ++f_ray; f_s -= S; }
-                } else {                                                  // sample i + CULL_BLOCK: (ray, s) advance by a wave-uniform step
+                if (k == 0) ray_of((unsigned)i, f_ray, f_s);
+                else {
                     f_ray += blk_q; f_s += blk_r;
-                    if (f_s >= S) { ++f_ray; f_s -= S; }
+                    if (f_s >= (unsigned)a.S) { ++f_ray; f_s -= (unsigned)a.S; }
                 }
-                const unsigned ray = f_ray, s = f_s;
-                const float near = a.near[ray], far = a.far[ray];
-                const float t = ((int)s < a.S / 2) ? lin_step * (float)(int)s : 1.0f - lin_step * (float)(a.S - 1 - (int)s);   // linspace01
-                z = near * (1.0f - t) + far * t;                          // sample_z
-                const float* __restrict__ rd = a.ray_d + (size_t)ray * 3u;        // (one address + immediate offsets per array)
-                const float* __restrict__ ro = a.ray_o + (size_t)ray * 3u;
-                const float dx = rd[0], dy = rd[1], dz = rd[2];
-                const float wx = ro[0] + dx * z, wy = ro[1] + dy * z, wz = ro[2] + dz * z;   // pts = o + d*z
-                const float qx = wx - Th[0], qy = wy - Th[1], qz = wz - Th[2];                                         // (p - Th) @ R
-                px = qx * R[0] + qy * R[3] + qz * R[6];
-                py = qx * R[1] + qy * R[4] + qz * R[7];
-                pz = qx * R[2] + qy * R[5] + qz * R[8];
+                fast_point(f_ray, f_s, px, py, pz, z);
             } else {
                 sample_pose_point(a, i, px, py, pz, &z, nullptr);
             }
             if (a.z_vals) a.z_vals[i] = z;
             float pn;
-            if (MASKED) pn = FAST ? cull_distance<uint32_t, PRE>(a.scene.pbw, w.cullmask, px, py, pz, rext, pre, bnd)
-                                  : cull_distance<int64_t, false>(a.scene.pbw, w.cullmask, px, py, pz, rext, pre, bnd);
+            if (MASKED) pn = FAST ? cull_distance<uint32_t>(a.scene.pbw, w.cullmask, px, py, pz, rext, bnd)
+                                  : cull_distance<int64_t>(a.scene.pbw, w.cullmask, px, py, pz, rext, bnd);
             else sample_volume_dev<1>(a.scene.pbw, a.scene.pbw.c - 1, px, py, pz, &pn);   // distance channel
             keep = pn < a.scene.thresh;                                               // :135
         }
@@ -178,6 +237,7 @@ __device__ __forceinline__ void cull_flag_body(const RenderArgs& a, const Worksp
             w.mask[tile * (CULL_TILE / 64) + k * (CULL_BLOCK / 64) + wv] = m;
             cnt[k * (CULL_BLOCK / 64) + wv] = __popcll(m);
         }
+    }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
