@@ -61,18 +61,16 @@ __device__ __forceinline__ void cull_cells_body(const VolDev& v, float thresh_hi
 // quotients.  Its cell comes from ONE multiply per axis by pre[c] = RN(1 / extent) x (d - 1): within 3e-7 x d of the exact lattice
 // coordinate (the exact form rounds five times, this one three), so unless the coordinate lies within CULL_PRE_DELTA of a lattice plane
 // (or was clamped: fraction 0) the cell IS the exact path's cell and a clear mask byte rejects the sample as the exact path would; the
-// others (~1.2 %) and every sample of a live cell are CANDIDATES for the exact path.  -> true: certainly not a survivor.
+// others (~1.2 %) and every sample of a live cell are CANDIDATES for the exact path.  -> the cell; sure = the cell is the exact path's.
 #define CULL_PRE_DELTA 2e-3f            // >> 3e-7 x 1024 (the host admits d <= 1024 per axis for the pre-test)
-__device__ __forceinline__ bool cull_pre_reject(const VolDev& v, const uint8_t* __restrict__ mask, float px, float py, float pz,
-                                                const float* pre, const float* bnd) {
+__device__ __forceinline__ int cull_pre_cell(const VolDev& v, float px, float py, float pz, const float* pre, const float* bnd, bool& sure) {
     const float ax = fminf(fmaxf((px - bnd[0]) * pre[0], 0.0f), (float)(v.dx - 1));        // (NaN -> 0 -> fraction 0 -> candidate)
     const float ay = fminf(fmaxf((py - bnd[1]) * pre[1], 0.0f), (float)(v.dy - 1));
     const float az = fminf(fmaxf((pz - bnd[2]) * pre[2], 0.0f), (float)(v.dz - 1));
     const float cx = floorf(ax), cy = floorf(ay), cz = floorf(az);
-    const bool sure = fabsf((ax - cx) - 0.5f) < 0.5f - CULL_PRE_DELTA && fabsf((ay - cy) - 0.5f) < 0.5f - CULL_PRE_DELTA &&
-                      fabsf((az - cz) - 0.5f) < 0.5f - CULL_PRE_DELTA;
-    const float cell = fmaf(fmaf(cx, (float)v.dy, cy), (float)v.dz, cz);                   // exact: cells <= CULL_MASK_MAX = 2^22
-    return sure && !mask[(unsigned)(int)cell];
+    sure = fabsf((ax - cx) - 0.5f) < 0.5f - CULL_PRE_DELTA && fabsf((ay - cy) - 0.5f) < 0.5f - CULL_PRE_DELTA &&
+           fabsf((az - cz) - 0.5f) < 0.5f - CULL_PRE_DELTA;
+    return (int)fmaf(fmaf(cx, (float)v.dy, cy), (float)v.dz, cz);                          // exact: cells <= CULL_MASK_MAX = 2^22; always a valid cell
 }
 
 template <typename IDX>        // IDX = uint32_t when dx*dy*dz*c < 2^31 (host-checked): 64-bit index multiplies are quarter rate
@@ -134,19 +132,23 @@ __device__ __forceinline__ void cull_flag_body(const RenderArgs& a, const Worksp
 #pragma unroll
         for (int c = 0; c < 3; ++c) Th[c] = a.scene.Th[c];
     }
-    // FAST: pose-space point of sample s of ray `ray` — the op sequence of sample_pose_point / sample_z / linspace01, bit for bit
-    auto fast_point = [&](unsigned ray, unsigned s, float& px, float& py, float& pz, float& z) {
-        const float near = a.near[ray], far = a.far[ray];
+    // FAST: pose-space point of sample s of a ray from the ray's near / far / origin / direction — the op sequence of
+    // sample_pose_point / sample_z / linspace01, bit for bit
+    auto point_from = [&](float near, float far, const float* ro, const float* rd, unsigned s, float& px, float& py, float& pz, float& z) {
         const float t = ((int)s < a.S / 2) ? lin_step * (float)(int)s : 1.0f - lin_step * (float)(a.S - 1 - (int)s);   // linspace01
         z = near * (1.0f - t) + far * t;                          // sample_z
-        const float* __restrict__ rd = a.ray_d + (size_t)ray * 3u;        // (one address + immediate offsets per array)
-        const float* __restrict__ ro = a.ray_o + (size_t)ray * 3u;
-        const float dx = rd[0], dy = rd[1], dz = rd[2];
-        const float wx = ro[0] + dx * z, wy = ro[1] + dy * z, wz = ro[2] + dz * z;   // pts = o + d*z
+        const float wx = ro[0] + rd[0] * z, wy = ro[1] + rd[1] * z, wz = ro[2] + rd[2] * z;   // pts = o + d*z
         const float qx = wx - Th[0], qy = wy - Th[1], qz = wz - Th[2];                                         // (p - Th) @ R
         px = qx * R[0] + qy * R[3] + qz * R[6];
         py = qx * R[1] + qy * R[4] + qz * R[7];
         pz = qx * R[2] + qy * R[5] + qz * R[8];
+    };
+    auto fast_point = [&](unsigned ray, unsigned s, float& px, float& py, float& pz, float& z) {
+        const float near = a.near[ray], far = a.far[ray];
+        const float* __restrict__ rd = a.ray_d + (size_t)ray * 3u;        // (one address + immediate offsets per array)
+        const float* __restrict__ ro = a.ray_o + (size_t)ray * 3u;
+        const float o[3] = {ro[0], ro[1], ro[2]}, d[3] = {rd[0], rd[1], rd[2]};
+        point_from(near, far, o, d, s, px, py, pz, z);
     };
     auto ray_of = [&](unsigned iu, unsigned& ray, unsigned& s) {
         const unsigned S = (unsigned)a.S;
@@ -167,21 +169,49 @@ __device__ __forceinline__ void cull_flag_body(const RenderArgs& a, const Worksp
         if (threadIdx.x < CULL_TILE / 64) s_mask[threadIdx.x] = 0ull;
         if (threadIdx.x == 0) s_ncand = 0;
         __syncthreads();
+        // (1) is a chain of dependent round trips per sample — the ray's near / far / origin / direction (first touch: HBM), then the
+        // mask byte — and measured latency-bound (instruction count halved: same 155 us), so the four samples of a thread are walked
+        // side by side: all ray loads first, then all points and mask loads, then the appends.
+        float rn[CULL_PER], rf[CULL_PER], o3[CULL_PER][3], d3[CULL_PER][3];
+        unsigned ss[CULL_PER];
+        bool valid[CULL_PER];
 #pragma unroll
         for (int k = 0; k < CULL_PER; ++k) {
             const int64_t i = tile * CULL_TILE + k * CULL_BLOCK + threadIdx.x;
-            bool cand = false;
-            if (i < a.N) {
-                if (k == 0) ray_of((unsigned)i, f_ray, f_s);
-                else {                                                    // sample i + CULL_BLOCK: (ray, s) advance by a wave-uniform step
-                    f_ray += blk_q; f_s += blk_r;
-                    if (f_s >= (unsigned)a.S) { ++f_ray; f_s -= (unsigned)a.S; }
-                }
-                float px, py, pz, z;
-                fast_point(f_ray, f_s, px, py, pz, z);
-                if (a.z_vals) a.z_vals[i] = z;
-                cand = !cull_pre_reject(a.scene.pbw, w.cullmask, px, py, pz, pre, bnd);
+            valid[k] = i < a.N;
+            if (k == 0) ray_of((unsigned)min(i, a.N - 1), f_ray, f_s);
+            else {                                                        // sample i + CULL_BLOCK: (ray, s) advance by a wave-uniform step
+                f_ray += blk_q; f_s += blk_r;
+                if (f_s >= (unsigned)a.S) { ++f_ray; f_s -= (unsigned)a.S; }
             }
+            const unsigned ray = min(f_ray, (unsigned)(a.R - 1));         // (samples beyond N: any ray, result unused)
+            ss[k] = f_s;
+            rn[k] = a.near[ray]; rf[k] = a.far[ray];
+            const float* __restrict__ rd = a.ray_d + (size_t)ray * 3u;    // (one address + immediate offsets per array)
+            const float* __restrict__ ro = a.ray_o + (size_t)ray * 3u;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { o3[k][c] = ro[c]; d3[k][c] = rd[c]; }
+        }
+        int cell[CULL_PER];
+        bool sure[CULL_PER];
+        float zz[CULL_PER];
+#pragma unroll
+        for (int k = 0; k < CULL_PER; ++k) {
+            float px, py, pz;
+            point_from(rn[k], rf[k], o3[k], d3[k], ss[k], px, py, pz, zz[k]);
+            cell[k] = cull_pre_cell(a.scene.pbw, px, py, pz, pre, bnd, sure[k]);
+        }
+        uint8_t mb[CULL_PER];
+#pragma unroll
+        for (int k = 0; k < CULL_PER; ++k) mb[k] = w.cullmask[cell[k]];
+        if (a.z_vals) {
+#pragma unroll
+            for (int k = 0; k < CULL_PER; ++k)
+                if (valid[k]) a.z_vals[tile * CULL_TILE + k * CULL_BLOCK + threadIdx.x] = zz[k];
+        }
+#pragma unroll
+        for (int k = 0; k < CULL_PER; ++k) {
+            const bool cand = valid[k] && !(sure[k] && !mb[k]);
             const unsigned long long m = __ballot(cand);
             if (m) {
                 const int first = __ffsll((long long)m) - 1;
