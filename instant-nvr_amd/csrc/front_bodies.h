@@ -73,7 +73,9 @@ __device__ __forceinline__ int cull_pre_cell(const VolDev& v, float px, float py
     return (int)fmaf(fmaf(cx, (float)v.dy, cy), (float)v.dz, cz);                          // exact: cells <= CULL_MASK_MAX = 2^22; always a valid cell
 }
 
-template <typename IDX>        // IDX = uint32_t when dx*dy*dz*c < 2^31 (host-checked): 64-bit index multiplies are quarter rate
+// CHECK = false (the candidates of the two-phase frame path): no mask read — a dead cell's 8 corners are all >= thresh (1 + 1e-5), its
+// trilinear value cannot pass `< thresh` (cull_cells_body), so the taps alone give the same decision one dependent round trip earlier.
+template <typename IDX, bool CHECK = true>        // IDX = uint32_t when dx*dy*dz*c < 2^31 (host-checked): 64-bit index multiplies are quarter rate
 __device__ __forceinline__ float cull_distance(const VolDev& v, const uint8_t* __restrict__ mask, float px, float py, float pz, const float* rext,
                                                const float* bnd) {
     const float b0x = bnd[0], b0y = bnd[1], b0z = bnd[2];          // v.bounds, read once per thread by the caller
@@ -90,7 +92,7 @@ __device__ __forceinline__ float cull_distance(const VolDev& v, const uint8_t* _
     iz = fminf(fmaxf(iz, 0.0f), (float)(v.dz - 1));
     const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
     const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
-    if (!mask[((IDX)x0 * (IDX)v.dy + (IDX)y0) * (IDX)v.dz + (IDX)z0]) return __builtin_inff();
+    if (CHECK && !mask[((IDX)x0 * (IDX)v.dy + (IDX)y0) * (IDX)v.dz + (IDX)z0]) return __builtin_inff();
     const float tx = ix - fx, ty = iy - fy, tz = iz - fz;
     const int x1 = min(x0 + 1, v.dx - 1), y1 = min(y0 + 1, v.dy - 1), z1 = min(z0 + 1, v.dz - 1);
     float out = 0.0f;
@@ -114,6 +116,39 @@ __device__ __forceinline__ void cull_flag_body(const RenderArgs& a, const Worksp
     __shared__ int cnt[CULL_PER * (CULL_BLOCK / 64)];
     float rext[3] = {0.f, 0.f, 0.f}, pre[3] = {0.f, 0.f, 0.f}, bnd[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     constexpr bool PRE = MASKED && FAST;
+    auto ray_of = [&](unsigned iu, unsigned& ray, unsigned& s) {
+        const unsigned S = (unsigned)a.S;
+        ray = (unsigned)((double)iu * inv_S);                     // floor(i / S), possibly one too small
+        s = iu - ray * S;
+        if (s >= S) { ++ray; s -= S; }
+    };
+    unsigned f_ray = 0u, f_s = 0u;
+    const unsigned blk_q = FAST ? (unsigned)CULL_BLOCK / (unsigned)a.S : 0u, blk_r = FAST ? (unsigned)CULL_BLOCK % (unsigned)a.S : 0u;   // (scalar unit)
+    // PRE, first thing in the workgroup: the ray loads of the thread's four samples (addresses from the kernel arguments alone) go out
+    // before the scene constants are fetched — the workgroup's life is a chain of dependent round trips (measured: halving the
+    // instructions of this body left its 155 us unchanged), so the chain is kept short and its links wide.
+    float rn[CULL_PER], rf[CULL_PER], o3[CULL_PER][3], d3[CULL_PER][3];
+    unsigned ss[CULL_PER];
+    bool valid[CULL_PER];
+    if (PRE) {
+#pragma unroll
+        for (int k = 0; k < CULL_PER; ++k) {
+            const int64_t i = tile * CULL_TILE + k * CULL_BLOCK + threadIdx.x;
+            valid[k] = i < a.N;
+            if (k == 0) ray_of((unsigned)min(i, a.N - 1), f_ray, f_s);
+            else {                                                        // sample i + CULL_BLOCK: (ray, s) advance by a wave-uniform step
+                f_ray += blk_q; f_s += blk_r;
+                if (f_s >= (unsigned)a.S) { ++f_ray; f_s -= (unsigned)a.S; }
+            }
+            const unsigned ray = min(f_ray, (unsigned)(a.R - 1));         // (samples beyond N: any ray, result unused)
+            ss[k] = f_s;
+            rn[k] = a.near[ray]; rf[k] = a.far[ray];
+            const float* __restrict__ rd = a.ray_d + (size_t)ray * 3u;    // (one address + immediate offsets per array)
+            const float* __restrict__ ro = a.ray_o + (size_t)ray * 3u;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { o3[k][c] = ro[c]; d3[k][c] = rd[c]; }
+        }
+    }
     if (MASKED) {
         const float* pb = a.scene.pbw.bounds;
         const int dd[3] = {a.scene.pbw.dx, a.scene.pbw.dy, a.scene.pbw.dz};
@@ -121,8 +156,8 @@ __device__ __forceinline__ void cull_flag_body(const RenderArgs& a, const Worksp
         for (int c = 0; c < 6; ++c) bnd[c] = pb[c];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            rext[c] = rcp_for_div(bnd[3 + c] - bnd[c]);
-            pre[c] = rext[c] * (float)(dd[c] - 1);             // (rext = 0: the pre-test never decides)
+            if (PRE) pre[c] = __builtin_amdgcn_rcpf(bnd[3 + c] - bnd[c]) * (float)(dd[c] - 1);    // (1 ulp: inside the pre-test's margin; the
+            else rext[c] = rcp_for_div(bnd[3 + c] - bnd[c]);                                       //  exact reciprocals: phase 2 only)
         }
     }
     float R[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, Th[3] = {0.f, 0.f, 0.f};
@@ -150,14 +185,6 @@ __device__ __forceinline__ void cull_flag_body(const RenderArgs& a, const Worksp
         const float o[3] = {ro[0], ro[1], ro[2]}, d[3] = {rd[0], rd[1], rd[2]};
         point_from(near, far, o, d, s, px, py, pz, z);
     };
-    auto ray_of = [&](unsigned iu, unsigned& ray, unsigned& s) {
-        const unsigned S = (unsigned)a.S;
-        ray = (unsigned)((double)iu * inv_S);                     // floor(i / S), possibly one too small
-        s = iu - ray * S;
-        if (s >= S) { ++ray; s -= S; }
-    };
-    unsigned f_ray = 0u, f_s = 0u;
-    const unsigned blk_q = FAST ? (unsigned)CULL_BLOCK / (unsigned)a.S : 0u, blk_r = FAST ? (unsigned)CULL_BLOCK % (unsigned)a.S : 0u;   // (scalar unit)
     if (PRE) {
         // Two phases.  A wave holds 64 consecutive samples of a ray: if one of them needs the exact path (three exact quotients, 8
         // taps) the whole wave walks it — with the exact path inside the sample loop nearly every wave of a frame that shows the body
@@ -172,26 +199,6 @@ __device__ __forceinline__ void cull_flag_body(const RenderArgs& a, const Worksp
         // (1) is a chain of dependent round trips per sample — the ray's near / far / origin / direction (first touch: HBM), then the
         // mask byte — and measured latency-bound (instruction count halved: same 155 us), so the four samples of a thread are walked
         // side by side: all ray loads first, then all points and mask loads, then the appends.
-        float rn[CULL_PER], rf[CULL_PER], o3[CULL_PER][3], d3[CULL_PER][3];
-        unsigned ss[CULL_PER];
-        bool valid[CULL_PER];
-#pragma unroll
-        for (int k = 0; k < CULL_PER; ++k) {
-            const int64_t i = tile * CULL_TILE + k * CULL_BLOCK + threadIdx.x;
-            valid[k] = i < a.N;
-            if (k == 0) ray_of((unsigned)min(i, a.N - 1), f_ray, f_s);
-            else {                                                        // sample i + CULL_BLOCK: (ray, s) advance by a wave-uniform step
-                f_ray += blk_q; f_s += blk_r;
-                if (f_s >= (unsigned)a.S) { ++f_ray; f_s -= (unsigned)a.S; }
-            }
-            const unsigned ray = min(f_ray, (unsigned)(a.R - 1));         // (samples beyond N: any ray, result unused)
-            ss[k] = f_s;
-            rn[k] = a.near[ray]; rf[k] = a.far[ray];
-            const float* __restrict__ rd = a.ray_d + (size_t)ray * 3u;    // (one address + immediate offsets per array)
-            const float* __restrict__ ro = a.ray_o + (size_t)ray * 3u;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { o3[k][c] = ro[c]; d3[k][c] = rd[c]; }
-        }
         int cell[CULL_PER];
         bool sure[CULL_PER];
         float zz[CULL_PER];
@@ -223,13 +230,17 @@ __device__ __forceinline__ void cull_flag_body(const RenderArgs& a, const Worksp
         }
         __syncthreads();
         const int n_cand = s_ncand;
+        if ((int)threadIdx.x < n_cand) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) rext[c] = rcp_for_div(bnd[3 + c] - bnd[c]);
+        }
         for (int c = threadIdx.x; c < n_cand; c += CULL_BLOCK) {
             const unsigned loc = s_cand[c];
             unsigned ray, sm;
             ray_of((unsigned)(tile * CULL_TILE) + loc, ray, sm);
             float px, py, pz, z;
             fast_point(ray, sm, px, py, pz, z);
-            const float pn = cull_distance<uint32_t>(a.scene.pbw, w.cullmask, px, py, pz, rext, bnd);
+            const float pn = cull_distance<uint32_t, false>(a.scene.pbw, w.cullmask, px, py, pz, rext, bnd);
             if (pn < a.scene.thresh) atomicOr(&s_mask[loc >> 6], 1ull << (loc & 63u));               // :135
         }
         __syncthreads();
