@@ -73,8 +73,8 @@ __global__ __launch_bounds__(CMP_BLOCK) void k_composite(Src src, int64_t R, int
                                                          float* __restrict__ rgb_map, float* __restrict__ acc_map,
                                                          float4* __restrict__ raw_out, float* __restrict__ occ_out) {
     const int lane = threadIdx.x & 63;
-    const int64_t ray = (int64_t)blockIdx.x * (CMP_BLOCK / 64) + (threadIdx.x >> 6);
-    if (ray >= R) return;
+    // a wave per ray, the waves of a fixed grid walking the rays: one workgroup per four rays was 62 k workgroups for a frame
+    for (int64_t ray = (int64_t)blockIdx.x * (CMP_BLOCK / 64) + (threadIdx.x >> 6); ray < R; ray += (int64_t)gridDim.x * (CMP_BLOCK / 64)) {
     float T_run = 1.0f, ar = 0.f, ag = 0.f, ab = 0.f, aw = 0.f;
     for (int s0 = 0; s0 < S; s0 += 64) {
         const int s = s0 + lane;
@@ -98,12 +98,19 @@ __global__ __launch_bounds__(CMP_BLOCK) void k_composite(Src src, int64_t R, int
         rgb_map[ray * 3] = ar; rgb_map[ray * 3 + 1] = ag; rgb_map[ray * 3 + 2] = ab;
         acc_map[ray] = aw;
     }
+    }
+}
+
+static unsigned composite_grid(int64_t n_rays) {
+    static const int wg = getenv("INVR_CMP_WG") ? atoi(getenv("INVR_CMP_WG")) : 4096;
+    const int64_t need = cdiv(n_rays, CMP_BLOCK / 64);
+    return (unsigned)(need < wg ? need : wg);
 }
 
 int launch_composite(const float* raw, int64_t n_rays, int S, float eps, float* weights, float* rgb_map, float* acc_map, hipStream_t st) {
     if (n_rays == 0) return 0;
     DenseRaw src{reinterpret_cast<const float4*>(raw)};
-    hipLaunchKernelGGL(k_composite<DenseRaw>, dim3((unsigned)cdiv(n_rays, CMP_BLOCK / 64)), dim3(CMP_BLOCK), 0, st,
+    hipLaunchKernelGGL(k_composite<DenseRaw>, dim3(composite_grid(n_rays)), dim3(CMP_BLOCK), 0, st,
                        src, n_rays, S, eps, weights, rgb_map, acc_map, (float4*)nullptr, (float*)nullptr);
     INVR_LAUNCH_CHECK();
     return 0;
@@ -113,7 +120,7 @@ int launch_merge_composite(const RenderArgs& a, const Workspace& w, float* rgb_m
                            float* occ, float* weights, hipStream_t st) {
     if (a.R == 0) return 0;
     MergedRaw src{w.mask, w.word_off, w.ord_rows > 0 ? w.byte_off : nullptr, w.wsel, w.rgbw, w.cap};
-    hipLaunchKernelGGL(k_composite<MergedRaw>, dim3((unsigned)cdiv(a.R, CMP_BLOCK / 64)), dim3(CMP_BLOCK), 0, st,
+    hipLaunchKernelGGL(k_composite<MergedRaw>, dim3(composite_grid(a.R)), dim3(CMP_BLOCK), 0, st,
                        src, a.R, a.S, a.scene.comp_eps, weights, rgb_map, acc_map, reinterpret_cast<float4*>(raw), occ);
     INVR_LAUNCH_CHECK();
     return 0;
