@@ -1113,13 +1113,9 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_front_cull(RenderArgs a, Workspa
     static_assert(VC_BLOCK == CULL_BLOCK, "the two bodies share a launch");
     const int b = (int)blockIdx.x;
     if (b < vc_gx * INVR_NUM_PARTS) { voxel_class_body(a.scene, w.knn, w.counters + CNT_LIVE, b % vc_gx, vc_gx, b / vc_gx); return; }
-    // the cull tiles: a fixed number of workgroups walks them (a tile's body is a chain of dependent round trips; dispatching one
-    // workgroup per tile added its launch to every chain and measured 4.2 ns per tile whatever the body did)
-    const int64_t n_tiles = (a.N + CULL_TILE - 1) / CULL_TILE, n_wg = (int64_t)gridDim.x - vc_gx * INVR_NUM_PARTS;
-    for (int64_t t = b - vc_gx * INVR_NUM_PARTS; t < n_tiles; t += n_wg) {
-        cull_flag_body<true, FAST>(a, w, inv_S, lin_step, t);
-        __syncthreads();                 // (thread 0 has read the tile's counts before the next tile's are written)
-    }
+    // (one workgroup per tile.  A fixed grid of 2048 workgroups walking the tiles measured 352 us against 155 us: the tile's body is a
+    // chain of dependent round trips, and workgroups that start together walk it in lockstep — profiles/r4_cull_experiments.md)
+    cull_flag_body<true, FAST>(a, w, inv_S, lin_step, (int64_t)(b - vc_gx * INVR_NUM_PARTS));
 }
 
 // lattice classes + cull flags in one launch; returns 0 and sets *done = 0 when the frame does not take the masked cull
@@ -1135,8 +1131,7 @@ int launch_front_cull(const RenderArgs& a, const Workspace& w, int* done, hipStr
     const float lin_step = 1.0f / (float)(a.S - 1);
     const bool fast = !a.wpts && !a.jitter && a.N < (1ll << 31) && cells * v.c < (1ll << 31) && a.S >= 2 &&
                       v.dx <= 1024 && v.dy <= 1024 && v.dz <= 1024;      // (front_bodies.h: the pre-test's error bound)
-    static const int cull_wg = getenv("INVR_CULL_WG") ? atoi(getenv("INVR_CULL_WG")) : 2048;          // (8 per CU)
-    const unsigned grid = gx * INVR_NUM_PARTS + (unsigned)(nb < cull_wg ? nb : cull_wg);
+    const unsigned grid = gx * INVR_NUM_PARTS + (unsigned)nb;
     if (fast) hipLaunchKernelGGL((k_front_cull<true>), dim3(grid), dim3(CULL_BLOCK), 0, st, a, w, inv_S, lin_step, (int)gx);
     else hipLaunchKernelGGL((k_front_cull<false>), dim3(grid), dim3(CULL_BLOCK), 0, st, a, w, inv_S, lin_step, (int)gx);
     INVR_LAUNCH_CHECK();
