@@ -60,19 +60,21 @@ for _n in [n for n in dir(P) if n.startswith('test_')]:
     globals()['test_hostsim__' + _n[5:]] = getattr(P, _n)
 
 
-@pytest.mark.parametrize('pose', [0, 2])
-def test_hostsim_cull_fast_path_survivor_set(small_net, pose):
-    """The frame path's cull (k_front_cull<true>: cell mask + the one-multiply pre-test of csrc/front_bodies.h) only runs when the call
-    has at least 4 ray-samples per lattice cell — more than the reduced frame of this module: a 128 x 128 x 64 frame of its own, every
-    ray-sample against the dense stage kernels.  (Inverting the pre-test's mask read fails this test; it does not fail on the 96 x 96 frame.)"""
-    old = P.RES
-    P.RES = 128
+@pytest.mark.parametrize('pose,samples', [(0, 64), (2, 64), (0, 66)])
+def test_hostsim_cull_fast_path_survivor_set(small_net, pose, samples):
+    """The frame path's cull (k_front_cull<true>: cell mask + the pre-test + compacted candidates, csrc/front_bodies.h) only runs when
+    the call has at least 4 ray-samples per lattice cell — more than the reduced frame of this module: a 128 x 128 frame of its own,
+    every ray-sample against the dense stage kernels, at 64 and at 66 samples per ray (a thread's four samples then sit on different
+    rays at different offsets).  (Inverting the pre-test's mask read fails this test; it does not fail
+    on the 96 x 96 frame.)"""
+    old = (P.RES, P.S)
+    P.RES, P.S = 128, samples
     try:
         f = P.make_frame(pose, *small_net)
         assert f['gb']['ray_o'].shape[1] * P.S >= 4 * f['gb']['pbw'][0].shape[:3].numel()
         P.test_cull_survivor_set_exact_whole_frame(f)
     finally:
-        P.RES = old
+        P.RES, P.S = old
 
 
 @pytest.mark.skipif(not os.environ.get('HOSTSIM_FULL'), reason='30 s on the wave machine: HOSTSIM_FULL=1 (tools/hostsim_asan.sh sets it); the GPU suite runs the same cases')
