@@ -689,6 +689,11 @@ def main():
             counters = json.load(open(cf))
         meta = counters.pop('_meta', {}) if isinstance(counters, dict) else {}
         traffic.pop('_meta', None)
+        # the profiler reports template instantiations by their full name: the eval frame's are <false> (arg-max merge)
+        for d in (traffic, counters):
+            for k in ('k_winner_lists', 'k_part_rgb_all'):
+                if k not in d and k + '<false>' in d:
+                    d[k] = d.pop(k + '<false>')
         counters_stale = bool(traffic or counters) and meta.get('csrc_digest') != csrc_digest()
         src = ('profiles/ (rocprofv3 --pmc passes of this command, tools/prof_all.sh; counters cannot be collected inside the timed run)'
                + (' — STALE: measured on other kernel sources (digest %s, now %s)' % (meta.get('csrc_digest'), csrc_digest()) if counters_stale else '')
