@@ -576,25 +576,37 @@ def main():
     # index_selects are part of the same captured graph: one replay = K complete frames on every rank, no per-frame host work.
     use_graph = not args.no_graph
     fs = None
-    if use_graph:
+    # Modes, best first; every rank must end up in the same one (the exchange is a collective), so each attempt's outcome is agreed on
+    # with an all-reduce: (1) renders + exchange captured — the captured exchange must also reproduce this rank's own rows on every
+    # rank (a runtime that mis-replays captured collectives fails here); (2) renders captured, the exchange issued from the host
+    # once per K frames; (3) eager launches (the same work, launch-bound).
+    modes = ([('graph+exchange', True, True), ('graph', True, False)] if use_graph else []) + [('eager', False, False)]
+    if world == 1:
+        modes = [m for m in modes if m[0] != 'graph']
+    for name, cap, cap_x in modes:
+        ok = 1
         try:
-            fs = frame_set(net, batches, S, rank, world, shard_of=args.shard_of, want_raw=want_raw)
-        except Exception as e:                       # keep the bench alive: eager launches measure the same work
-            sys.stderr.write('hipGraph capture failed (%s); falling back to eager launches\n' % e)
-            use_graph = False
-    if fs is not None and world > 1:
-        # the captured exchange must reproduce this rank's own rows on every rank; otherwise (a runtime that mis-replays captured
-        # collectives) the renders stay captured and the exchange is issued from the host, once per K frames
-        fs.replay()
-        ok = torch.tensor([1 if fs.own_rows_match() else 0], device=dev)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 0:
-            sys.stderr.write('captured all-gather did not reproduce the local rows; exchanging from the host behind every replay\n')
-            del fs
-            torch.cuda.empty_cache()
-            fs = frame_set(net, batches, S, rank, world, shard_of=args.shard_of, want_raw=want_raw, capture_exchange=False)
-    if fs is None:
-        fs = frame_set(net, batches, S, rank, world, shard_of=args.shard_of, want_raw=want_raw, capture=False)
+            fs = frame_set(net, batches, S, rank, world, shard_of=args.shard_of, want_raw=want_raw, capture=cap, capture_exchange=cap_x)
+            if world > 1 and cap_x:
+                fs.replay()
+                ok = 1 if fs.own_rows_match() else 0
+                if not ok:
+                    sys.stderr.write('captured all-gather did not reproduce the local rows\n')
+        except Exception as e:                       # keep the bench alive: the next mode measures the same work
+            sys.stderr.write('%s failed (%s)\n' % (name, e))
+            ok = 0
+        if world > 1:
+            flag = torch.tensor([ok], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item())
+        if ok:
+            break
+        fs = None
+        torch.cuda.empty_cache()
+        if name == 'eager':
+            raise RuntimeError('no render mode worked')
+        sys.stderr.write('falling back from %s\n' % name)
+    use_graph = fs.graph is not None
     for _ in range(max(1, -(-args.warmup // K))):
         fs.replay()
     fence()
