@@ -7,7 +7,7 @@ overlap on this runtime, parallel BRANCHES of one graph do.  `FrameSet` captures
 side stream, with its own workspace and outputs), joins them, and — with more than one rank — appends ONE all-gather of the K
 frames' [r, g, b, acc] tiles (RCCL, captured in the same graph) and the K index_selects that put the rows in ray order.
 `replay()` is one launch per K frames: no per-frame host work, no per-frame collective.
-Measured on one MI355X (rank 0's shard of a W-way split, ms per frame): W = 1: 2.50 -> 2.16 (K = 4), W = 8: 0.51 -> 0.36.
+Measured on one MI355X (rank 0's shard of a W-way split, ms per frame): W = 1: 2.38 -> 2.08 (K = 4) -> 2.02 (K = 10), W = 8: 0.50 -> 0.33.
 
 The reference has no equivalent: its renderer walks one frame in 4096-ray chunks (inb_renderer.py:217-237) and its only
 parallelism is DDP training."""
@@ -39,17 +39,6 @@ class FrameSet:
     (`local` rows for a group of one).  capture=False runs the same steps eagerly (CPU / gloo tests, debugging); capture_exchange=False
     captures the renders only and issues the all-gather + index_selects from the host behind every replay (one per K frames)."""
 
-    def own_rows_match(self):
-        """Sanity check of an exchange: the rows of every full map that THIS rank rendered equal its local rows (synchronises)."""
-        from .dist import tile_indices
-        for k in range(self.K):
-            if self.full[k] is None or self.local[k] is None:
-                return False
-            idx = tile_indices(self.n_rays[k], self.rank, self.world, self.tile, device=self.full[k].device)
-            if not torch.equal(self.full[k][idx], self._rgba(self.local[k])):
-                return False
-        return True
-
     def __init__(self, render_fns, n_rays, rank=0, world=1, device='cuda', tile=DEFAULT_TILE, group=None, capture=True, capture_exchange=True):
         self.fns, self.n_rays, self.rank, self.world = list(render_fns), [int(n) for n in n_rays], rank, world
         self.device, self.tile, self.group, self.capture = torch.device(device), tile, group, capture
@@ -63,6 +52,17 @@ class FrameSet:
             self.recv = torch.empty(world * self.plan['rows'], 4, device=self.device)
         if capture:
             self._capture()
+
+    def own_rows_match(self):
+        """Sanity check of an exchange: the rows of every full map that THIS rank rendered equal its local rows (synchronises)."""
+        from .dist import tile_indices
+        for k in range(self.K):
+            if self.full[k] is None or self.local[k] is None:
+                return False
+            idx = tile_indices(self.n_rays[k], self.rank, self.world, self.tile, device=self.full[k].device)
+            if not torch.equal(self.full[k][idx], self._rgba(self.local[k])):
+                return False
+        return True
 
     @staticmethod
     def _rgba(out):
