@@ -117,6 +117,25 @@ class LazyHostRet(dict):
         self._fetch(tuple(self._lazy))
         return dict.values(self)
 
+    def pop(self, k, *default):
+        self._fetch((k,))
+        return dict.pop(self, k, *default)
+
+    def copy(self):
+        return dict(self)                       # (the plain all-host dict)
+
+    def __eq__(self, other):
+        self._fetch(tuple(self._lazy))
+        return dict.__eq__(self, other)
+
+    __hash__ = None
+
+    def __repr__(self):
+        return 'LazyHostRet(%s%s)' % (dict.__repr__(self), ''.join(', %s: <on the device>' % k for k in self._lazy))
+
+    def __reduce__(self):                       # pickle / copy.deepcopy: the plain all-host dict
+        return (dict, (dict(self),))
+
     def pending(self):
         """keys whose host copy has not been made yet"""
         return tuple(self._lazy)
