@@ -235,7 +235,19 @@ def test_random_bg_epsilon_training_steps_vs_oracle():
     weights = alpha * cumprod(1 - alpha + 1)); the fused forward / backward composite with that epsilon.  On a small model: every
     parameter gradient of one forward + backward against CPU autograd of the oracle, then three optimiser steps' losses against the
     oracle + torch.optim.Adam."""
-    cfg = make_cfg(table_log2=12, N_samples=12, random_bg=True)
+    # (with epsilon = 1 the weights grow like 2^S and cancel in the sums: looser than the 2e-4 of the epsilon-0 golden gradients)
+    _mode_training_steps(dict(random_bg=True), dict(random_bg=False), 1e-3, 3e-3)
+
+
+def test_aggr_mean_training_steps_vs_oracle():
+    """cfg.aggr = 'mean' (inb_part_network_multiassign.py:236-239) through NetworkWrapper + the fused node (k_merge_bwd<MEAN>) +
+    FusedAdam: the same check — gradients of one iteration against CPU autograd of the (reference-pinned) oracle, three optimiser
+    steps' losses against the oracle + torch.optim.Adam."""
+    _mode_training_steps(dict(aggr='mean'), dict(aggr=''), 2e-4, 3e-3)
+
+
+def _mode_training_steps(over, default, tol, tol_deformer):
+    cfg = make_cfg(table_log2=12, N_samples=12, **over)
     sd0 = params.init_state_dict(cfg, seed=21)
     bc = patch_batch(16, seed=2, frame=9, centre=(250, 262))
     n, S, LR, STEPS = bc['ray_o'].shape[1], 12, 1e-3, 3
@@ -265,8 +277,8 @@ def test_random_bg_epsilon_training_steps_vs_oracle():
     l_ref, _ = OT.train_loss(sd, cfg, bc, jit, noi)
     l_ref.backward()
     assert abs(float(loss) - float(l_ref)) < 2e-5 * max(1.0, abs(float(l_ref)))
-    cfg0 = copy.deepcopy(cfg)                                          # the epsilon is in play: with epsilon 0 the loss is a different number
-    cfg0.random_bg = False
+    cfg0 = copy.deepcopy(cfg)                                          # the switch is in play: with its default the loss is a different number
+    cfg0.update(default)
     with torch.no_grad():
         l0, _ = OT.train_loss({k: v.detach() for k, v in sd0.items()}, cfg0, bc, jit, noi)
     assert abs(float(l0) - float(l_ref)) > 1e-3 * abs(float(l_ref))
@@ -280,8 +292,7 @@ def test_random_bg_epsilon_training_steps_vs_oracle():
             assert float(mine_g[k].abs().max()) == 0.0, k
             continue
         err = float((mine_g[k] - gr.double()).abs().max())
-        # (with epsilon = 1 the weights grow like 2^S and cancel in the sums: looser than the 2e-4 of the epsilon-0 golden gradients)
-        assert err <= (3e-3 if k.startswith('tpose_deformer') else 1e-3) * scale + 1e-12, (k, err, scale)
+        assert err <= (tol_deformer if k.startswith('tpose_deformer') else tol) * scale + 1e-12, (k, err, scale)
         checked += 1
     assert checked >= 40
     # ---- three optimiser steps: the loss trajectory
