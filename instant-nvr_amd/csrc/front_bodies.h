@@ -110,7 +110,7 @@ __device__ __forceinline__ float cull_distance(const VolDev& v, const uint8_t* _
 // FAST (rays, no jitter, N < 2^31, small volume): 32-bit sample / ray / volume indices — the generic path spends a
 // third of its instructions on a 64-bit division by S and 64-bit index multiplies (quarter-rate integer ops).  The
 // float arithmetic is the same op sequence as sample_pose_point / sample_z / linspace01, bit for bit.
-template <bool MASKED, bool FAST>
+template <bool MASKED, bool FAST, bool RAY4 = false>      // RAY4: FAST && MASKED && S % 4 == 0 (the host's choice)
 __device__ __forceinline__ void cull_flag_body(const RenderArgs& a, const Workspace& w, double inv_S, float lin_step, const int64_t tile) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     __shared__ int cnt[CULL_PER * (CULL_BLOCK / 64)];
@@ -130,7 +130,21 @@ __device__ __forceinline__ void cull_flag_body(const RenderArgs& a, const Worksp
     float rn[CULL_PER], rf[CULL_PER], o3[CULL_PER][3], d3[CULL_PER][3];
     unsigned ss[CULL_PER];
     bool valid[CULL_PER];
-    if (PRE) {
+    // RAY4 (S a multiple of 4): a thread takes four CONSECUTIVE samples of one ray — one set of ray loads, and the lattice coordinate is
+    // affine in the sample depth, a(z) = A + z B, so the pre-test of a sample is three multiply-adds instead of the whole pose transform
+    // (the mask words are built in LDS, bit j = sample j of the tile: any sample-to-thread map gives the same words).
+    constexpr bool ray4 = PRE && RAY4;
+    if (PRE && ray4) {
+        const int64_t i0 = tile * CULL_TILE + 4 * (int64_t)threadIdx.x;
+        valid[0] = i0 < a.N;                                              // (N = R S, S % 4 == 0: all four samples or none)
+        ray_of((unsigned)min(i0, a.N - 1), f_ray, f_s);
+        const unsigned ray = min(f_ray, (unsigned)(a.R - 1));
+        rn[0] = a.near[ray]; rf[0] = a.far[ray];
+        const float* __restrict__ rd = a.ray_d + (size_t)ray * 3u;
+        const float* __restrict__ ro = a.ray_o + (size_t)ray * 3u;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { o3[0][c] = ro[c]; d3[0][c] = rd[c]; }
+    } else if (PRE) {
 #pragma unroll
         for (int k = 0; k < CULL_PER; ++k) {
             const int64_t i = tile * CULL_TILE + k * CULL_BLOCK + threadIdx.x;
@@ -202,11 +216,46 @@ __device__ __forceinline__ void cull_flag_body(const RenderArgs& a, const Worksp
         int cell[CULL_PER];
         bool sure[CULL_PER];
         float zz[CULL_PER];
+        if (ray4) {
+            // lattice coordinate of the ray: a(z) = A + z B, A = (((o - Th) R) - b0) pre, B = (d R) pre.  Against the exact path's point
+            // (o + d z - Th) R both forms round a handful of times at magnitudes <= M = |o| + |Th| + far |d|: the two differ by
+            // < 1e-6 M metres = 1e-6 M pre cells; a ray for which 2e-6 M pre reaches half of CULL_PRE_DELTA decides nothing here
+            // (every sample a candidate).  The bench frame: M = 8.5 m, 32 cells / m: 5e-4 of the 1e-3 allowed.
+            const float* o = o3[0];
+            const float* d = d3[0];
+            const float q0 = o[0] - Th[0], q1 = o[1] - Th[1], q2 = o[2] - Th[2];
+            float A[3], B[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                A[c] = ((q0 * R[c] + q1 * R[3 + c] + q2 * R[6 + c]) - bnd[c]) * pre[c];
+                B[c] = (d[0] * R[c] + d[1] * R[3 + c] + d[2] * R[6 + c]) * pre[c];
+            }
+            const float M = (fabsf(o[0]) + fabsf(o[1]) + fabsf(o[2])) + (fabsf(Th[0]) + fabsf(Th[1]) + fabsf(Th[2])) +
+                            fmaxf(fabsf(rn[0]), fabsf(rf[0])) * (fabsf(d[0]) + fabsf(d[1]) + fabsf(d[2]));
+            const bool ok_ray = 2e-6f * M * fmaxf(fmaxf(pre[0], pre[1]), pre[2]) <= 0.5f * CULL_PRE_DELTA;      // (NaN: false)
+            const VolDev& v = a.scene.pbw;
+#pragma unroll
+            for (int k = 0; k < CULL_PER; ++k) {
+                const int sk = (int)f_s + k;
+                const float t = (sk < a.S / 2) ? lin_step * (float)sk : 1.0f - lin_step * (float)(a.S - 1 - sk);   // linspace01
+                const float z = rn[0] * (1.0f - t) + rf[0] * t;           // sample_z (exact: also the z_vals output)
+                zz[k] = z;
+                const float ax = fminf(fmaxf(fmaf(z, B[0], A[0]), 0.0f), (float)(v.dx - 1));
+                const float ay = fminf(fmaxf(fmaf(z, B[1], A[1]), 0.0f), (float)(v.dy - 1));
+                const float az = fminf(fmaxf(fmaf(z, B[2], A[2]), 0.0f), (float)(v.dz - 1));
+                const float cx = floorf(ax), cy = floorf(ay), cz = floorf(az);
+                sure[k] = ok_ray && fabsf((ax - cx) - 0.5f) < 0.5f - CULL_PRE_DELTA && fabsf((ay - cy) - 0.5f) < 0.5f - CULL_PRE_DELTA &&
+                          fabsf((az - cz) - 0.5f) < 0.5f - CULL_PRE_DELTA;
+                cell[k] = (int)fmaf(fmaf(cx, (float)v.dy, cy), (float)v.dz, cz);
+                valid[k] = valid[0];
+            }
+        } else {
 #pragma unroll
         for (int k = 0; k < CULL_PER; ++k) {
             float px, py, pz;
             point_from(rn[k], rf[k], o3[k], d3[k], ss[k], px, py, pz, zz[k]);
             cell[k] = cull_pre_cell(a.scene.pbw, px, py, pz, pre, bnd, sure[k]);
+        }
         }
         uint8_t mb[CULL_PER];
 #pragma unroll
@@ -214,19 +263,24 @@ __device__ __forceinline__ void cull_flag_body(const RenderArgs& a, const Worksp
         if (a.z_vals) {
 #pragma unroll
             for (int k = 0; k < CULL_PER; ++k)
-                if (valid[k]) a.z_vals[tile * CULL_TILE + k * CULL_BLOCK + threadIdx.x] = zz[k];
+                if (valid[k]) a.z_vals[tile * CULL_TILE + (ray4 ? 4 * (int)threadIdx.x + k : k * CULL_BLOCK + (int)threadIdx.x)] = zz[k];
         }
+        // one append per thread: its (up to four) candidates take consecutive list slots — rank inside the wave by a scan of the
+        // per-thread counts, one LDS atomic per wave
+        bool cand[CULL_PER];
+        int nc = 0;
 #pragma unroll
-        for (int k = 0; k < CULL_PER; ++k) {
-            const bool cand = valid[k] && !(sure[k] && !mb[k]);
-            const unsigned long long m = __ballot(cand);
-            if (m) {
-                const int first = __ffsll((long long)m) - 1;
-                int base = 0;
-                if (lane == first) base = atomicAdd(&s_ncand, __popcll(m));
-                base = __shfl(base, first);
-                if (cand) s_cand[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)(k * CULL_BLOCK + threadIdx.x);
-            }
+        for (int k = 0; k < CULL_PER; ++k) { cand[k] = valid[k] && !(sure[k] && !mb[k]); nc += cand[k] ? 1 : 0; }
+        const int incl = wave_incl_sum_i(nc);
+        const int tot = __builtin_amdgcn_readlane(incl, 63);
+        if (tot) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&s_ncand, tot);
+            base = __builtin_amdgcn_readfirstlane(base);
+            int pos = base + incl - nc;
+#pragma unroll
+            for (int k = 0; k < CULL_PER; ++k)
+                if (cand[k]) s_cand[pos++] = (unsigned short)(ray4 ? 4 * (int)threadIdx.x + k : k * CULL_BLOCK + (int)threadIdx.x);
         }
         __syncthreads();
         const int n_cand = s_ncand;

@@ -18,9 +18,9 @@ __global__ void k_cull_cells(VolDev v, float thresh_hi, uint8_t* __restrict__ ma
     cull_cells_body(v, thresh_hi, mask, live, n_live, voxcls, (int)(blockIdx.x * blockDim.x + threadIdx.x));
 }
 
-template <bool MASKED, bool FAST>
+template <bool MASKED, bool FAST, bool RAY4>
 __global__ __launch_bounds__(CULL_BLOCK) void k_cull_flag(RenderArgs a, Workspace w, double inv_S, float lin_step) {
-    cull_flag_body<MASKED, FAST>(a, w, inv_S, lin_step, (int64_t)blockIdx.x);
+    cull_flag_body<MASKED, FAST, RAY4>(a, w, inv_S, lin_step, (int64_t)blockIdx.x);
 }
 
 #define SCAN_T 1024
@@ -194,10 +194,11 @@ int launch_cull(const RenderArgs& a, const Workspace& w, int64_t max_active, boo
     } else if (have_cells && a.N >= 4 * cells) {        // the mask pays for itself on full frames only
         const bool fast = !a.wpts && !a.jitter && a.N < (1ll << 31) && cells * v.c < (1ll << 31) && a.S >= 2 &&
                       v.dx <= 1024 && v.dy <= 1024 && v.dz <= 1024;      // (front_bodies.h: the pre-test's error bound)
-        if (fast) hipLaunchKernelGGL((k_cull_flag<true, true>), dim3((unsigned)nb), dim3(CULL_BLOCK), 0, st, a, w, inv_S, lin_step);
-        else hipLaunchKernelGGL((k_cull_flag<true, false>), dim3((unsigned)nb), dim3(CULL_BLOCK), 0, st, a, w, inv_S, lin_step);
+        if (fast && (a.S & 3) == 0) hipLaunchKernelGGL((k_cull_flag<true, true, true>), dim3((unsigned)nb), dim3(CULL_BLOCK), 0, st, a, w, inv_S, lin_step);
+        else if (fast) hipLaunchKernelGGL((k_cull_flag<true, true, false>), dim3((unsigned)nb), dim3(CULL_BLOCK), 0, st, a, w, inv_S, lin_step);
+        else hipLaunchKernelGGL((k_cull_flag<true, false, false>), dim3((unsigned)nb), dim3(CULL_BLOCK), 0, st, a, w, inv_S, lin_step);
     } else {
-        hipLaunchKernelGGL((k_cull_flag<false, false>), dim3((unsigned)nb), dim3(CULL_BLOCK), 0, st, a, w, inv_S, lin_step);
+        hipLaunchKernelGGL((k_cull_flag<false, false, false>), dim3((unsigned)nb), dim3(CULL_BLOCK), 0, st, a, w, inv_S, lin_step);
     }
     INVR_LAUNCH_CHECK();
     if (w.ord_rows > 0) {

@@ -1107,7 +1107,7 @@ int launch_front_scene(const RenderArgs& a, const Workspace& w, const GridDev& d
     return 0;
 }
 
-template <bool FAST>
+template <bool FAST, bool RAY4>
 __attribute__((amdgpu_waves_per_eu(8, 8)))
 __global__ __launch_bounds__(CULL_BLOCK) void k_front_cull(RenderArgs a, Workspace w, double inv_S, float lin_step, int vc_gx) {
     static_assert(VC_BLOCK == CULL_BLOCK, "the two bodies share a launch");
@@ -1115,7 +1115,7 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_front_cull(RenderArgs a, Workspa
     if (b < vc_gx * INVR_NUM_PARTS) { voxel_class_body(a.scene, w.knn, w.counters + CNT_LIVE, b % vc_gx, vc_gx, b / vc_gx); return; }
     // (one workgroup per tile.  A fixed grid of 2048 workgroups walking the tiles measured 352 us against 155 us: the tile's body is a
     // chain of dependent round trips, and workgroups that start together walk it in lockstep — profiles/r4_cull_experiments.md)
-    cull_flag_body<true, FAST>(a, w, inv_S, lin_step, (int64_t)(b - vc_gx * INVR_NUM_PARTS));
+    cull_flag_body<true, FAST, RAY4>(a, w, inv_S, lin_step, (int64_t)(b - vc_gx * INVR_NUM_PARTS));
 }
 
 // lattice classes + cull flags in one launch; returns 0 and sets *done = 0 when the frame does not take the masked cull
@@ -1132,8 +1132,9 @@ int launch_front_cull(const RenderArgs& a, const Workspace& w, int* done, hipStr
     const bool fast = !a.wpts && !a.jitter && a.N < (1ll << 31) && cells * v.c < (1ll << 31) && a.S >= 2 &&
                       v.dx <= 1024 && v.dy <= 1024 && v.dz <= 1024;      // (front_bodies.h: the pre-test's error bound)
     const unsigned grid = gx * INVR_NUM_PARTS + (unsigned)nb;
-    if (fast) hipLaunchKernelGGL((k_front_cull<true>), dim3(grid), dim3(CULL_BLOCK), 0, st, a, w, inv_S, lin_step, (int)gx);
-    else hipLaunchKernelGGL((k_front_cull<false>), dim3(grid), dim3(CULL_BLOCK), 0, st, a, w, inv_S, lin_step, (int)gx);
+    if (fast && (a.S & 3) == 0) hipLaunchKernelGGL((k_front_cull<true, true>), dim3(grid), dim3(CULL_BLOCK), 0, st, a, w, inv_S, lin_step, (int)gx);
+    else if (fast) hipLaunchKernelGGL((k_front_cull<true, false>), dim3(grid), dim3(CULL_BLOCK), 0, st, a, w, inv_S, lin_step, (int)gx);
+    else hipLaunchKernelGGL((k_front_cull<false, false>), dim3(grid), dim3(CULL_BLOCK), 0, st, a, w, inv_S, lin_step, (int)gx);
     INVR_LAUNCH_CHECK();
     *done = 1;
     return 0;
