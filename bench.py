@@ -218,12 +218,12 @@ def frame_batches(res, cam_dist, K, dev):
     return cpu, gpu
 
 
-def frame_set(net, batches, S, rank, world, shard_of=0, want_raw=True, capture=True, capture_exchange=True):
+def frame_set(net, batches, S, rank, world, shard_of=0, want_raw=True, capture=True, capture_exchange=True, streams=False):
     """invr.frames.FrameSet over this rank's shards of `batches`: one hipGraph replay renders all of them side by side (and, world > 1,
     exchanges their tiles with one captured all-gather).  shard_of = W renders rank 0's shard of a W-way split without any exchange."""
     fns, n_rays, keep = iframes.shard_render_fns(net, batches, S, 0 if shard_of else rank, shard_of or world, want_raw=want_raw)
     fs = iframes.FrameSet(fns, n_rays, rank=0 if shard_of else rank, world=1 if shard_of else world, device=batches[0]['ray_o'].device,
-                          capture=capture, capture_exchange=capture_exchange)
+                          capture=capture, capture_exchange=capture_exchange, streams=streams)
     fs._keep = keep
     return fs
 
@@ -344,8 +344,36 @@ def variant_lines(net, cfg, batches, dev, S, in_flight=1):
             _ = ret['rgb_map'], ret['acc_map']              # what the reference's evaluator / visualizers read (evaluators/if_nerf.py:77)
         torch.cuda.synchronize()
         api[key] = (time.perf_counter() - t0) / 3 * 1e3
+    # ... and with frames in flight ACROSS render() calls (Renderer.in_flight lanes, round 5): the caller submits the frames of the
+    # sequence one render(batch) at a time — every batch a new dict with its own volume dimensions, nothing captured — and reads
+    # frame f's maps after submitting frames f+1 .. f+7, as driver.run_evaluate does
+    from collections import deque
+    for to_cpu, key in ((False, 'in_flight8_eval_to_cpu_false_ms'), (True, 'in_flight8_eval_to_cpu_true_ms')):
+        r = Renderer(net)
+        r.eval_to_cpu, r.in_flight = to_cpu, 8
+        q = deque()
+
+        def sweep(n):
+            for i in range(n):
+                q.append(r.render(dict(batches[i % len(batches)])))
+                while len(q) >= r.in_flight:
+                    o = q.popleft()
+                    _ = o['rgb_map'], o['acc_map']
+            while q:
+                o = q.popleft()
+                _ = o['rgb_map'], o['acc_map']
+            torch.cuda.synchronize()
+        sweep(2 * len(batches))
+        t0 = time.perf_counter()
+        sweep(4 * len(batches))
+        api[key] = (time.perf_counter() - t0) / (4 * len(batches)) * 1e3
+        r.flush(release=True)
+        del r
+        torch.cuda.empty_cache()
     api['outputs'] = sorted(ret.keys())
-    api['note'] = ('Renderer.render(batch): eager launches + statistics read-back; eval_to_cpu=True is the reference contract '
+    api['note'] = ('Renderer.render(batch): eager launches + statistics read-back, one frame at a time (the maps are read after every call); '
+                   'in_flight8_* = the same call with Renderer.in_flight = 8 over the frames of the sequence, maps read 7 calls later '
+                   '(driver.run_evaluate\'s loop); eval_to_cpu=True is the reference contract '
                    '(inb_renderer.py:199-200 moves every output to the host: raw + occ = %.0f MB), into page-locked host tensors by '
                    'default, `_pageable` = ordinary host tensors as torch\'s .cpu() gives' % (n_rays * S * 20 / 1e6))
     out['api_frame'] = api

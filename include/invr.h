@@ -267,6 +267,15 @@ int invr_part_field_fwd(const InvrModel* model, int32_t pid, const int64_t* late
                         const float* tpts, const float* tdirs, int64_t n, float* raw,
                         void* workspace, size_t workspace_bytes, void* stream);
 
+/* HashEmbedder.forward (part_base_embedder.py:106-174) of one 16-level sum / sum_over_features part grid through the render
+ * path's own pair-list encoder kernels (invr_grid_encode_fwd is the generic any-configuration kernel): kernel 0 = the
+ * XCD-partitioned row-sum kernel of eval frames, 1 = the 64-byte-row kernel (training forward / eval_row_sums False), 2 = the
+ * one-part row-sum kernel; 0 and 2 need grid->row_sums.  xyz (n,3) -> out (n,19) = [normalised xyz, 16 level sums].
+ * workspace >= invr_part_encode_workspace(n). */
+size_t invr_part_encode_workspace(int64_t n);
+int invr_part_encode_fwd(const InvrGrid* grid, const float* xyz, int64_t n, int32_t kernel, float* out,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
 /* Deformer.forward without flag (uv_deformer.py:31-38; Network.resd, inb_part_network_multiassign.py:122-124):
  * canonical points (n,3) -> residual (n,3).  Uses scene->tuv/tbounds/frame_dim only. */
 int invr_deform_fwd(const InvrScene* scene, const InvrModel* model, const float* pts, int64_t n, float* resd,

@@ -92,7 +92,8 @@ EXPORTS = ['invr_last_error', 'invr_version', 'invr_sizeof', 'invr_workspace_byt
            'invr_field_workspace_bytes', 'invr_field_fwd', 'invr_geometry_fwd', 'invr_generate_rays',
            'invr_rigid_transformation', 'invr_pack_parts', 'invr_grid_row_sums_len', 'invr_grid_row_sums', 'invr_adam_chunk_elems', 'invr_adam_step', 'invr_part_mlp_fwd', 'invr_part_mlp_bwd',
            'invr_knn_neighbors', 'invr_pose_points', 'invr_adam_advance', 'invr_train_workspace_bytes', 'invr_train_fwd',
-           'invr_train_bwd', 'invr_expand_row_grad', 'invr_train_loss_fwd', 'invr_train_loss_bwd']
+           'invr_train_bwd', 'invr_expand_row_grad', 'invr_train_loss_fwd', 'invr_train_loss_bwd',
+           'invr_part_encode_workspace', 'invr_part_encode_fwd']
 BWD_HEAD, BWD_DEFORMER, BWD_ALL = 1, 64, 127
 NUM_STAGES = 14
 STAGE_NAMES = ['cull', 'knn', 'warp'] + ['encode_%d' % p for p in range(5)] + ['mlp_%d' % p for p in range(5)] + ['composite']
@@ -146,6 +147,9 @@ def lib():
         L.invr_pose_points.restype = C.c_int
         L.invr_warp_deform.argtypes = [C.POINTER(InvrScene), C.POINTER(InvrModel), vp, vp, vp, vp, C.c_int64, vp, vp, vp, vp]
         L.invr_part_field_fwd.argtypes = [C.POINTER(InvrModel), C.c_int32, vp, vp, vp, C.c_int64, vp, vp, C.c_size_t, vp]
+        L.invr_part_encode_workspace.restype = C.c_size_t
+        L.invr_part_encode_workspace.argtypes = [C.c_int64]
+        L.invr_part_encode_fwd.argtypes = [C.POINTER(InvrGrid), vp, C.c_int64, C.c_int32, vp, vp, C.c_size_t, vp]
         L.invr_composite_fwd.argtypes = [vp, C.c_int64, C.c_int32, vp, vp, vp, vp]
         L.invr_workspace_layout.argtypes = [C.c_int64, C.c_int32, C.c_int64, C.POINTER(InvrWsLayout)]
         L.invr_deform_fwd.argtypes = [C.POINTER(InvrScene), C.POINTER(InvrModel), vp, C.c_int64, vp, vp]

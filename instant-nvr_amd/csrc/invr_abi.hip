@@ -554,6 +554,59 @@ extern "C" int invr_part_field_fwd(const InvrModel* model, int32_t pid, const in
     return launch_part_mlp(pm, emb, ds, n, count, n, reinterpret_cast<float4*>(raw), st);
 }
 
+// HashEmbedder.forward of ONE part grid through the render path's pair-list encoders (the generic any-configuration kernel is
+// invr_grid_encode_fwd): kernel 0 = the XCD-partitioned row-sum kernel of eval frames (k_part_encode_rs_xcd; needs grid->row_sums),
+// 1 = the 64-byte-row kernel of the training forward / eval_row_sums False (k_part_encode), 2 = the one-part row-sum kernel
+// (k_part_encode_rs).  xyz (n,3) -> out (n,19) = [normalised xyz, 16 level sums].
+__global__ void k_xyz_to_soa(const float* a, int64_t n, int64_t stride, float* xs, int32_t* count) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) { count[0] = (int32_t)n; count[1] = count[2] = count[3] = count[4] = 0; }
+    if (i >= n) return;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) xs[c * stride + i] = a[i * 3 + c];
+}
+__global__ void k_emb_to_aos(const float* emb, int64_t n, int64_t cap, float* out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * 19) return;
+    out[i] = emb[(i % 19) * cap + i / 19];
+}
+
+extern "C" size_t invr_part_encode_workspace(int64_t n) {
+    if (n < 1) n = 1;
+    return align_up(256 + (size_t)n * (3 + EMB_K) * sizeof(float) + 3 * 256, 256);
+}
+
+extern "C" int invr_part_encode_fwd(const InvrGrid* grid, const float* xyz, int64_t n, int32_t kernel, float* out,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    INVR_CHECK(grid && kernel >= 0 && kernel <= 2, "invr_part_encode_fwd: bad grid / kernel");
+    if (n == 0) return 0;
+    INVR_CHECK(xyz && out, "invr_part_encode_fwd: null pointer");
+    INVR_CHECK(n < (1ll << 31), "invr_part_encode_fwd: n too large");
+    INVR_CHECK(workspace && workspace_bytes >= invr_part_encode_workspace(n), "invr_part_encode_fwd: workspace too small");
+    if (check_grid(grid, "part grid")) return 1;
+    INVR_CHECK(kernel == 1 || grid->row_sums, "invr_part_encode_fwd: the row-sum kernels need grid->row_sums (invr_grid_row_sums)");
+    Carver c{(char*)workspace, 0};
+    int32_t* count = c.take<int32_t>(8);
+    float* xs = c.take<float>(3 * n);
+    float* emb = c.take<float>(EMB_K * n);
+    hipLaunchKernelGGL(k_xyz_to_soa, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, xyz, n, n, xs, count);
+    INVR_LAUNCH_CHECK();
+    GridDev g = make_grid_dev(grid);
+    if (kernel == 0) {
+        EncodeAllArgs ea;
+        for (int p = 0; p < INVR_NUM_PARTS; ++p) { ea.g[p] = g; ea.xs[p] = xs; ea.emb[p] = emb; }      // counts = {n, 0, 0, 0, 0}
+        ea.counts = count; ea.stride = n; ea.cap = n;
+        if (launch_part_encode_all(ea, st)) return 1;
+    } else {
+        if (kernel == 1) g.row_sums = nullptr;
+        if (launch_part_encode(g, xs, n, count, n, emb, st)) return 1;
+    }
+    hipLaunchKernelGGL(k_emb_to_aos, dim3((unsigned)cdiv(n * 19, 256)), dim3(256), 0, st, emb, n, n, out);
+    INVR_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int invr_deform_fwd(const InvrScene* scene, const InvrModel* model, const float* pts, int64_t n, float* resd,
                                void* stream) {
     INVR_CHECK(scene && model && (n == 0 || (pts && resd)), "invr_deform_fwd: null pointer");

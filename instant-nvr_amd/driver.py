@@ -29,19 +29,39 @@ def assemble_image(values, batch):
     return img
 
 
-def run_evaluate(net, batches, device='cuda'):
-    """-> dict(psnr=[...], mse=[...]) over an iterable of collated batches (CPU or device tensors)."""
+def run_evaluate(net, batches, device='cuda', in_flight=8, renderer=None, keep_maps=False):
+    """-> dict(psnr=[...], mse=[...]) over an iterable of collated batches (CPU or device tensors): the loop of run.py:61-90 with
+    `in_flight` frames kept on the GPU — frame f is submitted (Renderer.render returns at once, Renderer.in_flight lanes) and the
+    metrics of frame f - in_flight + 1 are computed while the younger frames render; the values are those of one frame at a time
+    (same kernels, a workspace per lane).  in_flight = 1: strictly render -> metrics -> next batch, as the reference.
+    keep_maps: also return the host rgb_map of every frame (tests)."""
+    from collections import deque
     net.eval()
-    renderer = Renderer(net)
+    renderer = renderer or Renderer(net)
+    renderer.in_flight = max(1, int(in_flight))
     out = {'psnr': [], 'mse': []}
+    if keep_maps:
+        out['rgb_map'] = []
+    queue = deque()
+
+    def finish(ret, batch):
+        rgb = ret['rgb_map'][0].detach().cpu()
+        pred = assemble_image(rgb.numpy(), batch)
+        gt = assemble_image(batch['rgb'][0].detach().cpu().numpy(), batch)
+        out['mse'].append(float(np.mean((pred - gt) ** 2)))
+        out['psnr'].append(float(psnr_metric(pred.reshape(-1, 3), gt.reshape(-1, 3))))
+        if keep_maps:
+            out['rgb_map'].append(rgb)
+
     for batch in batches:
         batch = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
         with torch.no_grad():
             ret = renderer.render(batch)
-        pred = assemble_image(ret['rgb_map'][0].detach().cpu().numpy(), batch)
-        gt = assemble_image(batch['rgb'][0].detach().cpu().numpy(), batch)
-        out['mse'].append(float(np.mean((pred - gt) ** 2)))
-        out['psnr'].append(float(psnr_metric(pred.reshape(-1, 3), gt.reshape(-1, 3))))
+        queue.append((ret, batch))
+        while len(queue) >= renderer.in_flight:
+            finish(*queue.popleft())
+    while queue:
+        finish(*queue.popleft())
     return out
 
 

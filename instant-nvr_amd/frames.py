@@ -39,10 +39,13 @@ class FrameSet:
     (`local` rows for a group of one).  capture=False runs the same steps eagerly (CPU / gloo tests, debugging); capture_exchange=False
     captures the renders only and issues the all-gather + index_selects from the host behind every replay (one per K frames)."""
 
-    def __init__(self, render_fns, n_rays, rank=0, world=1, device='cuda', tile=DEFAULT_TILE, group=None, capture=True, capture_exchange=True):
+    def __init__(self, render_fns, n_rays, rank=0, world=1, device='cuda', tile=DEFAULT_TILE, group=None, capture=True, capture_exchange=True,
+                 streams=False):
         self.fns, self.n_rays, self.rank, self.world = list(render_fns), [int(n) for n in n_rays], rank, world
         self.device, self.tile, self.group, self.capture = torch.device(device), tile, group, capture
         self.K = len(self.fns)
+        self.use_streams = bool(streams) and not capture and self.device.type == 'cuda'
+        self.streams = [torch.cuda.Stream(self.device) for _ in range(self.K)] if self.use_streams else None
         self.exchange = world > 1 or (FORCE_COLLECTIVES() and dist.is_initialized())
         self.plan = exchange_plan(self.n_rays, world, tile, self.device) if self.exchange else None
         self.graph, self.exchange_captured, self.want_exchange_captured = None, False, capture_exchange
@@ -105,7 +108,7 @@ class FrameSet:
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
         self.graph = torch.cuda.CUDAGraph()
-        self.streams = [torch.cuda.Stream(self.device) for _ in range(self.K)]
+        self.streams = [torch.cuda.Stream(self.device) for _ in range(self.K)]          # capture streams of the K branches
         # thread_local capture mode: the RCCL watchdog thread of a multi-rank run may query events while this thread captures
         with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
             cur = torch.cuda.current_stream(self.device)
@@ -126,9 +129,27 @@ class FrameSet:
             if self.exchange and not self.exchange_captured:
                 self._exchange()
             return
+        if self.use_streams:
+            # no graph: frame k's chain is launched eagerly on stream k (its workspace and outputs are only ever touched there, so
+            # replay r + 1 of frame k queues behind replay r of frame k and nothing else); with an exchange the renders first wait
+            # for the previous replay's exchange to have read the send buffer, and the exchange waits for the K renders
+            cur = torch.cuda.current_stream(self.device)
+            for k in range(self.K):
+                self.streams[k].wait_stream(cur)          # (inputs made on the caller's stream; with an exchange: the previous replay's gather)
+                with torch.cuda.stream(self.streams[k]):
+                    self._render(k)
+            if self.exchange:
+                for k in range(self.K):
+                    cur.wait_stream(self.streams[k])
+                self._exchange()
+            return
         for k in range(self.K):
             self._render(k)
         self._exchange()
+
+    def synchronize(self):
+        """host-side join of everything replay() has enqueued (the K streams of the no-graph mode included)"""
+        torch.cuda.synchronize(self.device) if self.device.type == 'cuda' else None
 
 
 def shard_render_fns(net, batches, n_samples, rank, world, tile=DEFAULT_TILE, want_raw=True, cap_margin=1.3):

@@ -70,11 +70,22 @@ class LazyHostRet(dict):
     frame, 12 ms of PCIe for a 2.5 ms render) are copied on first access — by key, or all of them by keys() / items() / values() /
     iteration — and are host tensors of the reference's shapes from then on.  The device tensors they come from stay alive inside
     this object until then; a dict built from it (`dict(ret)`) is the plain all-host dict."""
-    def __init__(self, host, lazy_dev, pin):
+    def __init__(self, host, lazy_dev, pin, pending=None, keys=()):
         super().__init__(host)
         self._lazy, self._pin = dict(lazy_dev), pin
+        # a frame still in flight on one of the renderer's lanes (Renderer.in_flight > 1): `pending.result()` joins it — a host wait
+        # on THAT frame's event only — and hands over (host maps, device tensors for the lazy keys); `keys` = the keys it will have
+        self._pending, self._keys = pending, tuple(keys)
+
+    def _settle(self):
+        if self._pending is not None:
+            pend, self._pending = self._pending, None
+            host, lazy = pend.result()
+            dict.update(self, host)
+            self._lazy = dict(lazy)
 
     def _fetch(self, keys):
+        self._settle()
         todo = [k for k in keys if k in self._lazy]
         if not todo:
             return
@@ -89,6 +100,8 @@ class LazyHostRet(dict):
             torch.cuda.current_stream().synchronize()
 
     def __contains__(self, k):
+        if self._pending is not None:
+            return k in self._keys
         return dict.__contains__(self, k) or k in self._lazy
 
     def __getitem__(self, k):
@@ -99,6 +112,8 @@ class LazyHostRet(dict):
         return self[k] if k in self else d
 
     def __len__(self):
+        if self._pending is not None:
+            return len(self._keys)
         return dict.__len__(self) + len(self._lazy)
 
     def __iter__(self):
@@ -131,6 +146,8 @@ class LazyHostRet(dict):
     __hash__ = None
 
     def __repr__(self):
+        if self._pending is not None:
+            return 'LazyHostRet(<frame in flight: %s>)' % ', '.join(self._keys)
         return 'LazyHostRet(%s%s)' % (dict.__repr__(self), ''.join(', %s: <on the device>' % k for k in self._lazy))
 
     def __reduce__(self):                       # pickle / copy.deepcopy: the plain all-host dict
@@ -138,7 +155,170 @@ class LazyHostRet(dict):
 
     def pending(self):
         """keys whose host copy has not been made yet"""
+        if self._pending is not None:
+            return tuple(self._keys)
         return tuple(self._lazy)
+
+    def in_flight(self):
+        """True while the frame behind this dict has not been joined (Renderer.in_flight > 1)"""
+        return self._pending is not None and not self._pending.done()
+
+
+class LazyDevRet(dict):
+    """The eval return dict of a frame in flight when the outputs stay on the device (Renderer.eval_to_cpu = False with
+    Renderer.in_flight > 1): every access joins the frame first (a host wait on that frame's event, which also checks its workspace
+    for overflow); from then on it is the plain dict of device tensors."""
+    def __init__(self, pending, keys):
+        super().__init__()
+        self._pending, self._keys = pending, tuple(keys)
+
+    def _settle(self):
+        if self._pending is not None:
+            pend, self._pending = self._pending, None
+            dev, _ = pend.result()
+            dict.update(self, dev)
+
+    def __contains__(self, k):
+        return k in self._keys if self._pending is not None else dict.__contains__(self, k)
+
+    def __len__(self):
+        return len(self._keys) if self._pending is not None else dict.__len__(self)
+
+    def __getitem__(self, k):
+        self._settle()
+        return dict.__getitem__(self, k)
+
+    def get(self, k, d=None):
+        self._settle()
+        return dict.get(self, k, d)
+
+    def __iter__(self):
+        self._settle()
+        return dict.__iter__(self)
+
+    def keys(self):
+        self._settle()
+        return dict.keys(self)
+
+    def items(self):
+        self._settle()
+        return dict.items(self)
+
+    def values(self):
+        self._settle()
+        return dict.values(self)
+
+    def pop(self, k, *default):
+        self._settle()
+        return dict.pop(self, k, *default)
+
+    def copy(self):
+        self._settle()
+        return dict(self)
+
+    def __eq__(self, other):
+        self._settle()
+        return dict.__eq__(self, other)
+
+    __hash__ = None
+
+    def __repr__(self):
+        return 'LazyDevRet(<frame in flight: %s>)' % ', '.join(self._keys) if self._pending is not None else dict.__repr__(self)
+
+    def __reduce__(self):
+        self._settle()
+        return (dict, (dict(self),))
+
+    def in_flight(self):
+        return self._pending is not None and not self._pending.done()
+
+
+class _Lane:
+    """One of the renderer's K frame slots: a stream, the workspace of the frames rendered there (only ever touched on that stream,
+    so frame f + K queues behind frame f and nothing else) and the frame in flight on it."""
+    def __init__(self, device):
+        self.stream = torch.cuda.Stream(device)
+        self.ws = None
+        self.pending = None
+
+
+class _PendingFrame:
+    """An eval frame launched on a lane.  `result()` joins it (event wait), reads its statistics block, re-renders it at full
+    workspace capacity if the survivor bound was too small (stats[6]: nothing was written out of bounds, the frame is just
+    incomplete), and returns (maps, lazy): eval_to_cpu -> host maps + device raw / occ for LazyHostRet, else the device dict."""
+    def __init__(self, renderer, lane, call, cap, keep):
+        self.r, self.lane, self.call, self.cap, self.keep = renderer, lane, call, cap, keep
+        self.out = self.stats_host = self.event = self.host = None
+        self._res = None
+
+    def launch(self):
+        r, lane = self.r, self.lane
+        with torch.cuda.stream(lane.stream):
+            self.out = self._run(self.cap)
+            self.event = torch.cuda.Event()
+            self.event.record(lane.stream)
+
+    def _run(self, cap):
+        r, lane, net = self.r, self.lane, self.r.net
+        prev, net._ws = net._ws, lane.ws
+        try:
+            out = self.call(cap)
+        finally:
+            lane.ws, net._ws = net._ws, prev
+        self.stats_host = torch.empty(out['stats'].shape, dtype=out['stats'].dtype, pin_memory=True)
+        self.stats_host.copy_(out['stats'], non_blocking=True)
+        self.host = {}
+        if r.eval_to_cpu:                     # the image maps follow the render on the lane's stream: on the host when the event fires
+            for k in ('rgb_map', 'acc_map'):
+                v = out[k][None]
+                h = torch.empty(v.shape, dtype=v.dtype, device='cpu', pin_memory=r.pin_host)
+                h.copy_(v, non_blocking=True)
+                self.host[k] = h
+        return out
+
+    def done(self):
+        return self._res is not None or self.event.query()
+
+    def result(self):
+        if self._res is not None:
+            return self._res
+        r, lane = self.r, self.lane
+        self.event.synchronize()
+        redo = bool(self.cap) and int(self.stats_host[6]) != 0
+        if redo:                                                          # survivor bound too small: once more at full capacity
+            lane.ws = None                                                # (not both workspaces at once)
+            with torch.cuda.stream(lane.stream):
+                self.out = self._run(0)
+            lane.stream.synchronize()
+            lane.ws = None          # ~1150 B per ray-sample: the next frame of this lane gets one sized from the new survivor count
+        st = self.stats_host
+        if int(st[6]) != 0:
+            raise RuntimeError('invr_render_fwd reported stats[6] = %d: workspace overflow' % int(st[6]))
+        r._cap_hint = int(1.5 * int(st[0])) + 65536
+        r.last_stats = self.out['stats']
+        out = self.out
+        cur = torch.cuda.current_stream(out['rgb_map'].device)
+        dev = {'rgb_map': out['rgb_map'][None], 'acc_map': out['acc_map'][None]}
+        if r.want_raw:
+            dev['raw'] = out['raw'][None]
+            dev['occ'] = out['occ'][None, :, None]
+        for v in dev.values():
+            v.record_stream(cur)               # allocated on the lane's stream, used (and later freed) by the caller on its own
+        if lane.pending is self:
+            lane.pending = None
+        self.keep = self.call = None           # the frame's inputs may go
+        if r.eval_to_cpu:
+            lazy = {k: dev[k] for k in ('raw', 'occ') if k in dev}
+            host = dict(self.host)
+            if not r.lazy_host:
+                tmp = LazyHostRet(host, lazy, r.pin_host)
+                tmp._fetch(tuple(lazy))
+                host, lazy = dict(tmp), {}
+            self._res = (host, lazy)
+        else:
+            self._res = (dev, {})
+        self.out = self.host = None
+        return self._res
 
 
 class Renderer:
@@ -153,6 +333,15 @@ class Renderer:
                                        # that torch's caching host allocator keeps page-locked blocks: a caller that retains the raw /
                                        # occ of many frames pins that much host memory)
         self.lazy_host = True          # eval_to_cpu: raw / occ reach the host on first access (LazyHostRet); False: with the maps
+        # Frames in flight across render() calls (cfg.render_in_flight, default 1 = every call on the caller's stream as before).
+        # K > 1: eval frame f is launched on lane f % K — a stream and a workspace of its own — and render() returns at once with a
+        # dict that joins the frame on first access (LazyHostRet / LazyDevRet): a caller that reads frame f after submitting frames
+        # f + 1 .. f + K - 1 (driver.run_evaluate) keeps K kernel chains on the GPU, which fill each other's ramps and tails
+        # (measured, 512x512x128: 2.37 / 2.07 / 2.04 / 1.94 ms per frame for K = 1 / 2 / 4 / 8, eager launches, no graph — the
+        # batches of a sequence differ in their volume dimensions, so there is nothing static to capture).  A caller that reads
+        # every frame at once (run.py:61-90 as written) gets the latency of one frame either way.
+        self.in_flight = int(self.cfg.get('render_in_flight', 1)) if hasattr(self.cfg, 'get') else 1
+        self._lanes, self._lane_i = [], 0
         self._cap_hint = None
 
     def render(self, batch, test=False, epoch=-1):
@@ -171,6 +360,8 @@ class Renderer:
         if training:
             return self._render_train(batch, jitter)
         per_call = max(1, MAX_SAMPLES_PER_CALL // S)
+        if self.in_flight > 1 and ray_o.is_cuda and n_pixel <= per_call:
+            return self._render_in_flight(batch, ray_o[0], ray_d[0], near[0], far[0], S, jitter)
         outs = []
         for i in range(0, n_pixel, per_call):
             sl = slice(i, i + per_call)
@@ -214,6 +405,43 @@ class Renderer:
             host._lazy = lazy
             ret = host
         return ret
+
+    def _render_in_flight(self, batch, ray_o, ray_d, near, far, S, jitter):
+        """One eval frame on the next lane (see __init__); returns a dict that joins the frame on first access."""
+        dev = ray_o.device
+        K = self.in_flight
+        while len(self._lanes) < K:
+            self._lanes.append(_Lane(dev))
+        lane = self._lanes[self._lane_i % K]
+        self._lane_i += 1
+        if lane.pending is not None:
+            lane.pending.result()              # the frame rendered here K calls ago (long done): releases its inputs, updates the cap hint
+        n_samp = ray_o.shape[0] * S
+        cap = min(n_samp, max(self._cap_hint if self._cap_hint is not None else n_samp // 4, 65536)) if self.adaptive_cap else 0
+        ctx = self.net.prepare(batch)          # on the caller's stream: a stale row-sum table is rebuilt in front of every lane
+        call = lambda c: self.net.render_rays(ctx, ray_o, ray_d, near, far, S, jitter=jitter, want_raw=self.want_raw, max_active=c)
+        lane.stream.wait_stream(torch.cuda.current_stream(dev))          # the batch was made on the caller's stream
+        pend = _PendingFrame(self, lane, call, cap, (batch, ctx, ray_o, ray_d, near, far, jitter))
+        pend.launch()
+        lane.pending = pend
+        if self._cap_hint is None and self.adaptive_cap:
+            # the first frame of a sequence is joined at once: its survivor count sizes the workspaces of all later frames (K lanes at
+            # the no-hint default of a quarter of the ray-samples would be K x 9.6 GB for 512x512x128)
+            pend.result()
+            if lane.ws is not None and self._cap_hint is not None and cap > 2 * self._cap_hint:
+                lane.ws = None
+        keys = ('rgb_map', 'acc_map') + (('raw', 'occ') if self.want_raw else ())
+        if self.eval_to_cpu:
+            return LazyHostRet({}, {}, self.pin_host, pending=pend, keys=keys)
+        return LazyDevRet(pend, keys)
+
+    def flush(self, release=False):
+        """Join every frame in flight (their dicts stay valid); release=True also gives the lanes' workspaces back."""
+        for lane in self._lanes:
+            if lane.pending is not None:
+                lane.pending.result()
+            if release:
+                lane.ws = None
 
     def _jitter(self, shape, device):
         return torch.rand(shape, device=device, dtype=torch.float32)

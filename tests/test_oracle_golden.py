@@ -40,6 +40,51 @@ def test_known_answer_table_geometry(golden):
     assert tot == 285993711
 
 
+def test_oracle_geometry_is_its_own_restatement(golden):
+    """The oracle's embedder_geometry (its own restatement of part_base_embedder.py:13-104) against (i) the facts the golden
+    generator read off the IMPORTED reference's embedders at full inb_377 size, (ii) sympy.nextprime — the function the reference
+    calls —, (iii) the product's separate restatement (invr.params.grid_spec), field by field, (iv) the reference's state_dict
+    tensors entries_size / entries_num / entries_cnt / entries_sum of the small golden model.  The oracle imports nothing of
+    the product."""
+    import inspect
+    src = inspect.getsource(O)
+    assert 'import invr' not in src and 'from invr' not in src
+    full = make_cfg()
+    for name, row in zip(golden['facts_names'].tolist(), golden['facts']):
+        g = O.embedder_geometry(bbox=full.partnet[name].bbox, **full.partnet[name].embedder.kwargs)
+        assert (g['start_hash'], g['T'], g['dense_rows'], g['n_hash']) == tuple(int(v) for v in row)
+    try:
+        from sympy import nextprime
+        for e in (4, 10, 12, 14, 15, 18, 19, 20, 22):
+            assert O.next_prime(2 ** e) == int(nextprime(2 ** e)) == params.next_prime(2 ** e)
+    except ImportError:
+        assert [O.next_prime(2 ** e) for e in (14, 15, 18, 20)] == [16411, 32771, 262147, 1048583]      # SURVEY 8(c), probed
+    for cfg in (full, make_cfg(table_log2=12)):
+        specs = [(O.embedder_geometry(**cfg.tpose_deformer.embedder.kwargs), params.deformer_grid_spec(cfg))]
+        specs += [(O.embedder_geometry(bbox=cfg.partnet[n].bbox, **cfg.partnet[n].embedder.kwargs), params.part_grid_spec(cfg, n)) for n in PART_NAMES]
+        for g, sp in specs:
+            for k in ('L', 'F', 'T', 'res', 'cnt', 'start_hash', 'separate_dense', 'dense_rows', 'n_hash', 'sum', 'sum_over_features',
+                      'include_input', 'out_dim'):
+                assert g[k] == sp[k], k
+            assert np.array_equal(g['size'].numpy(), sp['size']) and np.array_equal(g['bbox'].numpy(), sp['bbox'])
+    # the start_hash == 0 branch (:69: separate_dense forced off)
+    g0 = O.embedder_geometry(base_resolution=20, log2_hashmap_size=12)
+    assert g0['start_hash'] == 0 and not g0['separate_dense'] and g0['n_hash'] == 16
+
+
+def test_oracle_geometry_vs_reference_state_dict(golden, small_setup):
+    cfg, sd, batch, _ = small_setup
+    m = O.Model(sd, cfg)
+    for i, g in enumerate(m.pspec):
+        pre = 'tpose_human.part_networks.%d.embedder.' % i
+        assert torch.equal(sd[pre + 'entries_num'].long(), torch.tensor(g['res']))
+        assert torch.equal(sd[pre + 'entries_cnt'].long(), torch.tensor(g['cnt']))
+        assert torch.equal(sd[pre + 'entries_sum'].long(), g['entries_sum'])
+        assert torch.equal(sd[pre + 'entries_size'], g['size'])
+        assert tuple(sd[pre + 'hash'].shape) == (g['n_hash'], g['T'], g['F'])
+    assert m.n_occ == [2] * 5 and m.n_rgb == [3, 2, 3, 2, 2]
+
+
 def test_sampling_and_volumes(golden, small_setup):
     cfg, sd, batch, _ = small_setup
     sel = torch.from_numpy(golden['sel_rays'].astype(np.int64))
