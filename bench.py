@@ -161,6 +161,7 @@ def train_probe(net, dev, S, iters, fused=None):
     wrap = NetworkWrapper(net)
     opt = driver.make_optimizer(net, fused=fused)
     opt_name = '%s.%s' % (type(opt).__module__, type(opt).__name__)
+    adopted = lambda: getattr(opt, '_invr_inner', None) is not None
     for i in range(4):
         driver.train_step(wrap, opt, batch, i + 2)
     torch.cuda.synchronize()
@@ -187,8 +188,9 @@ def train_probe(net, dev, S, iters, fused=None):
         del net._grad_arena
     for p_ in net.parameters():
         p_.grad = None
+    was_adopted = adopted()
     del opt
-    return {'ms_per_iter': dt * 1e3, 'synchronised_ms': {'forward': parts[0] * 1e3, 'backward': parts[1] * 1e3, 'optimizer_step': parts[2] * 1e3}, 'rays_per_iter': int(batch['ray_o'].shape[1]), 'samples_per_ray': S,
+    return {'adopted_by_fused_step': was_adopted, 'ms_per_iter': dt * 1e3, 'synchronised_ms': {'forward': parts[0] * 1e3, 'backward': parts[1] * 1e3, 'optimizer_step': parts[2] * 1e3}, 'rays_per_iter': int(batch['ray_o'].shape[1]), 'samples_per_ray': S,
             'ray_samples_per_sec': batch['ray_o'].shape[1] * S / dt, 'optimizer': opt_name,
             'parameters_updated': int(sum(p.numel() for p in net.parameters() if p.requires_grad)), 'final_loss': float(loss)}
 
@@ -842,8 +844,9 @@ def main():
                 torch.cuda.empty_cache()
                 line['api_train_step'] = train_probe(net, dev, S, args.train_iters, fused=False)
                 line['api_train_step']['note'] = ('NetworkWrapper + the reference\'s own optimizer construction (torch.optim.Adam, 186 one-tensor '
-                                                  'groups) + its step form: the drop-in training call; train_step = the same with driver.make_optimizer (FusedAdam) — what one added line, '
-                                                  '`optimizer = invr.optim.fuse(optimizer, network)` after the reference\'s make_optimizer, turns the first into')
+                                                  'groups) + its step form, nothing else changed: the drop-in training call.  The optimizer object is bound to the fused step at its first '
+                                                  'step() (invr.optim.adopt_on_first_step, installed by NetworkWrapper: shared param_groups / state, gradient arena); '
+                                                  'INVR_NO_OPTIM_HOOK=1 leaves torch\'s own Adam (9.3 ms in round 4).  train_step = the same with driver.make_optimizer (FusedAdam)')
             except Exception as e:
                 line['api_train_step'] = {'error': repr(e)}
         if world == 1 and not args.no_cpu_baseline:

@@ -22,6 +22,8 @@ def FORCE_COLLECTIVES():
 def tile_indices(n_rays, rank, world, tile=DEFAULT_TILE, device='cpu'):
     """Ray indices owned by `rank`: tiles rank, rank+world, rank+2*world, ... of `tile` rays."""
     n_tiles = (n_rays + tile - 1) // tile
+    if rank >= n_tiles:              # fewer tiles than ranks: this rank renders nothing (torch.arange refuses start > end)
+        return torch.empty(0, dtype=torch.int64, device=device)
     mine = torch.arange(rank, n_tiles, world, device=device)
     idx = (mine[:, None] * tile + torch.arange(tile, device=device)[None, :]).reshape(-1)
     return idx[idx < n_rays]

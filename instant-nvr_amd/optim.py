@@ -181,3 +181,105 @@ def fuse(optimizer, net=None):
     if net is not None and hasattr(net, 'tpose_human') and getattr(net, 'cfg', {}).get('train_fused', True):
         new.attach(net)
     return new
+
+
+# ---- drop-in: the reference's own optimizer, unchanged, at the fused step's speed ---------------------------------------------
+# train_net.py builds torch.optim.Adam over net.named_parameters() (lib/train/optimizer.py:15-31), hands it to its schedulers and to
+# Trainer.train (trainer.py:139-149: zero_grad -> backward -> scaler.step(optimizer)).  With that optimizer an iteration is 9.3 ms —
+# 1.09 GB of dense table gradients and torch's foreach Adam over 286 M parameters — against 3.7 ms with FusedAdam + the gradient
+# arena.  `adopt_on_first_step(net)` (called by invr.trainer.NetworkWrapper) closes the gap without an edit of the host: a global
+# optimizer-step pre-hook recognises, at its FIRST step, a plain torch.optim.Adam whose parameters are exactly this network's, and
+# from then on that optimizer OBJECT (the one the host's schedulers and checkpoints hold) steps through invr_adam_step:
+#   * an inner FusedAdam SHARES the host optimizer's `param_groups` list and `state` dict — a scheduler's group['lr'] writes are
+#     seen, the moments live where optimizer.state_dict() / save_model (net_utils.py:461-479) expect them, same layout;
+#   * the host object's step / zero_grad / state_dict / load_state_dict are bound to the inner optimizer's;
+#   * the gradient arena is attached (row-scalar table gradients: no 1.09 GB dense gradient) unless a process group exists — a
+#     DistributedDataParallel wrapper (trainer.py:21-26) reduces p.grad and expects every parameter to receive one, which the arena
+#     bypasses — in which case the dense gradients stay and only the update is fused.
+# The first step itself is taken by the fused kernel from the dense gradients of the first backward; torch's own step, which runs
+# right after the hook, then finds no gradients and does nothing.  INVR_NO_OPTIM_HOOK=1 or cfg.fused_optimizer_hook False: off.
+import os as _os
+import types as _types
+import weakref as _weakref
+
+_ADOPT_NETS = _weakref.WeakSet()
+_HOOK = [None]
+
+
+def _adam_matches(opt, net):
+    if type(opt) is not torch.optim.Adam or getattr(opt, '_invr_inner', None) is not None:
+        return False
+    groups = opt.param_groups
+    if any(g.get('amsgrad') or g.get('maximize') or g.get('capturable') or g.get('differentiable') for g in groups):
+        return False
+    if len({(tuple(g['betas']), g['eps']) for g in groups}) != 1:
+        return False
+    mine = {id(p) for p in net.parameters() if p.requires_grad}
+    theirs = [p for g in groups for p in g['params']]
+    if {id(p) for p in theirs} != mine:
+        return False
+    return all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in theirs)
+
+
+def adopt(opt, net, attach=None):
+    """Bind the host's torch.optim.Adam `opt` (over exactly `net`'s parameters) to the fused step; returns the inner FusedAdam."""
+    d = opt.defaults
+    inner = FusedAdam([{'params': [torch.zeros(1)]}], d['lr'], betas=d['betas'], eps=d['eps'], weight_decay=d['weight_decay'])
+    inner.param_groups = opt.param_groups                   # the SAME list of the SAME dicts
+    inner.state = opt.state                                 # the SAME state mapping (step / exp_avg / exp_avg_sq per parameter)
+    if attach is None:
+        import torch.distributed as dist
+        attach = not (dist.is_available() and dist.is_initialized())
+    if attach and hasattr(net, 'tpose_human') and getattr(net, 'cfg', {}).get('train_fused', True):
+        inner.attach(net)
+    orig_zero, orig_sd, orig_load = opt.zero_grad, opt.state_dict, opt.load_state_dict
+
+    def step(self, closure=None):
+        self._opt_called = True                             # (what torch's lr_scheduler wrapper of step() records)
+        return inner.step(closure)
+
+    def zero_grad(self, set_to_none=True):
+        orig_zero(set_to_none)
+        if inner.arena is not None:
+            inner.arena.zero()
+
+    def state_dict(self):
+        inner._flush_steps()
+        return orig_sd()
+
+    def load_state_dict(self, sd):
+        inner._flush_steps()
+        orig_load(sd)
+        inner.state, inner.param_groups = self.state, self.param_groups          # (load_state_dict rebinds both)
+        inner._plan_key = None
+    opt.step = _types.MethodType(step, opt)
+    opt.zero_grad = _types.MethodType(zero_grad, opt)
+    opt.state_dict = _types.MethodType(state_dict, opt)
+    opt.load_state_dict = _types.MethodType(load_state_dict, opt)
+    opt._invr_inner = inner
+    return inner
+
+
+def _step_pre_hook(opt, args, kwargs):
+    if not _ADOPT_NETS or type(opt) is not torch.optim.Adam or getattr(opt, '_invr_inner', None) is not None:
+        return None
+    for net in list(_ADOPT_NETS):
+        if _adam_matches(opt, net):
+            inner = adopt(opt, net)
+            inner.step()                                    # this step, from the dense gradients the first backward produced
+            for g in opt.param_groups:                      # ... and torch's own step, which follows this hook, finds nothing to do
+                for p in g['params']:
+                    p.grad = None
+            break
+    return None
+
+
+def adopt_on_first_step(net):
+    """Register `net` for the adoption above (idempotent; a weak reference)."""
+    if _os.environ.get('INVR_NO_OPTIM_HOOK', '0') == '1' or not getattr(net, 'cfg', {}).get('fused_optimizer_hook', True):
+        return False
+    _ADOPT_NETS.add(net)
+    if _HOOK[0] is None:
+        from torch.optim.optimizer import register_optimizer_step_pre_hook
+        _HOOK[0] = register_optimizer_step_pre_hook(_step_pre_hook)
+    return True

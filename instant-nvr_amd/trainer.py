@@ -59,6 +59,10 @@ class NetworkWrapper(nn.Module):
         self.net = net
         self.renderer = Renderer(self.net)
         self.cfg = cfg = getattr(net, 'cfg', global_cfg)
+        # a torch.optim.Adam the host builds over this network's parameters (lib/train/optimizer.py:15-31) is bound to the fused
+        # step at its first step() — invr.optim.adopt_on_first_step: train_net.py unchanged, FusedAdam's speed
+        from .optim import adopt_on_first_step
+        adopt_on_first_step(net)
         self.img2mse = lambda x, y: torch.mean((x - y) ** 2)
         if cfg.get('use_lpips', False):                                                  # inb_trainer.py:28-29
             if perceptual_loss is None:

@@ -192,3 +192,32 @@ def test_grad_reducer_world2_averages_every_block():
     ret = mgr.dict()
     mp.spawn(_reduce_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
     assert all(ret[r] for r in range(2)), dict(ret)
+
+
+# ---- world 8: the node size of BASELINE configs[2] / configs[4] (one process per GPU; 8 gloo ranks on the CPU here) ----------
+def test_frame_set_world8_ragged_frames_one_exchange():
+    """8 ranks, K = 5 frames of different sizes — incl. a frame with fewer tiles than ranks (ranks that render nothing) and a
+    ragged last tile: ONE padded all-gather per replay, every rank ends with every full frame, replay after replay."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_frameset_worker, args=(8, _free_port(), (4097, 30, 517, 64, 1000), 64, ret), nprocs=8, join=True)
+    assert all(ret[r] for r in range(8)), dict(ret)
+
+
+def test_gather_world8_ragged_and_fewer_tiles_than_ranks():
+    _run(8, 4097, 64)          # 65 tiles over 8 ranks: shards of 9 / 8 tiles, last tile one ray
+    _run(8, 200, 64)           # 4 tiles: ranks 4..7 render nothing
+
+
+def test_async_gather_world8_one_frame_in_flight():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_async_worker, args=(8, _free_port(), 3000, 64, ret), nprocs=8, join=True)
+    assert all(ret[r] for r in range(8)), dict(ret)
+
+
+def test_grad_reducer_world8_averages_every_block():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_reduce_worker, args=(8, _free_port(), ret), nprocs=8, join=True)
+    assert all(ret[r] for r in range(8)), dict(ret)

@@ -487,3 +487,60 @@ def test_configs3_real_shape_three_steps_vs_oracle_autograd(full_net):
                 p.copy_(sd0[k])
         for p in net.parameters():
             p.grad = None
+
+
+def test_reference_built_adam_is_adopted_by_the_fused_step():
+    """train_net.py unchanged: torch.optim.Adam built the reference's way (lib/train/optimizer.py:15-31: one group per tensor) over a
+    network behind invr's NetworkWrapper, a scheduler built ON that optimizer (make_lr_scheduler), the reference's step form.
+    At its first step() the optimizer object is bound to the fused step (invr.optim.adopt_on_first_step): it stays the SAME
+    torch.optim.Adam object — the scheduler's lr writes are honoured, its state_dict has torch's layout and loads into a fresh
+    torch.optim.Adam — and the run follows the FusedAdam + arena run built by driver.make_optimizer."""
+    cfg = make_cfg(table_log2=12, N_samples=32, smpl_thresh=0.1, pair_loss_weight=1e-4)
+    LR, EPOCHS, EP_ITER = 1e-3, 2, 4
+    sd0 = params.init_state_dict(cfg, seed=19)
+    batches = [patch_batch(20, seed=4, frame=10 + 7 * k, centre=(250 + 9 * k, 262 - 11 * k)) for k in range(3)]
+    gbs = [{k: v.to(DEV) for k, v in b.items()} for b in batches]
+    g = torch.Generator().manual_seed(29)
+    jit = [torch.rand(b['ray_o'].shape[1], cfg.N_samples, generator=g).to(DEV) for b in batches]
+    noi = [torch.rand(b['ray_o'].shape[1] * cfg.N_samples * 5, 3, generator=g).to(DEV) for b in batches]
+    runs = {}
+    for mode in ('reference_adam', 'fused'):
+        net = Network(cfg=copy.deepcopy(cfg))
+        net.load_state_dict(sd0, strict=True)
+        net = net.to(DEV).train()
+        wrap = NetworkWrapper(net)
+        opt = driver.make_optimizer(net, lr=LR, eps=1e-15, fused=(mode == 'fused'))
+        assert (type(opt) is torch.optim.Adam) == (mode == 'reference_adam')
+        sched = driver.ExponentialLR(opt, decay_epochs=1, gamma=0.5)
+        cur = {}
+
+        def batch_fn(epoch, index, cur=cur):
+            cur['k'] = (epoch * EP_ITER + index) % len(gbs)
+            return dict(gbs[cur['k']])
+        wrap.renderer._jitter = lambda shape, device, cur=cur: jit[cur['k']]
+        wrap.renderer._pair_noise_dense = lambda rows, device, cur=cur: noi[cur['k']][:rows]
+        out = driver.train(wrap, opt, batch_fn, EPOCHS, EP_ITER, scheduler=sched)
+        torch.cuda.synchronize()
+        runs[mode] = (np.array(out['losses']), {k: v.detach().cpu() for k, v in net.state_dict().items()}, opt, net, sched)
+    l_ref, sd_ref, opt, net, sched = runs['reference_adam']
+    l_fus, sd_fus = runs['fused'][:2]
+    assert type(opt) is torch.optim.Adam and getattr(opt, '_invr_inner', None) is not None          # same object, adopted
+    assert getattr(net, '_grad_arena', None) is opt._invr_inner.arena is not None                 # row-scalar table gradients from step 2 on
+    assert opt._invr_inner.param_groups is opt.param_groups and opt._invr_inner.state is opt.state
+    assert abs(opt.param_groups[0]['lr'] - LR * 0.5 ** EPOCHS) < 1e-12                            # the scheduler drove the object it was built on
+    assert np.all(np.isfinite(l_ref)) and np.abs(l_ref - l_fus).max() <= 2e-4 * max(1.0, np.abs(l_fus).max()), (l_ref, l_fus)
+    frac = []
+    for k in sd_ref:
+        if sd_ref[k].is_floating_point():
+            d = (sd_ref[k].double() - sd_fus[k].double()).abs()
+            assert float(d.max()) <= 2 * EPOCHS * EP_ITER * LR * 1.01, k          # (unordered float atomics + eps 1e-15: a few elements move by +-lr)
+            if d.numel() >= 100000:          # the tables: all but a sliver of their rows agree to rounding; the small MLP tensors see every
+                frac.append(float((d <= 1e-6 + 1e-5 * sd_fus[k].double().abs()).double().mean()))          # pair's noise (the loss curve pins them)
+    assert len(frac) >= 5 and min(frac) >= 0.98, frac
+    osd = opt.state_dict()                                                                        # torch's layout, current step counts
+    assert len(osd['state']) == len(opt.param_groups) and all(float(s['step']) == EPOCHS * EP_ITER for s in osd['state'].values())
+    fresh = torch.optim.Adam([{'params': [p]} for p in net.parameters() if p.requires_grad], LR, eps=1e-15)
+    fresh.load_state_dict(osd)                                                                    # net_utils.load_model's resume path
+    assert float(fresh.state_dict()['state'][0]['step']) == EPOCHS * EP_ITER
+    opt.load_state_dict(osd)                                                                      # ... and into the adopted object itself
+    assert opt._invr_inner.state is opt.state
