@@ -630,6 +630,7 @@ def main():
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             ok = int(flag.item())
         if ok:
+            mode_name = name
             break
         fs = None
         torch.cuda.empty_cache()
@@ -766,7 +767,10 @@ def main():
                 'frames': '%d frames of a synthetic sequence (same body, %d poses / orientations / latent codes; frame 0 = the frame of the '
                           'round-1..3 lines) rendered side by side by ONE hipGraph replay (parallel branches, invr.frames.FrameSet); a step is '
                           'one frame, every frame does all of its per-frame scene work' % (K, K),
-                'parallelism': 'tile-cyclic ray shards x%d, full replicas, 1 all-gather per %d frames inside the same graph replay' % (world, K),
+                'render_mode': mode_name,
+                'parallelism': ('tile-cyclic ray shards x%d, full replicas, 1 all-gather per %d frames ' % (world, K)) +
+                               ('inside the same graph replay' if exchange_captured else 'issued from the host behind the %s' % ('graph replay' if use_graph else 'eager launches'))
+                               if world > 1 else 'one GPU: whole frames',
                 'exchange_only_ms_per_replay': exchange_ms, 'exchange_captured_in_graph': exchange_captured,
                 'rays_per_sec': mean_rays * args.steps / dt,
                 'note': 'value counts every ray-sample of the frames; %.1f %% of them survive the near-surface cull (the camera sits at %.1f m so '

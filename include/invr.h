@@ -125,6 +125,10 @@ typedef struct InvrScene {
 #define INVR_STAT_OVERFLOW 6      /* non-zero if max_active was too small (results truncated)       */
 
 const char* invr_last_error(void);
+/* Version of THIS header's ABI: bumped by every incompatible change of a struct or a signature.  A host built against another
+ * version must refuse the library (invr._abi.lib() does).  History: 1 = rounds 1-3; 2 = round 4 (InvrScene grew composite_eps / aggr,
+ * the Adam entry points take the betas as double, launch-level epsilon of the compositing) + round 5 (invr_part_encode_fwd). */
+#define INVR_ABI_VERSION 2
 int invr_version(void);
 /* sizeof() of the ABI structs as compiled (0 InvrGrid, 1 InvrMlp, 2 InvrPart, 3 InvrModel,
  * 4 InvrScene, 5 InvrWsLayout, 6 InvrMlpBwdOut, 7 InvrAdamTensor): lets a binding verify its struct mirrors. */

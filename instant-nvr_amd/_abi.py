@@ -94,6 +94,7 @@ EXPORTS = ['invr_last_error', 'invr_version', 'invr_sizeof', 'invr_workspace_byt
            'invr_knn_neighbors', 'invr_pose_points', 'invr_adam_advance', 'invr_train_workspace_bytes', 'invr_train_fwd',
            'invr_train_bwd', 'invr_expand_row_grad', 'invr_train_loss_fwd', 'invr_train_loss_bwd',
            'invr_part_encode_workspace', 'invr_part_encode_fwd']
+ABI_VERSION = 2          # include/invr.h INVR_ABI_VERSION
 BWD_HEAD, BWD_DEFORMER, BWD_ALL = 1, 64, 127
 NUM_STAGES = 14
 STAGE_NAMES = ['cull', 'knn', 'warp'] + ['encode_%d' % p for p in range(5)] + ['mlp_%d' % p for p in range(5)] + ['composite']
@@ -110,6 +111,9 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.invr_last_error.restype = C.c_char_p
         L.invr_version.restype = C.c_int
+        if L.invr_version() != ABI_VERSION:
+            raise RuntimeError('libinvr.so speaks ABI version %d, this binding %d (include/invr.h INVR_ABI_VERSION): rebuild the library '
+                               '(python -m invr.build)' % (L.invr_version(), ABI_VERSION))
         L.invr_sizeof.restype = C.c_size_t
         L.invr_sizeof.argtypes = [C.c_int32]
         for i, t in enumerate((InvrGrid, InvrMlp, InvrPart, InvrModel, InvrScene, InvrWsLayout, InvrMlpBwdOut, InvrAdamTensor, InvrTrainGrads)):

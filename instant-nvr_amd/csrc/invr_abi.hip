@@ -21,7 +21,7 @@ void invr_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* invr_last_error(void) { return g_err; }
-extern "C" int invr_version(void) { return 1; }
+extern "C" int invr_version(void) { return INVR_ABI_VERSION; }
 extern "C" size_t invr_sizeof(int32_t which) {
     switch (which) {
         case 0: return sizeof(InvrGrid);

@@ -17,6 +17,11 @@ import torch.distributed as dist
 from .dist import DEFAULT_TILE, FORCE_COLLECTIVES, gather_plan
 
 
+def _packet_capture_off():
+    import sys
+    return bool(getattr(sys.modules.get('invr'), 'PACKET_CAPTURE_OFF', False))
+
+
 def exchange_plan(n_rays, world, tile=DEFAULT_TILE, device='cpu'):
     """Layout of ONE all-gather for K frames: every rank sends `rows` = sum_k mx_k rows (frame k at row offset off[k], padded to
     the largest shard mx_k of that frame); ray i of frame k then sits at row src[k][i] of the gathered (world * rows, 4) buffer."""
@@ -119,6 +124,17 @@ class FrameSet:
                     self._render(k)
             for k in range(self.K):
                 cur.wait_stream(self.streams[k])
+            if self.exchange and self.K == 1 and not _packet_capture_off():
+                # one frame + a collective = a graph without parallel branches, which this runtime replays from pre-built packets —
+                # the path that faults beside RCCL (invr/__init__.py) unless it was switched off before HIP initialised: give the
+                # graph a second, empty branch instead
+                self._side = getattr(self, '_side', None) or torch.zeros(64, device=self.device)
+                extra = torch.cuda.Stream(self.device)
+                self.streams.append(extra)
+                extra.wait_stream(cur)
+                with torch.cuda.stream(extra):
+                    self._side.add_(0.0)
+                cur.wait_stream(extra)
             if self.exchange_captured:
                 self._exchange()
         torch.cuda.synchronize(self.device)

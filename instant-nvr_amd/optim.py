@@ -252,6 +252,7 @@ def adopt(opt, net, attach=None):
         orig_load(sd)
         inner.state, inner.param_groups = self.state, self.param_groups          # (load_state_dict rebinds both)
         inner._plan_key = None
+    step._wrapped_by_lr_sched = True                        # (torch's lr_scheduler looks for its own step wrapper's mark, else it warns)
     opt.step = _types.MethodType(step, opt)
     opt.zero_grad = _types.MethodType(zero_grad, opt)
     opt.state_dict = _types.MethodType(state_dict, opt)

@@ -25,7 +25,10 @@ def test_library_exports_header_symbols():
     for n in names:
         assert hasattr(L, n), n
     assert sorted(_abi.EXPORTS) == names
-    assert L.invr_version() == 1
+    assert L.invr_version() == _abi.ABI_VERSION == 2
+    import re
+    hdr = open(os.path.join(ROOT, 'include', 'invr.h')).read()
+    assert int(re.search(r'#define INVR_ABI_VERSION (\d+)', hdr).group(1)) == _abi.ABI_VERSION
 
 
 def test_workspace_query_and_error_path():
