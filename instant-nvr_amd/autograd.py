@@ -630,3 +630,35 @@ class LazyTrainRet(dict):
     def items(self):
         self._fill()
         return dict.items(self)
+
+    # every other dict view fills first too (dict's C fast paths — values(), iteration, len(), dict(ret), copy() — would not see the
+    # thunks / lazy tensors otherwise: a host loop `for k, v in dict(ret).items()` must find offset_loss / pair_loss / resd ...)
+    def values(self):
+        self._fill()
+        return dict.values(self)
+
+    def __iter__(self):
+        self._fill()
+        return dict.__iter__(self)
+
+    def __len__(self):
+        return dict.__len__(self) + len(self._thunks) + (0 if self._done else sum(1 for k in self._lazy if not dict.__contains__(self, k)))
+
+    def copy(self):
+        self._fill()
+        return dict(self)
+
+    def pop(self, k, *default):
+        if k in self:
+            self[k]
+        return dict.pop(self, k, *default)
+
+    def __eq__(self, other):
+        self._fill()
+        return dict.__eq__(self, other)
+
+    __hash__ = None
+
+    def __reduce__(self):
+        self._fill()
+        return (dict, (dict(self),))

@@ -11,6 +11,12 @@
 static_assert(sizeof(float*) == 8, "64-bit");
 #define ADAM_BLOCK 256
 #define ADAM_CHUNK 16384            // elements per workgroup
+#ifndef ADAM_NT
+#define ADAM_NT 1
+#endif
+#ifndef ADAM_UNROLL
+#define ADAM_UNROLL 4
+#endif
 
 struct AdamTensor {                 // device-resident table, one entry per tensor that has a gradient this step (InvrAdamTensor)
     float* p; const float* g; float* m; float* v;
@@ -48,33 +54,59 @@ __global__ __launch_bounds__(ADAM_BLOCK) void k_adam(const AdamTensor* __restric
         const float denom = sqrtf(v) / t.bc2_sqrt + eps;
         p = p - step_size * (m / denom);                           // addcdiv_(m, denom, value=-step_size)
     };
-    if (t.grad_shift > 0) {         // row-scalar gradient: 16 B of p / m / v per lane, ONE gradient load per 2^shift elements
-        const int sh = t.grad_shift;
-        const bool vec4 = ((((uintptr_t)t.p | (uintptr_t)t.m | (uintptr_t)t.v) & 15) == 0) && sh >= 2;
-        if (vec4) {
-            for (int64_t i = base + (int64_t)threadIdx.x * 4; i + 3 < end; i += ADAM_BLOCK * 4) {
-                float4 p = *reinterpret_cast<float4*>(t.p + i), m = *reinterpret_cast<float4*>(t.m + i), v = *reinterpret_cast<float4*>(t.v + i);
-                const float g = t.g[i >> sh];
-                upd(p.x, g, m.x, v.x); upd(p.y, g, m.y, v.y); upd(p.z, g, m.z, v.z); upd(p.w, g, m.w, v.w);
-                *reinterpret_cast<float4*>(t.p + i) = p; *reinterpret_cast<float4*>(t.m + i) = m; *reinterpret_cast<float4*>(t.v + i) = v;
-            }
-            for (int64_t i = base + ((end - base) & ~(int64_t)3) + threadIdx.x; i < end; i += ADAM_BLOCK) upd(t.p[i], t.g[i >> sh], t.m[i], t.v[i]);
-        } else {
-            for (int64_t i = base + threadIdx.x; i < end; i += ADAM_BLOCK) upd(t.p[i], t.g[i >> sh], t.m[i], t.v[i]);
-        }
-        return;
-    }
-    const bool vec = ((((uintptr_t)t.p | (uintptr_t)t.g | (uintptr_t)t.m | (uintptr_t)t.v) & 15) == 0);
+    // 28 B per parameter stream through this kernel once per step and nothing of it is read again before the next step has streamed
+    // another 6.9 GB through the caches: nontemporal loads / stores (no L2 / Infinity-Cache allocation), and ADAM_UNROLL float4 per
+    // array and thread in flight before the first use (the loop form issued one float4 per array, waited, computed, stored: too
+    // few bytes in flight per CU for the HBM latency).  ADAM_NT=0 / ADAM_UNROLL=1: the round-4 form (A/B builds).
+    auto ld4 = [](const float* q) -> float4 {
+#if ADAM_NT
+        typedef float v4 __attribute__((ext_vector_type(4)));
+        const v4 r = __builtin_nontemporal_load(reinterpret_cast<const v4*>(q));
+        return make_float4(r.x, r.y, r.z, r.w);
+#else
+        return *reinterpret_cast<const float4*>(q);
+#endif
+    };
+    auto st4 = [](float* q, const float4& x) {
+#if ADAM_NT
+        typedef float v4 __attribute__((ext_vector_type(4)));
+        v4 r = {x.x, x.y, x.z, x.w};
+        __builtin_nontemporal_store(r, reinterpret_cast<v4*>(q));
+#else
+        *reinterpret_cast<float4*>(q) = x;
+#endif
+    };
+    const int sh = t.grad_shift;
+    const bool vec = ((((uintptr_t)t.p | (uintptr_t)t.m | (uintptr_t)t.v | (sh > 0 ? (uintptr_t)0 : (uintptr_t)t.g)) & 15) == 0) && (sh == 0 || sh >= 2);
     if (vec) {
-        for (int64_t i = base + (int64_t)threadIdx.x * 4; i + 3 < end; i += ADAM_BLOCK * 4) {
-            float4 p = *reinterpret_cast<float4*>(t.p + i), m = *reinterpret_cast<float4*>(t.m + i), v = *reinterpret_cast<float4*>(t.v + i);
-            const float4 g = *reinterpret_cast<const float4*>(t.g + i);
-            upd(p.x, g.x, m.x, v.x); upd(p.y, g.y, m.y, v.y); upd(p.z, g.z, m.z, v.z); upd(p.w, g.w, m.w, v.w);
-            *reinterpret_cast<float4*>(t.p + i) = p; *reinterpret_cast<float4*>(t.m + i) = m; *reinterpret_cast<float4*>(t.v + i) = v;
+        constexpr int U = ADAM_UNROLL;
+        int64_t i = base + (int64_t)threadIdx.x * 4;
+        for (; i + (int64_t)(U - 1) * ADAM_BLOCK * 4 + 3 < end; i += (int64_t)U * ADAM_BLOCK * 4) {
+            float4 p[U], m[U], v[U], g[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t j = i + (int64_t)u * ADAM_BLOCK * 4;
+                p[u] = ld4(t.p + j); m[u] = ld4(t.m + j); v[u] = ld4(t.v + j);
+                if (sh > 0) { const float gs = t.g[j >> sh]; g[u] = make_float4(gs, gs, gs, gs); }      // row scalar: one load per 2^shift elements
+                else g[u] = ld4(t.g + j);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t j = i + (int64_t)u * ADAM_BLOCK * 4;
+                upd(p[u].x, g[u].x, m[u].x, v[u].x); upd(p[u].y, g[u].y, m[u].y, v[u].y); upd(p[u].z, g[u].z, m[u].z, v[u].z); upd(p[u].w, g[u].w, m[u].w, v[u].w);
+                st4(t.p + j, p[u]); st4(t.m + j, m[u]); st4(t.v + j, v[u]);
+            }
         }
-        for (int64_t i = base + ((end - base) & ~(int64_t)3) + threadIdx.x; i < end; i += ADAM_BLOCK) upd(t.p[i], t.g[i], t.m[i], t.v[i]);
+        for (; i + 3 < end; i += ADAM_BLOCK * 4) {
+            float4 p = ld4(t.p + i), m = ld4(t.m + i), v = ld4(t.v + i), g;
+            if (sh > 0) { const float gs = t.g[i >> sh]; g = make_float4(gs, gs, gs, gs); }
+            else g = ld4(t.g + i);
+            upd(p.x, g.x, m.x, v.x); upd(p.y, g.y, m.y, v.y); upd(p.z, g.z, m.z, v.z); upd(p.w, g.w, m.w, v.w);
+            st4(t.p + i, p); st4(t.m + i, m); st4(t.v + i, v);
+        }
+        for (int64_t k = base + ((end - base) & ~(int64_t)3) + threadIdx.x; k < end; k += ADAM_BLOCK) upd(t.p[k], t.g[k >> sh], t.m[k], t.v[k]);
     } else {
-        for (int64_t i = base + threadIdx.x; i < end; i += ADAM_BLOCK) upd(t.p[i], t.g[i], t.m[i], t.v[i]);
+        for (int64_t k = base + threadIdx.x; k < end; k += ADAM_BLOCK) upd(t.p[k], t.g[k >> sh], t.m[k], t.v[k]);
     }
 }
 

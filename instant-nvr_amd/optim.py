@@ -99,12 +99,26 @@ class FusedAdam(torch.optim.Optimizer):
                 out.append((p, group, g if g.is_contiguous() else g.contiguous(), shift))
         return out, betas, eps
 
+    def _check_replicas(self):
+        """With the arena the table gradients never pass through p.grad: under data parallelism somebody has to average the arena
+        itself (dist_train.GradReducer).  A plain DistributedDataParallel wrapper would silently train every rank on its own
+        table gradients."""
+        if self.arena is None or getattr(self.arena, 'reducer', None) is not None or getattr(self, '_replicas_checked', False):
+            return
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            raise RuntimeError('FusedAdam with a gradient arena in a process group of %d ranks but no invr.dist_train.GradReducer: the '
+                               'row-scalar table gradients bypass p.grad, so DistributedDataParallel does not average them.  Use '
+                               'dist_train (driver / bench --train --gpus N) or build the optimizer without attach().' % dist.get_world_size())
+        self._replicas_checked = True
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        self._check_replicas()
         entries, betas, eps = self._entries()
         if not entries:
             return loss
@@ -172,12 +186,11 @@ def fuse(optimizer, net=None):
     d = optimizer.defaults
     new = FusedAdam([{'params': list(g['params']), 'lr': g['lr'], 'weight_decay': g['weight_decay'], 'betas': g['betas'], 'eps': g['eps']}
                      for g in groups], d['lr'], betas=d['betas'], eps=d['eps'], weight_decay=d['weight_decay'])
-    for g_new, g_old in zip(new.param_groups, groups):          # scheduler bookkeeping (initial_lr, ...) travels with the groups
-        for k, v in g_old.items():
-            if k != 'params' and k not in g_new:
-                g_new[k] = v
-    if optimizer.state:
-        new.load_state_dict(optimizer.state_dict())
+    # the SAME group dicts and the SAME state mapping as the optimizer that is replaced: a scheduler (or any wrapper) constructed on
+    # the old object before fuse() keeps driving this one — it writes group['lr'] into dicts both share — and the moments /
+    # step counts continue in place
+    new.param_groups = optimizer.param_groups
+    new.state = optimizer.state
     if net is not None and hasattr(net, 'tpose_human') and getattr(net, 'cfg', {}).get('train_fused', True):
         new.attach(net)
     return new

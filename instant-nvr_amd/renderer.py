@@ -159,6 +159,21 @@ class LazyHostRet(dict):
             return tuple(self._keys)
         return tuple(self._lazy)
 
+    def device_bytes(self):
+        """bytes of device memory the not-yet-fetched tensors of a joined frame keep alive (occ is a view of raw: counted once)"""
+        if self._pending is not None:
+            return 0
+        seen = {}
+        for v in self._lazy.values():
+            if v.is_cuda:
+                st = v.untyped_storage()
+                seen[st.data_ptr()] = st.nbytes()
+        return sum(seen.values())
+
+    def fetch(self):
+        """make every entry a host tensor now (releases the device tensors)"""
+        self._fetch(tuple(self._lazy) if self._pending is None else self._keys)
+
     def in_flight(self):
         """True while the frame behind this dict has not been joined (Renderer.in_flight > 1)"""
         return self._pending is not None and not self._pending.done()
@@ -342,6 +357,11 @@ class Renderer:
         # every frame at once (run.py:61-90 as written) gets the latency of one frame either way.
         self.in_flight = int(self.cfg.get('render_in_flight', 1)) if hasattr(self.cfg, 'get') else 1
         self._lanes, self._lane_i = [], 0
+        # raw / occ of returned dicts stay on the device until somebody reads them (LazyHostRet): a caller that COLLECTS the dicts of
+        # a sequence and never reads raw would pin 656 MB of HBM per 512x512x128 frame.  At most this many bytes stay device-side
+        # behind returned dicts; beyond it the oldest dicts are completed on the host (what the reference does for every frame)
+        self.lazy_device_budget = int(self.cfg.get('lazy_device_budget', 8 << 30)) if hasattr(self.cfg, 'get') else 8 << 30
+        self._lazy_live = []
         self._cap_hint = None
 
     def render(self, batch, test=False, epoch=-1):
@@ -403,7 +423,7 @@ class Renderer:
             host = LazyHostRet({}, {k: v for k, v in ret.items() if k not in lazy}, self.pin_host)
             host._fetch(tuple(host._lazy))
             host._lazy = lazy
-            ret = host
+            ret = self._track_lazy(host) if lazy else host
         return ret
 
     def _render_in_flight(self, batch, ray_o, ray_d, near, far, S, jitter):
@@ -432,8 +452,28 @@ class Renderer:
                 lane.ws = None
         keys = ('rgb_map', 'acc_map') + (('raw', 'occ') if self.want_raw else ())
         if self.eval_to_cpu:
-            return LazyHostRet({}, {}, self.pin_host, pending=pend, keys=keys)
+            return self._track_lazy(LazyHostRet({}, {}, self.pin_host, pending=pend, keys=keys))
         return LazyDevRet(pend, keys)
+
+    def _track_lazy(self, ret):
+        """bound the device memory behind returned LazyHostRet dicts (lazy_device_budget); called with every new dict"""
+        import weakref
+        self._lazy_live.append(weakref.ref(ret))
+        live, total = [], 0
+        for w in self._lazy_live:
+            r = w()
+            if r is not None and (r._pending is not None or r._lazy):
+                live.append(w)
+                total += r.device_bytes()
+        self._lazy_live = live
+        for w in live:                                   # oldest first
+            if total <= self.lazy_device_budget:
+                break
+            r = w()
+            if r is not None and r._pending is None:
+                total -= r.device_bytes()
+                r.fetch()
+        return ret
 
     def flush(self, release=False):
         """Join every frame in flight (their dicts stay valid); release=True also gives the lanes' workspaces back."""

@@ -39,3 +39,44 @@ def test_pop_eq_repr():
     r2, _, _ = make()
     r2.pop('raw')
     assert set(r.keys()) == set(r2.keys())
+
+
+def test_renderer_bounds_the_memory_behind_unread_dicts():
+    """Renderer._track_lazy: dicts whose raw / occ nobody read are completed on the host, oldest first, once the tensors they keep
+    alive exceed lazy_device_budget (device_bytes counts CUDA storages; on the CPU the bookkeeping is exercised with a stand-in)."""
+    from invr.renderer import Renderer
+
+    class R(LazyHostRet):
+        def device_bytes(self):
+            return 0 if self._pending is not None else sum(v.numel() * 4 for k, v in self._lazy.items() if k == 'raw')
+    r = Renderer.__new__(Renderer)
+    r.lazy_device_budget, r._lazy_live = 2 * 8 * 4, []
+    rets = []
+    for i in range(5):
+        host = {'rgb_map': torch.zeros(1, 2, 3)}
+        raw = torch.full((1, 2, 4), float(i))
+        rets.append(r._track_lazy(R(host, {'raw': raw, 'occ': raw[..., 3:]}, pin=False)))
+    assert [x.pending() for x in rets[:3]] == [(), (), ()] and all(set(x.pending()) == {'raw', 'occ'} for x in rets[3:])
+    assert all(float(x['raw'][0, 0, 0]) == i for i, x in enumerate(rets))            # values survive either way
+    del rets
+    r._track_lazy(R({}, {'raw': torch.zeros(1, 2, 4)}, pin=False))
+    assert len(r._lazy_live) == 1                                                  # dead dicts are dropped from the book
+
+
+def test_lazy_train_ret_dict_views_see_thunks_and_lazy_tensors():
+    from invr.autograd import LazyTrainRet
+    calls = []
+
+    def mat():
+        calls.append(1)
+        return {'resd': torch.ones(1, 2, 3), 'tocc': torch.zeros(1, 2, 1)}
+    mk = lambda: LazyTrainRet({'rgb_map': torch.zeros(1, 2, 3)}, ['resd', 'tocc'], mat, {'offset_loss': lambda: torch.tensor(2.0)})
+    r = mk()
+    assert len(r) == 4 and 'offset_loss' in r and 'resd' in r and not calls
+    assert set(dict(r)) == {'rgb_map', 'resd', 'tocc', 'offset_loss'} and len(calls) == 1
+    for use in (lambda x: {k: v for k, v in x.items()}, lambda x: dict(zip(x.keys(), x.values())), lambda x: {k: x[k] for k in x},
+                lambda x: x.copy(), lambda x: copy.deepcopy(x), lambda x: pickle.loads(pickle.dumps(x))):
+        d = use(mk())
+        assert type(d) is dict and set(d) == {'rgb_map', 'resd', 'tocc', 'offset_loss'} and float(d['offset_loss']) == 2.0
+    r = mk()
+    assert float(r.pop('offset_loss')) == 2.0 and 'offset_loss' not in r and len(r) == 3
