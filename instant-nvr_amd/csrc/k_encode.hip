@@ -580,18 +580,40 @@ int launch_part_encode_bwd_lists(const GridDev& g, const float* x_soa, const flo
 // same / adjacent 64-byte lines; the level constants are wave-uniform (scalar registers).
 #define RS_BLOCK 256
 #ifndef ENC_X2
-#define ENC_X2 0
+#define ENC_X2 1          // A/B round 5: encoder 0.553 -> 0.542 ms, frame -1.1 % (gpurun_out/r5h), bit-identical
 #endif
+#ifndef ENC_HOIST
+#define ENC_HOIST 1       // A/B round 5: encoder stage 0.538 -> 0.528 ms (gpurun_out/r5i), bit-identical
+#endif
+// (Measured and not kept, round 5: both levels' gathers + the next tile's coordinates in flight at once — a prepare / fetch / finish
+//  split of the level — 93 instead of 69 VGPRs, 5 instead of 7 waves per SIMD: 0.540 -> 0.588 ms, gpurun_out/r5k.)
 // one level of one point through the row-sum table (wave-uniform level l)
+// FASTDIV: the caller has established, once per tile of pairs, that every lane's three coordinates are in div_exact's proven range
+// and that this level's reciprocal is usable (rcell != 0) — the three quotients then take the 5-instruction reciprocal form without
+// div_exact's per-call range test + ballot + branch (nine wave-uniform branches per level pair of a tile otherwise).  Same bits.
+__device__ __forceinline__ void level_corners_fast(float x, float cell, float rcell, int res, int& c0, int& c1, float& t) {
+    const float f = div_by_rcp(x, cell, rcell);
+    const int a = (int)f, b = (int)(f + 1.0f);
+    c0 = min(max(a, 0), res - 1);
+    c1 = min(max(b, 0), res - 1);
+    t = f - (float)c0;
+}
+template <bool FASTDIV = false>
 __device__ __forceinline__ float level_rowsum(const GridDev& g, const float* __restrict__ rs, int hstart, int l, float x, float y, float z) {
     const int res = g.res[l];
     const float cell = g.cell[l];
     int c0x, c1x, c0y, c1y, c0z, c1z;
     float tx, ty, tz;
     const float rcell = g.rcell[l];
+    if (FASTDIV) {
+        level_corners_fast(x, cell, rcell, res, c0x, c1x, tx);
+        level_corners_fast(y, cell, rcell, res, c0y, c1y, ty);
+        level_corners_fast(z, cell, rcell, res, c0z, c1z, tz);
+    } else {
     level_corners(x, cell, rcell, res, c0x, c1x, tx);
     level_corners(y, cell, rcell, res, c0y, c1y, ty);
     level_corners(z, cell, rcell, res, c0z, c1z, tz);
+    }
     unsigned row[8];
     const float* tab;
     if (l >= g.start_hash) {
@@ -762,8 +784,18 @@ __global__ __launch_bounds__(RS_BLOCK) void k_part_encode_rs_xcd(EncodeAllArgs a
             const float x = (xs[i] - b0x) / ex, y = (xs[a.stride + i] - b0y) / ey, z = (xs[2 * a.stride + i] - b0z) / ez;   // :112
             if (lg < 3) emb[(int64_t)lg * a.cap + i] = lg == 0 ? x : (lg == 1 ? y : z);
             else if (lg == 3) emb[(int64_t)(EMB_K - 1) * a.cap + i] = 0.0f;          // pad column
+#if ENC_HOIST
+            // div_exact's range test, once per tile instead of once per quotient (the coordinates are the same for every level)
+            const bool okp = fabsf(x) > 8.7e-19f && fabsf(x) < 1.0e6f && fabsf(y) > 8.7e-19f && fabsf(y) < 1.0e6f && fabsf(z) > 8.7e-19f && fabsf(z) < 1.0e6f;
+            const bool fast = __ballot(!okp) == 0ull;
+            if (fast && g.rcell[la] != 0.0f) emb[(int64_t)(3 + la) * a.cap + i] = level_rowsum<true>(g, rs, hstart, la, x, y, z);
+            else emb[(int64_t)(3 + la) * a.cap + i] = level_rowsum<false>(g, rs, hstart, la, x, y, z);
+            if (fast && g.rcell[lb] != 0.0f) emb[(int64_t)(3 + lb) * a.cap + i] = level_rowsum<true>(g, rs, hstart, lb, x, y, z);
+            else emb[(int64_t)(3 + lb) * a.cap + i] = level_rowsum<false>(g, rs, hstart, lb, x, y, z);
+#else
             emb[(int64_t)(3 + la) * a.cap + i] = level_rowsum(g, rs, hstart, la, x, y, z);
             emb[(int64_t)(3 + lb) * a.cap + i] = level_rowsum(g, rs, hstart, lb, x, y, z);
+#endif
         }
     }
 }
