@@ -396,7 +396,9 @@ __device__ __forceinline__ void lane_level_slice(const float2* S, const LaneSlic
     int c0x, c1x, c0y, c1y;
     float tx, ty;
     // (the hardware division on purpose: the reciprocal form of common.h:div_exact measured SLOWER in this kernel, 0.46 -> 0.50 ms
-    // for the stage — its branch breaks the MFMA / VALU interleave of the column blocks)
+    // for the stage — its branch breaks the MFMA / VALU interleave of the column blocks; round 5: the range test hoisted to ONE
+    // wave-uniform branch per tile with both forms of the tile body, 170 instead of 168 registers = 2 instead of 3 waves per SIMD:
+    // stage 0.495 -> 0.513 ms, gpurun_out/r5l — not kept)
     level_corners(x, L.cell, L.res, c0x, c1x, tx);
     level_corners(y, L.cell, L.res, c0y, c1y, ty);
     const float2* row0 = S + L.off + c0x * L.res;
