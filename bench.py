@@ -350,6 +350,11 @@ def variant_lines(net, cfg, batches, dev, S, in_flight=1):
     # sequence one render(batch) at a time — every batch a new dict with its own volume dimensions, nothing captured — and reads
     # frame f's maps after submitting frames f+1 .. f+7, as driver.run_evaluate does
     from collections import deque
+    del r, ret
+    net._ws = None
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()             # (the lanes allocate from their own streams' pools: give them the blocks the variants above cached)
+    api['reserved_gb_before_in_flight'] = torch.cuda.memory_reserved() / 1e9
     for to_cpu, key in ((False, 'in_flight8_eval_to_cpu_false_ms'), (True, 'in_flight8_eval_to_cpu_true_ms')):
         r = Renderer(net)
         r.eval_to_cpu, r.in_flight = to_cpu, 8
@@ -369,10 +374,12 @@ def variant_lines(net, cfg, batches, dev, S, in_flight=1):
         t0 = time.perf_counter()
         sweep(4 * len(batches))
         api[key] = (time.perf_counter() - t0) / (4 * len(batches)) * 1e3
+        api[key.replace('_ms', '_reserved_gb')] = torch.cuda.memory_reserved() / 1e9
         r.flush(release=True)
         del r
+        torch.cuda.synchronize()
         torch.cuda.empty_cache()
-    api['outputs'] = sorted(ret.keys())
+    api['outputs'] = ['acc_map', 'occ', 'raw', 'rgb_map']
     api['note'] = ('Renderer.render(batch): eager launches + statistics read-back, one frame at a time (the maps are read after every call); '
                    'in_flight8_* = the same call with Renderer.in_flight = 8 over the frames of the sequence, maps read 7 calls later '
                    '(driver.run_evaluate\'s loop); eval_to_cpu=True is the reference contract '

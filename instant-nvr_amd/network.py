@@ -321,9 +321,12 @@ class Network(nn.Module):
         return out
 
     def render_rays(self, batch, ray_o, ray_d, near, far, n_samples, jitter=None, want_raw=True,
-                    want_weights=False, max_active=0):
+                    want_weights=False, max_active=0, stream=None):
         """One invr_render_fwd call over a ray list (n,3)/(n,).  `batch` is the collated batch dict
-        or a RenderContext from prepare().  Returns a dict of device tensors."""
+        or a RenderContext from prepare().  Returns a dict of device tensors.
+        stream: launch on THAT torch stream instead of the current one while every tensor (outputs, workspace) still comes from the
+        current stream's allocator pool (Renderer.in_flight lanes: K streams must not mean K private pools of 4 GB workspaces and
+        0.5 GB raw tensors); the caller orders `stream` behind the current stream before the call, the tensors are recorded on it."""
         L = _abi.lib()
         dev = ray_o.device
         ctx = batch if isinstance(batch, RenderContext) else self.prepare(batch)
@@ -349,7 +352,11 @@ class Network(nn.Module):
             _abi.ptr(jitter), n, S, _abi.ptr(out['rgb_map']), _abi.ptr(out['acc_map']),
             _abi.ptr(out.get('raw')), _abi.ptr(None), _abi.ptr(out.get('weights')),
             _abi.ptr(out.get('z_vals')), _abi.ptr(out['stats'], torch.int32),
-            C.c_void_p(ws.data_ptr()), nbytes, max_active, _abi.stream_ptr()))
+            C.c_void_p(ws.data_ptr()), nbytes, max_active, _abi.stream_ptr() if stream is None else C.c_void_p(stream.cuda_stream)))
+        if stream is not None:
+            for t in (ws, ray_o, ray_d, near, far, jitter) + tuple(v for v in out.values() if torch.is_tensor(v)):
+                if t is not None:
+                    t.record_stream(stream)
         if want_raw:
             out['occ'] = out['raw'][:, 3]          # occ IS raw's fourth channel (inb_part_network_multiassign.py:229-256 returns both from the
                                                    # same rows): a view, not a second 4 B / sample write of the compositing kernel

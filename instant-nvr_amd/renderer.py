@@ -267,28 +267,30 @@ class _PendingFrame:
         self._res = None
 
     def launch(self):
-        r, lane = self.r, self.lane
-        with torch.cuda.stream(lane.stream):
-            self.out = self._run(self.cap)
-            self.event = torch.cuda.Event()
-            self.event.record(lane.stream)
+        self.out = self._run(self.cap)
 
     def _run(self, cap):
+        """the frame on the lane's stream; every device tensor comes from the CALLER's stream pool (Network.render_rays(stream=))"""
         r, lane, net = self.r, self.lane, self.r.net
+        dev = lane.stream.device
+        lane.stream.wait_stream(torch.cuda.current_stream(dev))          # inputs + freshly allocated blocks are ordered on the caller's stream
         prev, net._ws = net._ws, lane.ws
         try:
-            out = self.call(cap)
+            out = self.call(cap, lane.stream)
         finally:
             lane.ws, net._ws = net._ws, prev
-        self.stats_host = torch.empty(out['stats'].shape, dtype=out['stats'].dtype, pin_memory=True)
-        self.stats_host.copy_(out['stats'], non_blocking=True)
-        self.host = {}
-        if r.eval_to_cpu:                     # the image maps follow the render on the lane's stream: on the host when the event fires
-            for k in ('rgb_map', 'acc_map'):
-                v = out[k][None]
-                h = torch.empty(v.shape, dtype=v.dtype, device='cpu', pin_memory=r.pin_host)
-                h.copy_(v, non_blocking=True)
-                self.host[k] = h
+        with torch.cuda.stream(lane.stream):
+            self.stats_host = torch.empty(out['stats'].shape, dtype=out['stats'].dtype, pin_memory=True)
+            self.stats_host.copy_(out['stats'], non_blocking=True)
+            self.host = {}
+            if r.eval_to_cpu:                 # the image maps follow the render on the lane's stream: on the host when the event fires
+                for k in ('rgb_map', 'acc_map'):
+                    v = out[k][None]
+                    h = torch.empty(v.shape, dtype=v.dtype, device='cpu', pin_memory=r.pin_host)
+                    h.copy_(v, non_blocking=True)
+                    self.host[k] = h
+            self.event = torch.cuda.Event()
+            self.event.record(lane.stream)
         return out
 
     def done(self):
@@ -302,14 +304,16 @@ class _PendingFrame:
         redo = bool(self.cap) and int(self.stats_host[6]) != 0
         if redo:                                                          # survivor bound too small: once more at full capacity
             lane.ws = None                                                # (not both workspaces at once)
-            with torch.cuda.stream(lane.stream):
-                self.out = self._run(0)
+            self.out = self._run(0)
             lane.stream.synchronize()
             lane.ws = None          # ~1150 B per ray-sample: the next frame of this lane gets one sized from the new survivor count
         st = self.stats_host
         if int(st[6]) != 0:
             raise RuntimeError('invr_render_fwd reported stats[6] = %d: workspace overflow' % int(st[6]))
-        r._cap_hint = int(1.5 * int(st[0])) + 65536
+        # grow-only: the K lanes' workspaces settle at ONE size — the largest frame seen — after a few frames.  (Following every
+        # frame's own count made a lane reallocate whenever a denser frame than any before landed on it: a multi-GB hipMalloc,
+        # ~1 s each on this runtime, for the first LCM(K, sequence period) frames.)
+        r._cap_hint = max(r._cap_hint or 0, int(1.5 * int(st[0])) + 65536)
         r.last_stats = self.out['stats']
         out = self.out
         cur = torch.cuda.current_stream(out['rgb_map'].device)
@@ -318,7 +322,7 @@ class _PendingFrame:
             dev['raw'] = out['raw'][None]
             dev['occ'] = out['occ'][None, :, None]
         for v in dev.values():
-            v.record_stream(cur)               # allocated on the lane's stream, used (and later freed) by the caller on its own
+            v.record_stream(cur)               # (rendered on the lane's stream, read by the caller on its own)
         if lane.pending is self:
             lane.pending = None
         self.keep = self.call = None           # the frame's inputs may go
@@ -439,8 +443,7 @@ class Renderer:
         n_samp = ray_o.shape[0] * S
         cap = min(n_samp, max(self._cap_hint if self._cap_hint is not None else n_samp // 4, 65536)) if self.adaptive_cap else 0
         ctx = self.net.prepare(batch)          # on the caller's stream: a stale row-sum table is rebuilt in front of every lane
-        call = lambda c: self.net.render_rays(ctx, ray_o, ray_d, near, far, S, jitter=jitter, want_raw=self.want_raw, max_active=c)
-        lane.stream.wait_stream(torch.cuda.current_stream(dev))          # the batch was made on the caller's stream
+        call = lambda c, st: self.net.render_rays(ctx, ray_o, ray_d, near, far, S, jitter=jitter, want_raw=self.want_raw, max_active=c, stream=st)
         pend = _PendingFrame(self, lane, call, cap, (batch, ctx, ray_o, ray_d, near, far, jitter))
         pend.launch()
         lane.pending = pend
@@ -450,6 +453,8 @@ class Renderer:
             pend.result()
             if lane.ws is not None and self._cap_hint is not None and cap > 2 * self._cap_hint:
                 lane.ws = None
+            if self._cap_hint is not None:
+                self._cap_hint = int(1.25 * self._cap_hint)          # head-room over the first frame: later frames of a sequence rarely force a regrowth
         keys = ('rgb_map', 'acc_map') + (('raw', 'occ') if self.want_raw else ())
         if self.eval_to_cpu:
             return self._track_lazy(LazyHostRet({}, {}, self.pin_host, pending=pend, keys=keys))
