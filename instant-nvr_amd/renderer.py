@@ -404,7 +404,7 @@ class Renderer:
                 if int(st[6]) != 0:
                     out = call(0)
                     st = out['stats'].cpu()
-                self._cap_hint = int(1.5 * int(st[0])) + 65536
+                self._cap_hint = max(self._cap_hint or 0, int(1.5 * int(st[0])) + 65536)          # grow-only (see _PendingFrame.result)
             elif self.eval_to_cpu:
                 st = out['stats'].cpu()
             else:
