@@ -307,6 +307,16 @@ def variant_lines(net, cfg, batches, dev, S, in_flight=1):
         net.cfg = cfg
     out['aggr_mean'] = {'ms_per_frame': ms, 'ray_samples_per_sec': mean_rays * S / (ms * 1e-3),
                         'note': 'the mean merge: k_part_rgb_all over all listed pairs (about twice the winners) + k_winner_lists<MEAN>'}
+    # (3c) cfg.aggr = 'dist' (:240-244, round 5): part_dist of EVERY (survivor, part) from a brute-force pass (k_knn_pdist) on top of the mean flow
+    acfg = copy.deepcopy(cfg)
+    acfg['aggr'] = 'dist'
+    net.cfg = acfg
+    try:
+        ms, _ = frames_ms(S, 12)
+    finally:
+        net.cfg = cfg
+    out['aggr_dist'] = {'ms_per_frame': ms, 'ray_samples_per_sec': mean_rays * S / (ms * 1e-3),
+                        'note': 'the distance-weighted merge: aggr_mean + an exact brute-force 4-NN of all five parts per survivor (non-default mode, not tuned)'}
     # (4) the 64-byte trainable rows (what a training-mode forward reads) instead of the derived row-sum tables
     old = cfg.get('eval_row_sums', True)
     cfg['eval_row_sums'] = False
@@ -742,8 +752,9 @@ def main():
         # the profiler reports template instantiations by their full name: the eval frame's are <false> (arg-max merge)
         for d in (traffic, counters):
             for k in ('k_winner_lists', 'k_part_rgb_all'):
-                if k not in d and k + '<false>' in d:
-                    d[k] = d.pop(k + '<false>')
+                for suffix in ('<false>', '<0>'):          # (k_winner_lists is <0> since round 5's merge modes)
+                    if k not in d and k + suffix in d:
+                        d[k] = d.pop(k + suffix)
         counters_stale = bool(traffic or counters) and meta.get('csrc_digest') != csrc_digest()
         src = ('profiles/ (rocprofv3 --pmc passes of this command, tools/prof_all.sh; counters cannot be collected inside the timed run)'
                + (' — STALE: measured on other kernel sources (digest %s, now %s)' % (meta.get('csrc_digest'), csrc_digest()) if counters_stale else '')

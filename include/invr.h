@@ -117,6 +117,8 @@ typedef struct InvrScene {
 } InvrScene;
 #define INVR_AGGR_MAX 0
 #define INVR_AGGR_MEAN 1
+#define INVR_AGGR_DIST 2      /* 'dist' (:240-244): sum over the parts weighted by normalize(1 / (part_dist + 1e-5))                  */
+#define INVR_AGGR_MINDIST 3   /* 'mindist' (:245-251): the (rgb, occ) of the part of smallest part_dist (zeros if that part is unflagged) */
 
 /* Device-side statistics block written by invr_render_fwd (int32[INVR_STATS_LEN]). */
 #define INVR_STATS_LEN 16

@@ -346,6 +346,6 @@ def make_scene(batch, cfg, keep):
     li = batch['latent_index'].reshape(-1)[:1].to(torch.int64).contiguous(); keep.append(li)
     s.frame_dim, s.latent_index = fd.data_ptr(), li.data_ptr()
     s.smpl_thresh, s.tpose_viewdir = float(cfg.smpl_thresh), int(bool(cfg.tpose_viewdir))
-    s.aggr = {'': 0, 'mean': 1}[cfg.get('aggr', '') or '']                 # inb_part_network_multiassign.py:236-256 (config.validate rejects the rest)
+    s.aggr = {'': 0, 'mean': 1, 'dist': 2, 'mindist': 3}[cfg.get('aggr', '') or '']          # inb_part_network_multiassign.py:236-256 (INVR_AGGR_*)
     s.composite_eps = float(bool(cfg.get('random_bg', False)))          # inb_renderer.py:72 passes cfg.random_bg as render_weights' epsilon
     return s

@@ -338,8 +338,19 @@ def render_train(net, batch, geo, views, stats, n_rays, S, pair_noise, ctx=None,
             known = (((views['pflags'][:Na].to(torch.int32) | far)[:, None] >> torch.arange(P, device=dev)[None]) & 1).bool()
         tpts = torch.where(known[..., None], tpts, tp)
     tocc = raws[..., 3]
-    if (cfg.get('aggr', '') or '') == 'mean':
+    aggr = cfg.get('aggr', '') or ''
+    if aggr == 'mean':
         merged = raws.mean(dim=1)                                                        # :236-239
+    elif aggr in ('dist', 'mindist'):                                                    # :240-251: part_dist of every (survivor, part)
+        from . import stages
+        ro, rd, nr, fa = rays
+        with torch.no_grad():
+            ppts, _ = stages.pose_points(ctx.scene, ro, rd, nr, fa, S, views['active_idx'][:Na], jitter=jitter, want_dirs=False)
+            _, pdist = stages.knn_blend(ctx.scene, ppts)
+        if aggr == 'dist':
+            merged = torch.sum(raws * torch.nn.functional.normalize(1.0 / (pdist + 1e-5), dim=-1)[..., None], dim=1)
+        else:
+            merged = raws[torch.arange(Na, device=dev), pdist.argmin(dim=1)]
     else:
         ind = tocc.argmax(dim=1)                                                         # :253
         merged = raws[torch.arange(Na, device=dev), ind]

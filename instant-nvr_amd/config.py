@@ -148,12 +148,13 @@ def validate(c):
     # cfg.random_bg True: inb_renderer.py:72 hands it to volume_rendering as render_weights' EPSILON (= 1.0; no background is ever added:
     # net_utils.py:29-44's use_random_bg stays False) — built in the fused paths; the op-by-op training graph composites with epsilon 0
     get = (lambda k, d: c.get(k, d)) if hasattr(c, 'get') else (lambda k, d: getattr(c, k, d))
-    # cfg.aggr (inb_part_network_multiassign.py:236-256): '' = the part of largest occupancy (every INB yaml) and 'mean' are built.
-    # 'dist' weights part p by normalize(1 / (part_dist + 1e-5)) where part_dist is the eps-normalised KNN distance, ~0 for FAR parts
-    # (so parts far from the point dominate), and 'mindist' stops at a breakpoint() in the reference itself: both raise.
-    if (get('aggr', '') or '') not in ('', 'mean'):
-        raise ValueError("invr: unsupported configuration aggr = %r — cfg.aggr in {'dist', 'mindist'} (inb_part_network_multiassign.py:240-251): "
-                         "the merges built are '' (max occupancy) and 'mean'" % (get('aggr', ''),))
+    # cfg.aggr (inb_part_network_multiassign.py:236-256): '' = the part of largest occupancy (every INB yaml), 'mean', and since round 5
+    # 'dist' (parts weighted by normalize(1 / (part_dist + 1e-5))) and 'mindist' (the part of smallest part_dist; the breakpoint() in
+    # front of it is disarmed by lib/config/config.py:328-332).  part_dist is the eps-normalised KNN distance, ~0 for FAR parts, so in
+    # both far parts dominate — reproduced as the reference computes it.
+    if (get('aggr', '') or '') not in ('', 'mean', 'dist', 'mindist'):
+        raise ValueError("invr: unsupported configuration aggr = %r — the reference's merges are '', 'mean', 'dist', 'mindist' "
+                         "(inb_part_network_multiassign.py:236-256)" % (get('aggr', ''),))
     if bool(get('random_bg', False)) and not bool(get('train_fused', True)):
         raise ValueError('invr: unsupported configuration random_bg = True with train_fused = False — the op-by-op training graph is built '
                          'for epsilon 0 only')

@@ -251,6 +251,7 @@ static size_t carve(Workspace& w, void* base, int64_t N, int64_t cap) {
     w.rgbw = c.take<float4>(lc + 8);
     w.dslice = c.take<float2>(DF_SLICE_MAX);
     w.cullmask = c.take<uint8_t>(CULL_MASK_MAX);
+    w.pdist = c.take<float>(lc * INVR_NUM_PARTS);          // (last: every older offset of invr_workspace_layout is unchanged)
     return align_up(c.off, 256);
 }
 
@@ -344,7 +345,7 @@ static int render_impl(const InvrScene* scene, const InvrModel* model,
     INVR_CHECK(scene->pbw_channels >= 1 && scene->part_stride >= 1, "invr_render_fwd: bad scene dims");
     INVR_CHECK(scene->tpose_viewdir, "invr_render_fwd: tpose_viewdir=False is not supported (the reference cannot run it either: "
                "TPoseHuman.forward indexes the (Na,3) view directions per part)");
-    INVR_CHECK(scene->aggr == INVR_AGGR_MAX || scene->aggr == INVR_AGGR_MEAN, "invr_render_fwd: InvrScene::aggr %d (0 = max-occupancy merge, 1 = mean)", scene->aggr);
+    INVR_CHECK(scene->aggr >= INVR_AGGR_MAX && scene->aggr <= INVR_AGGR_MINDIST, "invr_render_fwd: InvrScene::aggr %d (0 = max-occupancy merge, 1 = mean, 2 = dist, 3 = mindist)", scene->aggr);
     INVR_CHECK(scene->part_stride <= KNN_MAX_PART, "invr_render_fwd: part_stride %d > %d vertices per part", scene->part_stride, KNN_MAX_PART);
 
     // survivor order of the frame: ray-major, or (eval frames with a power-of-two sample count) depth-windowed inside
@@ -384,6 +385,7 @@ static int render_impl(const InvrScene* scene, const InvrModel* model,
     {
         ProfStage ps(INVR_STAGE_KNN, st);
         if (launch_knn_pairs(a, w, stats, st)) return 1;
+        if (scene->aggr >= INVR_AGGR_DIST && launch_knn_pdist(a, w, st)) return 1;
     }
     {
         ProfStage ps(INVR_STAGE_WARP, st);

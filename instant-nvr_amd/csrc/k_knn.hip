@@ -1140,6 +1140,55 @@ int launch_front_cull(const RenderArgs& a, const Workspace& w, int* done, hipStr
     return 0;
 }
 
+// cfg.aggr in {'dist', 'mindist'} (inb_part_network_multiassign.py:240-251) merges by `part_dist` = the KNN's weighted distance of
+// EVERY (survivor, part) (blend_utils.py:749 through :817-825; Network.forward hands pbw[..., -1:] down, :88-91,161) — also of the
+// parts the pruned search never scans (provably unflagged, far).  These non-default modes take it from a brute-force pass over the
+// survivors: the arithmetic of k_knn_dense, the point of a slot from the ray list.  A part with fewer than 4 vertices gives NaN as in
+// the reference (inf distances, zero weights: inf * 0).
+#define PD_BLOCK 256
+__global__ __launch_bounds__(PD_BLOCK) void k_knn_pdist(RenderArgs a, Workspace w) {
+    __shared__ float4 sv[KNN_TILE];
+    const int na = w.counters[CNT_ACTIVE];
+    for (int64_t tile = blockIdx.x; tile * PD_BLOCK < na; tile += gridDim.x) {
+        const int64_t slot = tile * PD_BLOCK + threadIdx.x;
+        const bool live = slot < na;
+        float px = 0, py = 0, pz = 0;
+        if (live) sample_pose_point(a, w.active_idx[slot], px, py, pz, nullptr, nullptr);
+        for (int p = 0; p < INVR_NUM_PARTS; ++p) {
+            const int len = (int)a.scene.lengths2[p];
+            const float* verts = a.scene.part_pts + (int64_t)p * a.scene.M * 3;
+            Top4 t;
+            t.init();
+            for (int base = 0; base < len; base += KNN_TILE) {
+                const int m = min(KNN_TILE, len - base);
+                __syncthreads();
+                for (int j = threadIdx.x; j < m; j += PD_BLOCK) {
+                    const float* v = verts + (int64_t)(base + j) * 3;
+                    sv[j] = make_float4(v[0], v[1], v[2], 0.0f);
+                }
+                __syncthreads();
+#pragma unroll 4
+                for (int j = 0; j < m; ++j) {
+                    const float4 v = sv[j];
+                    const float dx = px - v.x, dy = py - v.y, dz = pz - v.z;
+                    t.push(dx * dx + dy * dy + dz * dz, base + j);
+                }
+            }
+            t.finish();
+            float wt[KNN_K];
+            const float ds = knn_weights(t, wt);          // (fewer than 4 vertices: +inf entries remain -> inf * 0 = NaN, as the reference)
+            if (live) w.pdist[slot * INVR_NUM_PARTS + p] = ds;
+        }
+    }
+}
+
+int launch_knn_pdist(const RenderArgs& a, const Workspace& w, hipStream_t st) {
+    const int64_t tiles = cdiv(w.cap, PD_BLOCK);
+    hipLaunchKernelGGL(k_knn_pdist, dim3((unsigned)(tiles < 2048 ? (tiles > 0 ? tiles : 1) : 2048)), dim3(PD_BLOCK), 0, st, a, w);
+    INVR_LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_knn_pairs(const RenderArgs& a, const Workspace& w, int32_t* stats, hipStream_t st) {
     const size_t lds_bytes = (size_t)KNN_LDS_FLOAT4 * sizeof(float4);      // ~150 KB: one workgroup per CU
     static bool attr_set = false;

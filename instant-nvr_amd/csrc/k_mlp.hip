@@ -381,8 +381,13 @@ __global__ __launch_bounds__(MLP_BLOCK, 4) void k_part_occ_all(MlpAllArgs a) {
 //   values of a survivor in part order, divides by 5 and writes rgbw[slot] (wsel = 0: "read rgbw[slot]").
 #define WL_BLOCK 512         // x WL_PER = PAIR_GROUP: one pass per group (the kernel is a chain of dependent round trips)
 #define WL_PER 8
-template <bool MEAN>
+// cfg.aggr == 'dist' (:240-244, MODE 2): the 'mean' flow with the parts weighted by F.normalize(1 / (part_dist + 1e-5)) (L2 over the five
+// parts, eps 1e-12) instead of 1 / 5 — part_dist of every (slot, part) from k_knn_pdist.  cfg.aggr == 'mindist' (:245-251, MODE 3): the
+// arg-max flow with the winner = the part of smallest part_dist (first minimum), whatever its occupancy — its listed pair, its far
+// constant, or zeros when that part is not flagged for the survivor.
+template <int MODE>          // 0 = max occupancy, 1 = mean, 2 = dist, 3 = mindist (InvrScene::aggr)
 __global__ __launch_bounds__(WL_BLOCK) void k_winner_lists(Workspace w) {
+    constexpr bool MEAN = MODE == 1 || MODE == 2;
     __shared__ int s_cnt[WL_BLOCK / 64][INVR_NUM_PARTS];
     __shared__ int s_red[WL_BLOCK / 64][INVR_NUM_PARTS];
     const int na = w.counters[CNT_ACTIVE];
@@ -456,6 +461,24 @@ __global__ __launch_bounds__(WL_BLOCK) void k_winner_lists(Workspace w) {
 #pragma unroll
                 for (int p = 0; p < INVR_NUM_PARTS; ++p) v[p] = w.feat[p][(int64_t)pidx[k][p] * 4];      // (unflagged: the part's far constant, dropped below)
                 float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (MODE == 2) {
+                    // torch.sum(raws * F.normalize(1.0 / (part_dist + 1e-5), dim=-1)[..., None], dim=1)
+                    float inv[INVR_NUM_PARTS], n2 = 0.0f;
+                    const int64_t sl = min(s0 + k, (int64_t)na - 1);
+#pragma unroll
+                    for (int p = 0; p < INVR_NUM_PARTS; ++p) { inv[p] = 1.0f / (w.pdist[sl * INVR_NUM_PARTS + p] + 1e-5f); n2 += inv[p] * inv[p]; }
+                    const float den = fmaxf(sqrtf(n2), 1e-12f);
+#pragma unroll
+                    for (int p = 0; p < INVR_NUM_PARTS; ++p) {
+                        const float wp = inv[p] / den;
+                        if ((fl | ff) & (1u << p)) { sum.x += v[p].x * wp; sum.y += v[p].y * wp; sum.z += v[p].z * wp; sum.w += v[p].w * wp; }
+                    }
+                    if (s0 + k < na) {
+                        w.rgbw[s0 + k] = sum;
+                        w.wsel[s0 + k] = ((fl | ff) & 0x1fu) ? (uint8_t)0 : (uint8_t)255;
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int p = 0; p < INVR_NUM_PARTS; ++p)
                     if ((fl | ff) & (1u << p)) { sum.x += v[p].x; sum.y += v[p].y; sum.z += v[p].z; sum.w += v[p].w; }
@@ -477,6 +500,24 @@ __global__ __launch_bounds__(WL_BLOCK) void k_winner_lists(Workspace w) {
             float best = 0.0f;
             unsigned bsel = 255u;
             int bidx = 0;
+            if (MODE == 3) {
+                // part_dist.argmin(dim=1): the first minimum (a NaN, from a part with fewer than 4 vertices, wins as in torch)
+                const int64_t sl = min(s0 + k, (int64_t)na - 1);
+                int bp = 0;
+                float bd = w.pdist[sl * INVR_NUM_PARTS];
+#pragma unroll
+                for (int p = 1; p < INVR_NUM_PARTS; ++p) {
+                    const float d = w.pdist[sl * INVR_NUM_PARTS + p];
+                    if (!(bd != bd) && (d < bd || d != d)) { bd = d; bp = p; }
+                }
+#pragma unroll
+                for (int p = 0; p < INVR_NUM_PARTS; ++p)
+                    if (p == bp) {
+                        if (fl & (1u << p)) bsel = (unsigned)p;
+                        else if (ff & (1u << p)) bsel = 8u + (unsigned)p;
+                        bidx = pidx[k][p];
+                    }
+            } else {
 #pragma unroll
             for (int p = 0; p < INVR_NUM_PARTS; ++p) {
                 float c = 0.0f;
@@ -484,6 +525,7 @@ __global__ __launch_bounds__(WL_BLOCK) void k_winner_lists(Workspace w) {
                 if (fl & (1u << p)) { c = oc[k][p]; sel = (unsigned)p; }
                 else if (ff & (1u << p)) { c = oc[k][p]; sel = 8u + (unsigned)p; }
                 if (p == 0 || c > best) { best = c; bsel = sel; bidx = pidx[k][p]; }
+            }
             }
             widx[k] = bidx;
             sel8 |= (unsigned long long)bsel << (8 * k);
@@ -732,17 +774,20 @@ int launch_part_mlp_all(const MlpAllArgs& a, const Workspace& w, hipStream_t st)
     unsigned grid_rgb = (unsigned)(tiles < 256 * RGB_WPS ? (tiles > 0 ? tiles : 1) : 256 * RGB_WPS);
     hipLaunchKernelGGL(k_part_occ_all, dim3(grid_occ), dim3(MLP_BLOCK), 0, st, a);
     INVR_LAUNCH_CHECK();
-    if (a.aggr == INVR_AGGR_MEAN) {
+    if (a.aggr == INVR_AGGR_MEAN || a.aggr == INVR_AGGR_DIST) {
         int64_t lt = cdiv(a.cap, 256);
         hipLaunchKernelGGL(k_all_lists, dim3((unsigned)(lt < 1024 ? (lt > 0 ? lt : 1) : 1024)), dim3(256), 0, st, w);
         INVR_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_part_rgb_all<true>, dim3(grid_rgb), dim3(MLP_BLOCK), 0, st, a);
         INVR_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_winner_lists<true>, dim3((unsigned)w.n_groups), dim3(WL_BLOCK), 0, st, w);
+        if (a.aggr == INVR_AGGR_MEAN) hipLaunchKernelGGL(k_winner_lists<1>, dim3((unsigned)w.n_groups), dim3(WL_BLOCK), 0, st, w);
+        else hipLaunchKernelGGL(k_winner_lists<2>, dim3((unsigned)w.n_groups), dim3(WL_BLOCK), 0, st, w);
         INVR_LAUNCH_CHECK();
         return 0;
     }
-    hipLaunchKernelGGL(k_winner_lists<false>, dim3((unsigned)w.n_groups), dim3(WL_BLOCK), 0, st, w);
+    if (a.aggr == INVR_AGGR_MINDIST) hipLaunchKernelGGL(k_winner_lists<3>, dim3((unsigned)w.n_groups), dim3(WL_BLOCK), 0, st, w);
+    else
+    hipLaunchKernelGGL(k_winner_lists<0>, dim3((unsigned)w.n_groups), dim3(WL_BLOCK), 0, st, w);
     INVR_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_part_rgb_all<false>, dim3(grid_rgb), dim3(MLP_BLOCK), 0, st, a);
     INVR_LAUNCH_CHECK();

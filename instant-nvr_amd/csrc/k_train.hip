@@ -200,19 +200,33 @@ __global__ __launch_bounds__(256) void k_distortion_bwd(const float* __restrict_
 // ---- max-occupancy merge, backward (inb_part_network_multiassign.py:229-256 + the scatter of :156-159) ---------------
 // The merged raw of a survivor is the (rgb, occ) of its first-maximum-occupancy part; its gradient goes to that (slot, part)
 // entry — for a far pair to the part's constant entry (slot = cap), where the contributions of all its far pairs add up.
-template <bool MEAN>
+template <int MODE>          // InvrScene::aggr: 0 = max occupancy (and 3 = mindist: the forward's wsel names the part either way), 1 = mean, 2 = dist
 __global__ __launch_bounds__(256) void k_merge_bwd(Workspace w, const float4* __restrict__ g_rawfull, float4* __restrict__ g_raws) {
+    constexpr bool MEAN = MODE == 1 || MODE == 2;
     const int na = w.counters[CNT_ACTIVE];
     for (int slot = blockIdx.x * blockDim.x + threadIdx.x; slot < na; slot += gridDim.x * blockDim.x) {
         const float4 g = g_rawfull[w.active_idx[slot]];
         if (MEAN) {
             // cfg.aggr == 'mean' (:236-239): raws.mean(dim=1) hands g / P to every part's entry; listed pairs keep theirs, the far
-            // pairs of a part add up in its constant entry, the zeros of unflagged parts have no producer
+            // pairs of a part add up in its constant entry, the zeros of unflagged parts have no producer.  'dist' (:240-244): the
+            // part's weight normalize(1 / (part_dist + 1e-5)) instead of 1 / P (the weights depend on the geometry alone: no gradient)
             const unsigned fl = w.pflags[slot], ff = w.farflags[slot];
-            const float s = 1.0f / (float)INVR_NUM_PARTS;
-            const float4 gp = make_float4(g.x * s, g.y * s, g.z * s, g.w * s);
+            float wgt[INVR_NUM_PARTS];
+            if (MODE == 2) {
+                float n2 = 0.0f;
+#pragma unroll
+                for (int p = 0; p < INVR_NUM_PARTS; ++p) { wgt[p] = 1.0f / (w.pdist[(int64_t)slot * INVR_NUM_PARTS + p] + 1e-5f); n2 += wgt[p] * wgt[p]; }
+                const float den = fmaxf(sqrtf(n2), 1e-12f);
+#pragma unroll
+                for (int p = 0; p < INVR_NUM_PARTS; ++p) wgt[p] = wgt[p] / den;
+            } else {
+#pragma unroll
+                for (int p = 0; p < INVR_NUM_PARTS; ++p) wgt[p] = 1.0f / (float)INVR_NUM_PARTS;
+            }
 #pragma unroll
             for (int p = 0; p < INVR_NUM_PARTS; ++p) {
+                const float s = wgt[p];
+                const float4 gp = make_float4(g.x * s, g.y * s, g.z * s, g.w * s);
                 g_raws[(int64_t)slot * INVR_NUM_PARTS + p] = (fl & (1u << p)) ? gp : make_float4(0.f, 0.f, 0.f, 0.f);
                 if (!(fl & (1u << p)) && (ff & (1u << p))) {
                     float* c = reinterpret_cast<float*>(g_raws + w.cap * INVR_NUM_PARTS + p);
@@ -576,8 +590,9 @@ int launch_merge_bwd(const Workspace& w, int aggr, const float4* g_rawfull, floa
     INVR_HIP(hipMemsetAsync(g_raws + w.cap * INVR_NUM_PARTS, 0, INVR_NUM_PARTS * sizeof(float4), st));      // far-constant row
     int64_t tiles = cdiv(w.cap, 256);
     const dim3 grid((unsigned)(tiles < 1024 ? (tiles > 0 ? tiles : 1) : 1024));
-    if (aggr == INVR_AGGR_MEAN) hipLaunchKernelGGL(k_merge_bwd<true>, grid, dim3(256), 0, st, w, g_rawfull, g_raws);
-    else hipLaunchKernelGGL(k_merge_bwd<false>, grid, dim3(256), 0, st, w, g_rawfull, g_raws);
+    if (aggr == INVR_AGGR_MEAN) hipLaunchKernelGGL(k_merge_bwd<1>, grid, dim3(256), 0, st, w, g_rawfull, g_raws);
+    else if (aggr == INVR_AGGR_DIST) hipLaunchKernelGGL(k_merge_bwd<2>, grid, dim3(256), 0, st, w, g_rawfull, g_raws);
+    else hipLaunchKernelGGL(k_merge_bwd<0>, grid, dim3(256), 0, st, w, g_rawfull, g_raws);
     INVR_LAUNCH_CHECK();
     return 0;
 }

@@ -88,6 +88,7 @@ struct Workspace {
     float4* rgbw;                         // cap + 8 : [rgb, occ] of the winning listed pair per survivor; [lcap + p] = far constant of part p
     uint8_t* cullmask;                    // CULL_MASK_MAX : 1 if the trilinear cell can hold a survivor (k_cull.hip)
     float2* dslice;                       // DF_SLICE_MAX : per-frame t-slices of the deformer grid (k_warp.hip)
+    float* pdist;                         // 5*lcap : cfg.aggr 'dist' / 'mindist' only — the KNN's weighted distance of EVERY (slot, part), [slot][p]
     int64_t cap;                          // max survivors
     int64_t lcap;                         // cap + 1: list / per-slot array capacity (stride of the SoA lists)
 };
@@ -146,6 +147,7 @@ int launch_knn_prepare(const RenderArgs& a, const Workspace& w, hipStream_t st);
 int launch_vertex_mats(const RenderArgs& a, const Workspace& w, hipStream_t st);
 int launch_knn_voxel_class(const RenderArgs& a, const Workspace& w, hipStream_t st);
 int launch_knn_pairs(const RenderArgs& a, const Workspace& w, int32_t* stats, hipStream_t st);     // stats: exported behind the pair lists when given
+int launch_knn_pdist(const RenderArgs& a, const Workspace& w, hipStream_t st);      // aggr 'dist' / 'mindist': part_dist of all (survivor, part)
 int launch_deform_slice(const RenderArgs& a, const Workspace& w, const GridDev& dg, hipStream_t st);   // per-call t-slices of the deformer grid (no-op when they do not fit)
 int launch_warp_pairs(const RenderArgs& a, const Workspace& w, const GridDev& dg, const MlpDev& dm, hipStream_t st);
 int launch_part_encode(const GridDev& g, const float* x_soa, int64_t stride, const int32_t* count, int64_t cap,

@@ -23,8 +23,11 @@ MODES = os.path.join(ROOT, 'tests', 'golden', 'modes_small.npz')
 def golden_modes():
     """tests/golden/make_golden_modes.py: the imported reference with cfg.aggr = 'mean' / cfg.random_bg = True (same scene / parameters)"""
     import numpy as np
-    g = np.load(MODES)
-    return {k: g[k] for k in g.files}
+    out = {}
+    for path in (MODES, MODES.replace('modes_small', 'modes_dist_small')):          # + aggr = 'dist' / 'mindist' (round 5; tags dist_ / mind_)
+        g = np.load(path)
+        out.update({k: g[k] for k in g.files})
+    return out
 
 
 @pytest.fixture(scope='session')

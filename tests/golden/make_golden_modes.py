@@ -18,6 +18,13 @@ sys.path.insert(0, HERE)
 import make_golden as MG      # noqa: E402
 
 
+MODES = (('mean', 'aggr', 'mean'), ('rbg', 'random_bg', True))
+OUT = 'modes_small.npz'
+if os.environ.get('GOLDEN_MODES') == 'dist':          # round 5: the two distance-weighted merges (:240-251) -> modes_dist_small.npz
+    MODES = (('dist', 'aggr', 'dist'), ('mind', 'aggr', 'mindist'))
+    OUT = 'modes_dist_small.npz'
+
+
 def main():
     import invr  # noqa: F401
     from invr import scene, params
@@ -39,7 +46,7 @@ def main():
     jit = torch.from_numpy(base['train_jitter'])
     out = {}
     rcfg.defrost()
-    for tag, key, val in (('mean', 'aggr', 'mean'), ('rbg', 'random_bg', True)):
+    for tag, key, val in MODES:
         old = rcfg[key]
         rcfg[key] = val
         try:
@@ -92,7 +99,7 @@ def main():
                     out['%s_grad::%s' % (tag, k)] = g
         finally:
             rcfg[key] = old
-    path = os.path.join(HERE, 'modes_small.npz')
+    path = os.path.join(HERE, OUT)
     np.savez_compressed(path, **out)
     print('wrote', path, os.path.getsize(path) / 1e6, 'MB;', len(out), 'arrays')
 

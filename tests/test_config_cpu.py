@@ -7,7 +7,7 @@ from invr import config
 from invr.network import Network
 
 
-BAD = [('aggr', 'dist'), ('aggr', 'mindist'), ('knn_k', 3), ('knn_k', 8), ('part_deform', True), ('tpose_viewdir', False), ('use_knn', False), ('use_amp', True)]
+BAD = [('aggr', 'median'), ('knn_k', 3), ('knn_k', 8), ('part_deform', True), ('tpose_viewdir', False), ('use_knn', False), ('use_amp', True)]
 
 
 @pytest.mark.parametrize('key,val', BAD)
@@ -40,6 +40,9 @@ def test_random_bg_is_built_on_the_fused_paths_only():
 def test_aggr_mean_is_built():
     Network(cfg=config.make_cfg(table_log2=8, aggr='mean'))
     Network(cfg=config.make_cfg(table_log2=8, aggr='mean', train_fused=False))
+    for a in ('dist', 'mindist'):                      # round 5 (inb_part_network_multiassign.py:240-251)
+        Network(cfg=config.make_cfg(table_log2=8, aggr=a))
+        Network(cfg=config.make_cfg(table_log2=8, aggr=a, train_fused=False))
 
 
 def test_defaults_and_ignored_keys_pass():

@@ -475,64 +475,85 @@ def _mode_net(net0, cfg0, **over):
     return net
 
 
-def test_aggr_mean_render_vs_reference_golden(gpu_setup, golden, golden_modes):
-    """cfg.aggr = 'mean' (inb_part_network_multiassign.py:236-239: raw = the mean over the five parts, zeros for unflagged parts)
+AGGR_TAGS = [('mean', 'mean'), ('dist', 'dist'), ('mind', 'mindist')]
+
+
+@pytest.mark.parametrize('tag,aggr', AGGR_TAGS)
+def test_aggr_mean_render_vs_reference_golden(gpu_setup, golden, golden_modes, tag, aggr):
+    """cfg.aggr = 'mean' (inb_part_network_multiassign.py:236-239: raw = the mean over the five parts, zeros for unflagged parts),
+    'dist' (:240-244: parts weighted by normalize(1 / (part_dist + 1e-5))) and 'mindist' (:245-251: the part of smallest part_dist)
     through Renderer.render against the IMPORTED reference (tests/golden/make_golden_modes.py), both encoder paths."""
     cfg0, sd, batch, gb, net0 = gpu_setup
-    net = _mode_net(net0, cfg0, aggr='mean').eval()
+    net = _mode_net(net0, cfg0, aggr=aggr).eval()
+    # The distance-weighted merges let the FAR parts dominate every survivor (their eps-normalised part_dist is ~0): their values come
+    # from encoders evaluated far outside their boxes, where the reference extrapolates with weights of 1e3..1e9 that cancel — its own
+    # fp32 result then carries that noise.  A pixel's allowance beyond the plain 1e-4 is 4 x the reference's OWN deviation from a
+    # float64 run of the oracle (0 for all but a handful of pixels: p99 5e-7, one pixel 5e-5 in 'dist').
+    noise_rgb = np.zeros(golden_modes[tag + '_rgb_map'].shape[1])
+    noise_raw = np.zeros(golden_modes[tag + '_raw_nz'].shape[0])
+    if aggr != 'mean':
+        sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+        b64 = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in batch.items()}
+        with torch.no_grad():
+            r64 = O.render(O.Model(sd64, net.cfg), b64)
+        noise_rgb = np.abs(golden_modes[tag + '_rgb_map'] - r64['rgb_map'].numpy()).max(-1)[0]
+        noise_raw = np.abs(golden_modes[tag + '_raw_nz'] - r64['raw'][0].numpy()[golden_modes[tag + '_raw_nz_idx']]).max(-1)
+        assert np.percentile(noise_rgb, 99) < 5e-6                     # (the allowance is about a handful of pixels)
     for row_sums in (True, False):
         r = Renderer(net)
         with encoder_mode(net.cfg, row_sums):
             ret = r.render(dict(gb))
         assert r.last_stats.cpu().numpy()[6] == 0
-        err = np.abs(ret['rgb_map'].numpy() - golden_modes['mean_rgb_map']).max(-1)[0]
-        assert int((err > 1e-4).sum()) == 0, float(err.max())
-        assert maxerr(ret['acc_map'], golden_modes['mean_acc_map']) < 1e-4
+        err = np.abs(ret['rgb_map'].numpy() - golden_modes[tag + '_rgb_map']).max(-1)[0]
+        assert int((err > 1e-4 + 4 * noise_rgb).sum()) == 0, float(err.max())
+        assert maxerr(ret['acc_map'], golden_modes[tag + '_acc_map']) < 1e-4 + 4 * float(noise_rgb.max())
         raw = ret['raw'][0].numpy()
-        nz = golden_modes['mean_raw_nz_idx']
-        assert np.abs(raw[nz] - golden_modes['mean_raw_nz']).max() < 1e-4
+        nz = golden_modes[tag + '_raw_nz_idx']
+        assert (np.abs(raw[nz] - golden_modes[tag + '_raw_nz']).max(-1) <= 1e-4 + 4 * noise_raw).all()
         mask = np.ones(raw.shape[0], bool)
         mask[nz] = False
         assert np.abs(raw[mask]).max() == 0.0
         assert maxerr(ret['occ'][0, :, 0], raw[:, 3]) == 0.0
-    assert np.abs(golden_modes['mean_rgb_map'] - golden['render_rgb_map']).max() > 1e-3          # (the switch does change the image)
+    assert np.abs(golden_modes[tag + '_rgb_map'] - golden['render_rgb_map']).max() > 1e-3          # (the switch does change the image)
 
 
+@pytest.mark.parametrize('tag,aggr', AGGR_TAGS)
 @pytest.mark.parametrize('mode', ['fused', 'graph'])
-def test_aggr_mean_train_step_gradients_vs_reference_golden(gpu_setup, golden, golden_modes, mode):
-    """cfg.aggr = 'mean' in train mode: forward, loss and every parameter gradient of the reference's autograd (256 rays, fixed jitter)
-    through the fused node (k_merge_bwd<MEAN>: g / 5 to every flagged part) and through the op-by-op graph."""
+def test_aggr_mean_train_step_gradients_vs_reference_golden(gpu_setup, golden, golden_modes, mode, tag, aggr):
+    """cfg.aggr = 'mean' / 'dist' / 'mindist' in train mode: forward, loss and every parameter gradient of the reference's autograd (256
+    rays, fixed jitter) through the fused node (k_merge_bwd: g / 5 resp. g x the part's distance weight to every flagged part; the
+    part of smallest part_dist) and through the op-by-op graph."""
     cfg0, sd, batch, gb, net0 = gpu_setup
-    net = _mode_net(net0, cfg0, aggr='mean', train_fused=(mode != 'graph'))
+    net = _mode_net(net0, cfg0, aggr=aggr, train_fused=(mode != 'graph'))
     cfg = net.cfg
     tb = _train_batch(gb, golden)
     net.train()
     r = Renderer(net)
     r._jitter = lambda shape, device: cu(golden['train_jitter'][0])
-    r._pair_noise = lambda like: cu(golden_modes['mean_train_pair_u'])
+    r._pair_noise = lambda like: cu(golden_modes[tag + '_train_pair_u'])
     if mode != 'graph':
-        sub = {'train_jitter': golden['train_jitter'], 'train_pair_u': golden_modes['mean_train_pair_u']}
+        sub = {'train_jitter': golden['train_jitter'], 'train_pair_u': golden_modes[tag + '_train_pair_u']}
         dense = _dense_pair_noise(net, tb, sub, cfg)
         r._pair_noise_dense = lambda rows, device: dense[:rows]
     net.zero_grad(set_to_none=True)
     ret = r.render(tb)
-    assert maxerr(ret['rgb_map'], golden_modes['mean_train_rgb_map']) < 1e-4
+    assert maxerr(ret['rgb_map'], golden_modes[tag + '_train_rgb_map']) < 1e-4
     offset = torch.norm(ret['resd'], dim=2).mean() if mode == 'graph' else ret['offset_loss']
     loss = ((ret['rgb_map'] - tb['rgb']) ** 2).mean() + 0.1 * ret['reg_distortion_loss'].mean() + 0.1 * offset   # make_golden_modes.py's loss
-    assert abs(float(loss.detach()) - float(golden_modes['mean_train_loss'])) < 1e-5
+    assert abs(float(loss.detach()) - float(golden_modes[tag + '_train_loss'])) < 1e-5
     loss.backward()
-    assert ret['tocc'].shape == golden_modes['mean_train_tocc'].shape
-    np.testing.assert_array_equal(golden_modes['mean_train_tocc'], golden['train_tocc'])           # the occupancies do not depend on the merge
+    assert ret['tocc'].shape == golden_modes[tag + '_train_tocc'].shape
+    np.testing.assert_array_equal(golden_modes[tag + '_train_tocc'], golden['train_tocc'])           # the occupancies do not depend on the merge
     params_, checked = dict(net.named_parameters()), 0
     for key in golden_modes:
-        if key.startswith('mean_grad::'):
-            name, want = key[len('mean_grad::'):], golden_modes[key]
+        if key.startswith(tag + '_grad::'):
+            name, want = key[len(tag + '_grad::'):], golden_modes[key]
             g = params_[name].grad.detach().cpu().numpy()
             scale = max(float(np.abs(want).max()), 1e-6)
             assert np.abs(g - want).max() <= 2e-4 * scale + 2e-7, (name, float(np.abs(g - want).max()), scale)
-        elif key.startswith('mean_grad_rows::'):
-            name = key[len('mean_grad_rows::'):]
-            rows, vals = golden_modes[key], golden_modes['mean_grad_vals::' + name]
+        elif key.startswith(tag + '_grad_rows::'):
+            name = key[len(tag + '_grad_rows::'):]
+            rows, vals = golden_modes[key], golden_modes[tag + '_grad_vals::' + name]
             g = params_[name].grad.detach().cpu().numpy()
             flat = g.reshape(-1, g.shape[-1])
             scale = max(float(np.abs(vals).max()), 1e-6)

@@ -246,6 +246,15 @@ def test_aggr_mean_training_steps_vs_oracle():
     _mode_training_steps(dict(aggr='mean'), dict(aggr=''), 2e-4, 3e-3)
 
 
+@pytest.mark.parametrize('aggr', ['dist', 'mindist'])
+def test_aggr_distance_merges_training_steps_vs_oracle(aggr):
+    """cfg.aggr = 'dist' / 'mindist' (inb_part_network_multiassign.py:240-251; round 5) through NetworkWrapper + the fused node
+    (k_knn_pdist, k_winner_lists<2 / 3>, k_merge_bwd<2 / 0>) + FusedAdam: gradients of one iteration against CPU autograd of the
+    (reference-pinned) oracle, three optimiser steps' losses against the oracle + torch.optim.Adam.  (The far parts' extrapolated
+    field values dominate these merges: the looser bounds of the random_bg case.)"""
+    _mode_training_steps(dict(aggr=aggr), dict(aggr=''), 1e-3, 3e-3)
+
+
 def _mode_training_steps(over, default, tol, tol_deformer):
     cfg = make_cfg(table_log2=12, N_samples=12, **over)
     sd0 = params.init_state_dict(cfg, seed=21)

@@ -17,7 +17,8 @@ from tests.test_gpu_parity import gpu_setup  # noqa: F401  (fixture)
 # every test of the parity module; of the training module the ones at the golden's / a toy size (the others need the 1.09 GB model)
 # (test_lan_config_training_loop_vs_oracle passes here too: 14 optimiser steps against the oracle's autograd, 110 s — left to -m gpu)
 BORROWED = [(T, None), (TT, ['test_pair_term_gradient_float64_arbitration', 'test_reference_step_form_with_disabled_grad_scaler',
-                             'test_random_bg_epsilon_training_steps_vs_oracle', 'test_aggr_mean_training_steps_vs_oracle'])]
+                             'test_random_bg_epsilon_training_steps_vs_oracle', 'test_aggr_mean_training_steps_vs_oracle',
+                             'test_aggr_distance_merges_training_steps_vs_oracle'])]
 
 
 @pytest.fixture(scope='module', autouse=True)

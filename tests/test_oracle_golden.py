@@ -196,7 +196,7 @@ def test_train_mode_forward(golden, small_setup):
     close(O.distortion_loss(r['weights'], r['z'])[None], golden['train_reg_distortion_loss'], 5e-6)
 
 
-MODE_CFG = {'mean': dict(aggr='mean'), 'rbg': dict(random_bg=True)}
+MODE_CFG = {'mean': dict(aggr='mean'), 'rbg': dict(random_bg=True), 'dist': dict(aggr='dist'), 'mind': dict(aggr='mindist')}
 
 
 def mode_train_loss(r, rgb):
@@ -208,7 +208,7 @@ def mode_train_loss(r, rgb):
 def test_non_default_modes_vs_reference(golden, golden_modes, small_setup):
     """cfg.aggr = 'mean' (inb_part_network_multiassign.py:236-239) and cfg.random_bg = True (= render_weights' epsilon,
     inb_renderer.py:72) against the imported reference (tests/golden/make_golden_modes.py): eval render, train-mode forward, loss and
-    every parameter gradient.  (aggr = 'dist' / 'mindist' stay unsupported: config.validate.)"""
+    every parameter gradient; round 5: aggr = 'dist' / 'mindist' (:240-251, tests/golden/modes_dist_small.npz) the same way."""
     cfg0, sd, batch, _ = small_setup
     import copy
     tsel = torch.from_numpy(golden['train_rays'].astype(np.int64))
