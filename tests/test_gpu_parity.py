@@ -499,17 +499,39 @@ def test_aggr_mean_render_vs_reference_golden(gpu_setup, golden, golden_modes, t
         noise_rgb = np.abs(golden_modes[tag + '_rgb_map'] - r64['rgb_map'].numpy()).max(-1)[0]
         noise_raw = np.abs(golden_modes[tag + '_raw_nz'] - r64['raw'][0].numpy()[golden_modes[tag + '_raw_nz_idx']]).max(-1)
         assert np.percentile(noise_rgb, 99) < 5e-6                     # (the allowance is about a handful of pixels)
+    tie_ray = np.zeros(noise_rgb.shape[0], bool)
+    tie_raw = np.zeros(noise_raw.shape[0], bool)
+    if aggr == 'mindist':
+        # A DISCRETE decision on ulp-level margins: the arg-min runs over the eps-normalised distances of FAR parts (1e-11 .. 1e-20, formed
+        # from exp() deep in its underflow range); where the two smallest part_dist of a survivor agree to 1e-4 relative, the transcendental
+        # units of two machines may order them differently; and where both are below 2e-30 they were formed from DENORMAL weights
+        # (exp(-d^2 / 0.01125) < 1.2e-38: a few significant bits — measured on the MI355X: 1 survivor of 3607, part_dist 1.05e-36 vs the
+        # reference's 1.50e-36 against a rival at 1.054e-36).  Such survivors — found from the float64 oracle's part_dist — and the rays
+        # they sit on are exempt from the value comparison; everything else is held to it.
+        S_ = int(net.cfg.N_samples)
+        pts, _ = O.sample_points(b64['ray_o'], b64['ray_d'], b64['near'], b64['far'], S_)
+        vd = b64['ray_d'][:, :, None].expand(-1, -1, S_, -1).reshape(-1, 3)
+        with torch.no_grad():
+            f64 = O.field(O.Model(sd64, net.cfg), pts.reshape(-1, 3), vd, b64, want_train=True)
+        d2 = torch.sort(f64['dist'], dim=1)[0][:, :2]
+        rel = (d2[:, 1] - d2[:, 0]) / d2[:, 1].clamp(min=1e-300)
+        amb = ((rel <= 1e-4) | ((d2[:, 1] < 2e-30) & (rel <= 0.75))).numpy()          # (denormal weights carry 1..3 significant bits)
+        amb_samples = f64['active'].numpy()[amb]
+        assert amb.sum() <= 0.08 * max(len(amb), 1), int(amb.sum())
+        tie_ray[np.unique(amb_samples // S_)] = True
+        tie_raw = np.isin(golden_modes[tag + '_raw_nz_idx'], amb_samples)
     for row_sums in (True, False):
         r = Renderer(net)
         with encoder_mode(net.cfg, row_sums):
             ret = r.render(dict(gb))
         assert r.last_stats.cpu().numpy()[6] == 0
         err = np.abs(ret['rgb_map'].numpy() - golden_modes[tag + '_rgb_map']).max(-1)[0]
-        assert int((err > 1e-4 + 4 * noise_rgb).sum()) == 0, float(err.max())
-        assert maxerr(ret['acc_map'], golden_modes[tag + '_acc_map']) < 1e-4 + 4 * float(noise_rgb.max())
+        assert int(((err > 1e-4 + 4 * noise_rgb) & ~tie_ray).sum()) == 0, float(err[~tie_ray].max())
+        acc_err = np.abs(ret['acc_map'].numpy() - golden_modes[tag + '_acc_map'])[0]
+        assert float(acc_err[~tie_ray].max()) < 1e-4 + 4 * float(noise_rgb.max())
         raw = ret['raw'][0].numpy()
         nz = golden_modes[tag + '_raw_nz_idx']
-        assert (np.abs(raw[nz] - golden_modes[tag + '_raw_nz']).max(-1) <= 1e-4 + 4 * noise_raw).all()
+        assert ((np.abs(raw[nz] - golden_modes[tag + '_raw_nz']).max(-1) <= 1e-4 + 4 * noise_raw) | tie_raw).all()
         mask = np.ones(raw.shape[0], bool)
         mask[nz] = False
         assert np.abs(raw[mask]).max() == 0.0
