@@ -55,6 +55,7 @@ struct GridDev {
     int32_t mod_k, mod32;
     uint32_t mod_c;
     int32_t xdelta;             // mod24 and T > 2^14: the c1x corners' rows follow from the c0x corners' by a +-delta fold (k_encode.hip)
+    int32_t mod1r;              // xdelta and c * (max hash key >> k) < 2 T for THIS grid's resolutions: one folding round + two fix-ups (hash_mod24_1r)
     int32_t mod24;              // mod32 and every multiplicand of its folding rounds < 2^24: v_mul_u32_u24 (full rate) instead of
                                 // v_mul_lo_u32 (quarter rate)
     int32_t res[INVR_MAX_LEVELS];
@@ -309,10 +310,22 @@ __device__ __forceinline__ uint32_t hash_mod24_2r(uint64_t x, int k, uint32_t c,
     const uint32_t mask = (1u << k) - 1u, lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
     const uint32_t a0 = lo & mask, h0 = (hi << (32 - k)) | (lo >> k);
     const uint32_t y1 = __umul24(c, h0), a1 = y1 & mask, h1 = y1 >> k;
-    int32_t v = (int32_t)(a0 + __umul24(c, h1)) - (int32_t)a1;
-    v += (v < 0) ? (int32_t)T : 0;
-    v -= (v >= (int32_t)T) ? (int32_t)T : 0;
-    return (uint32_t)v;
+    uint32_t v = (a0 + __umul24(c, h1)) - a1;       // in (-2^k, 2^k + c h1) as a signed value: the two fix-ups as unsigned minima
+    v = min(v, v + T);                                // (a negative value is a huge unsigned one: v + T wraps to the small result)
+    v = min(v, v - T);
+    return v;
+}
+
+// ONE folding round: x = h0 2^k + a0 == a0 - c h0 (mod T = 2^k + c).  Valid when c h0 < 2 T for every key the grid can form (host-checked
+// from its largest resolution: GridDev.mod1r — T = 2^20 + 7 with keys < 2^38: c h0 < 1.84 M < 2 T): a0 - c h0 + 2 T lies in (0, 3 T), two
+// fix-ups written as unsigned minima (v - T wraps above v when v < T).  Same value as hash_mod24 / _2r, 5 instructions fewer than _2r.
+__device__ __forceinline__ uint32_t hash_mod24_1r(uint64_t x, int k, uint32_t c, uint32_t T) {
+    const uint32_t mask = (1u << k) - 1u, lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    const uint32_t a0 = lo & mask, h0 = (hi << (32 - k)) | (lo >> k);
+    uint32_t v = a0 + (2u * T - __umul24(c, h0));
+    v = min(v, v - T);
+    v = min(v, v - T);
+    return v;
 }
 
 // ---- wave scans on the DPP network ------------------------------------------------------------------------------------------

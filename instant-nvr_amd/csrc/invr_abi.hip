@@ -61,6 +61,11 @@ GridDev make_grid_dev(const InvrGrid* g) {
             int64_t max_res = 0;
             for (int l = 0; l < g->n_levels && l < INVR_MAX_LEVELS; ++l) max_res = g->res[l] > max_res ? g->res[l] : max_res;
             d.xdelta = d.mod24 && d.T > (1ll << 14) && y2 < (1ull << k) && 2 * max_res <= d.T;      // (one +/- T fix-up: |delta| < 2 res <= T)
+            // one-round reduction (common.h:hash_mod24_1r): the keys are XORs of cx, cy * 19349663, cz * 83492791 with c. <= max_res - 1,
+            // so they stay below the next power of two above max_res * 83492791
+            int xbits = 0;
+            while (xbits < 62 && (1ull << xbits) <= (uint64_t)max_res * 83492791ull) ++xbits;
+            d.mod1r = d.xdelta && xbits > k && c * ((1ull << xbits) >> k) < 2ull * (uint64_t)d.T && 3ull * (uint64_t)d.T < (1ull << 31);
         }
     }
     for (int l = 0; l < INVR_MAX_LEVELS; ++l) {

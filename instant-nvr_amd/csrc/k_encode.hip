@@ -582,6 +582,9 @@ int launch_part_encode_bwd_lists(const GridDev& g, const float* x_soa, const flo
 #ifndef ENC_X2
 #define ENC_X2 1          // A/B round 5: encoder 0.553 -> 0.542 ms, frame -1.1 % (gpurun_out/r5h), bit-identical
 #endif
+#ifndef ENC_MOD1R
+#define ENC_MOD1R 1       // A/B round 5: encoder stage 0.534 -> 0.524 ms (gpurun_out/r5o), bit-identical
+#endif
 #ifndef ENC_HOIST
 #define ENC_HOIST 1       // A/B round 5: encoder stage 0.538 -> 0.528 ms (gpurun_out/r5i), bit-identical
 #endif
@@ -633,15 +636,30 @@ __device__ __forceinline__ float level_rowsum(const GridDev& g, const float* __r
             // back into [0, T) (T > 2^14 > 2 |delta|: host-checked, GridDev.xdelta), instead of four
             // more 3-round reductions
             const uint32_t m = (uint32_t)c0x ^ (uint32_t)c1x;
+#if ENC_MOD1R
+            if (g.mod1r) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint64_t X = hx[0] ^ hy[(k >> 1) & 1] ^ hz[k & 1];
+                    const uint32_t r0 = hash_mod24_1r(X, g.mod_k, g.mod_c, (uint32_t)g.T);
+                    row[k] = r0;
+                    // r0 + delta in (-T, 2 T): both fix-ups as unsigned minima (a negative value is a huge unsigned one)
+                    uint32_t r1 = r0 + m - 2u * ((uint32_t)X & m);
+                    r1 = min(r1, r1 + (uint32_t)g.T);
+                    r1 = min(r1, r1 - (uint32_t)g.T);
+                    row[4 + k] = r1;
+                }
+            } else
+#endif
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const uint64_t X = hx[0] ^ hy[(k >> 1) & 1] ^ hz[k & 1];
                 const uint32_t r0 = hash_mod24_2r(X, g.mod_k, g.mod_c, (uint32_t)g.T);
                 row[k] = r0;
-                int32_t r1 = (int32_t)r0 + (int32_t)m - 2 * (int32_t)((uint32_t)X & m);
-                r1 += (r1 < 0) ? (int32_t)g.T : 0;
-                r1 -= (r1 >= (int32_t)g.T) ? (int32_t)g.T : 0;
-                row[4 + k] = (uint32_t)r1;
+                uint32_t r1 = r0 + m - 2u * ((uint32_t)X & m);
+                r1 = min(r1, r1 + (uint32_t)g.T);
+                r1 = min(r1, r1 - (uint32_t)g.T);
+                row[4 + k] = r1;
             }
         } else if (g.mod24) {
 #pragma unroll
