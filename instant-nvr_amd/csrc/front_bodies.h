@@ -234,6 +234,34 @@ __device__ __forceinline__ void cull_flag_body(const RenderArgs& a, const Worksp
                             fmaxf(fabsf(rn[0]), fabsf(rf[0])) * (fabsf(d[0]) + fabsf(d[1]) + fabsf(d[2]));
             const bool ok_ray = 2e-6f * M * fmaxf(fmaxf(pre[0], pre[1]), pre[2]) <= 0.5f * CULL_PRE_DELTA;      // (NaN: false)
             const VolDev& v = a.scene.pbw;
+            // One look-up for the thread's whole segment (w.use_d1: k_dilate_mask ran for this frame).  The lattice coordinates of its
+            // four samples lie between those of the first and the last (affine in z, z monotone in the sample index, the clamp monotone):
+            // within h = half that span of the midpoint's, per axis.  The exact path's coordinate of a sample differs from the affine
+            // form by < CULL_PRE_DELTA (ok_ray), so with h + 2 CULL_PRE_DELTA < 1 every sample's EXACT cell is within +-1 of the
+            // midpoint's cell on every axis — and if the dilated mask is clear there, none of the four can survive: no candidates.
+            bool need = true;
+            if (w.use_d1) {
+                const int s0 = (int)f_s, s3 = (int)f_s + 3;
+                const float t0 = (s0 < a.S / 2) ? lin_step * (float)s0 : 1.0f - lin_step * (float)(a.S - 1 - s0);
+                const float t3 = (s3 < a.S / 2) ? lin_step * (float)s3 : 1.0f - lin_step * (float)(a.S - 1 - s3);
+                const float z0 = rn[0] * (1.0f - t0) + rf[0] * t0, z3 = rn[0] * (1.0f - t3) + rf[0] * t3;
+                const float zm = 0.5f * (z0 + z3), hz = 0.5f * fabsf(z3 - z0);
+                const float h = hz * fmaxf(fmaxf(fabsf(B[0]), fabsf(B[1])), fabsf(B[2]));
+                const float mx = fminf(fmaxf(fmaf(zm, B[0], A[0]), 0.0f), (float)(v.dx - 1));
+                const float my = fminf(fmaxf(fmaf(zm, B[1], A[1]), 0.0f), (float)(v.dy - 1));
+                const float mz = fminf(fmaxf(fmaf(zm, B[2], A[2]), 0.0f), (float)(v.dz - 1));
+                const int mc = (int)fmaf(fmaf(floorf(mx), (float)v.dy, floorf(my)), (float)v.dz, floorf(mz));
+                const bool seg_ok = ok_ray && h + 2.0f * CULL_PRE_DELTA + 1e-3f < 1.0f;          // (NaN: false)
+#ifdef CULL_D1_MUTATE          // (test builds only: a WRONG skip rule — the exact survivor-set tests must catch it)
+                need = !(seg_ok && w.cullmask[mc] == 0);
+#else
+                need = !(seg_ok && w.cullmask_d1[mc] == 0);
+#endif
+            }
+            if (!need) {
+#pragma unroll
+                for (int k = 0; k < CULL_PER; ++k) { zz[k] = 0.0f; sure[k] = true; cell[k] = -1; valid[k] = false; }      // no candidate, no mask read
+            } else
 #pragma unroll
             for (int k = 0; k < CULL_PER; ++k) {
                 const int sk = (int)f_s + k;
@@ -259,7 +287,7 @@ __device__ __forceinline__ void cull_flag_body(const RenderArgs& a, const Worksp
         }
         uint8_t mb[CULL_PER];
 #pragma unroll
-        for (int k = 0; k < CULL_PER; ++k) mb[k] = w.cullmask[cell[k]];
+        for (int k = 0; k < CULL_PER; ++k) mb[k] = cell[k] >= 0 ? w.cullmask[cell[k]] : (uint8_t)0;
         if (a.z_vals) {
 #pragma unroll
             for (int k = 0; k < CULL_PER; ++k)

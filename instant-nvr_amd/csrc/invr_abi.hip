@@ -257,6 +257,8 @@ static size_t carve(Workspace& w, void* base, int64_t N, int64_t cap) {
     w.dslice = c.take<float2>(DF_SLICE_MAX);
     w.cullmask = c.take<uint8_t>(CULL_MASK_MAX);
     w.pdist = c.take<float>(lc * INVR_NUM_PARTS);          // (last: every older offset of invr_workspace_layout is unchanged)
+    w.cullmask_d1 = c.take<uint8_t>(CULL_MASK_MAX);
+    w.use_d1 = 0;
     return align_up(c.off, 256);
 }
 

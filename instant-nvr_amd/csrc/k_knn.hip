@@ -1107,6 +1107,22 @@ int launch_front_scene(const RenderArgs& a, const Workspace& w, const GridDev& d
     return 0;
 }
 
+// cullmask OR-dilated by one cell in every direction (27 bytes per cell, L2-resident): d1[c] = 0 means no cell within +-1 of c can hold a survivor
+__global__ __launch_bounds__(256) void k_dilate_mask(int dx, int dy, int dz, const uint8_t* __restrict__ mask, uint8_t* __restrict__ d1) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= dx * dy * dz) return;
+    const int z0 = i % dz, y0 = (i / dz) % dy, x0 = i / (dz * dy);
+    unsigned any = 0;
+    for (int x = max(x0 - 1, 0); x <= min(x0 + 1, dx - 1); ++x)
+        for (int y = max(y0 - 1, 0); y <= min(y0 + 1, dy - 1); ++y)
+#pragma unroll
+            for (int dzz = -1; dzz <= 1; ++dzz) {
+                const int z = min(max(z0 + dzz, 0), dz - 1);
+                any |= mask[(x * dy + y) * dz + z];
+            }
+    d1[i] = any ? 1 : 0;
+}
+
 template <bool FAST, bool RAY4>
 __attribute__((amdgpu_waves_per_eu(8, 8)))
 __global__ __launch_bounds__(CULL_BLOCK) void k_front_cull(RenderArgs a, Workspace w, double inv_S, float lin_step, int vc_gx) {
@@ -1132,6 +1148,16 @@ int launch_front_cull(const RenderArgs& a, const Workspace& w, int* done, hipStr
     const bool fast = !a.wpts && !a.jitter && a.N < (1ll << 31) && cells * v.c < (1ll << 31) && a.S >= 2 &&
                       v.dx <= 1024 && v.dy <= 1024 && v.dz <= 1024;      // (front_bodies.h: the pre-test's error bound)
     const unsigned grid = gx * INVR_NUM_PARTS + (unsigned)nb;
+    static const bool no_d1 = getenv("INVR_NO_CULL_D1") != nullptr;
+    if (fast && (a.S & 3) == 0 && !a.z_vals && !no_d1) {
+        // the cell mask dilated by one cell (k_dilate_mask, ~3 us between the two front launches): a thread of the RAY4 cull drops
+        // its four samples on ONE look-up when the whole segment provably stays inside dead cells (front_bodies.h)
+        Workspace w2 = w;
+        w2.use_d1 = 1;
+        hipLaunchKernelGGL(k_dilate_mask, dim3((unsigned)cdiv(cells, 256)), dim3(256), 0, st, v.dx, v.dy, v.dz, w.cullmask, w.cullmask_d1);
+        INVR_LAUNCH_CHECK();
+        hipLaunchKernelGGL((k_front_cull<true, true>), dim3(grid), dim3(CULL_BLOCK), 0, st, a, w2, inv_S, lin_step, (int)gx);
+    } else
     if (fast && (a.S & 3) == 0) hipLaunchKernelGGL((k_front_cull<true, true>), dim3(grid), dim3(CULL_BLOCK), 0, st, a, w, inv_S, lin_step, (int)gx);
     else if (fast) hipLaunchKernelGGL((k_front_cull<true, false>), dim3(grid), dim3(CULL_BLOCK), 0, st, a, w, inv_S, lin_step, (int)gx);
     else hipLaunchKernelGGL((k_front_cull<false, false>), dim3(grid), dim3(CULL_BLOCK), 0, st, a, w, inv_S, lin_step, (int)gx);

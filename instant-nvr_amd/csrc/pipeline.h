@@ -88,6 +88,8 @@ struct Workspace {
     float4* rgbw;                         // cap + 8 : [rgb, occ] of the winning listed pair per survivor; [lcap + p] = far constant of part p
     uint8_t* cullmask;                    // CULL_MASK_MAX : 1 if the trilinear cell can hold a survivor (k_cull.hip)
     float2* dslice;                       // DF_SLICE_MAX : per-frame t-slices of the deformer grid (k_warp.hip)
+    uint8_t* cullmask_d1;                 // CULL_MASK_MAX : cullmask OR-dilated by one cell in every direction (k_dilate_mask; valid when use_d1)
+    int32_t use_d1;                       // this frame's k_front_cull may drop a thread's 4-sample segment on one look-up of cullmask_d1
     float* pdist;                         // 5*lcap : cfg.aggr 'dist' / 'mindist' only — the KNN's weighted distance of EVERY (slot, part), [slot][p]
     int64_t cap;                          // max survivors
     int64_t lcap;                         // cap + 1: list / per-slot array capacity (stride of the SoA lists)

@@ -321,12 +321,13 @@ class Network(nn.Module):
         return out
 
     def render_rays(self, batch, ray_o, ray_d, near, far, n_samples, jitter=None, want_raw=True,
-                    want_weights=False, max_active=0, stream=None):
+                    want_weights=False, max_active=0, stream=None, raw_out=None):
         """One invr_render_fwd call over a ray list (n,3)/(n,).  `batch` is the collated batch dict
         or a RenderContext from prepare().  Returns a dict of device tensors.
         stream: launch on THAT torch stream instead of the current one while every tensor (outputs, workspace) still comes from the
         current stream's allocator pool (Renderer.in_flight lanes: K streams must not mean K private pools of 4 GB workspaces and
-        0.5 GB raw tensors); the caller orders `stream` behind the current stream before the call, the tensors are recorded on it."""
+        0.5 GB raw tensors); the caller orders `stream` behind the current stream before the call, the tensors are recorded on it.
+        raw_out: a flat float32 device buffer of at least n * S * 4 elements to hold `raw` (a lane's buffer nobody references any more)."""
         L = _abi.lib()
         dev = ray_o.device
         ctx = batch if isinstance(batch, RenderContext) else self.prepare(batch)
@@ -339,7 +340,7 @@ class Network(nn.Module):
         out = {'rgb_map': torch.empty(n, 3, device=dev), 'acc_map': torch.empty(n, device=dev),
                'stats': (torch.empty if n else torch.zeros)(_abi.STATS_LEN, dtype=torch.int32, device=dev)}
         if want_raw:
-            out['raw'] = torch.empty(n * S, 4, device=dev)
+            out['raw'] = torch.empty(n * S, 4, device=dev) if raw_out is None else raw_out[:n * S * 4].view(n * S, 4)
         if want_weights:
             out['weights'] = torch.empty(n, S, device=dev)
             out['z_vals'] = torch.empty(n, S, device=dev)

@@ -255,6 +255,28 @@ class _Lane:
         self.stream = torch.cuda.Stream(device)
         self.ws = None
         self.pending = None
+        self.stats_host = None       # a page-locked copy target for the frame's statistics block (64 bytes, allocated once per lane)
+        self.raw_buf = None          # the lane's `raw` buffer (0.5 GB for 512x512x128): handed to the next frame once nobody references it
+
+    def raw_buffer(self, numel, device):
+        """A flat float32 buffer of >= numel elements for this frame's raw: the lane's previous one when every dict / tensor that
+        viewed it is gone (the common loop reads the maps and drops the dict: no 0.5 GB allocation per frame — hipMalloc of such
+        blocks took up to seconds when the caching allocator had to go back to the driver), else a fresh one."""
+        buf = self.raw_buf
+        if buf is not None and buf.numel() >= numel and buf.device == device:
+            try:
+                free = torch._C._storage_Use_Count(buf.untyped_storage()._cdata) <= 2          # `buf` itself + the wrapper just made
+            except Exception:
+                free = False
+            if free:
+                return buf
+        self.raw_buf = torch.empty(int(numel * 1.05) + 1024, device=device, dtype=torch.float32)
+        return self.raw_buf
+
+    def stats_buffer(self, like):
+        if self.stats_host is None or self.stats_host.shape != like.shape:
+            self.stats_host = torch.empty(like.shape, dtype=like.dtype, pin_memory=True)
+        return self.stats_host
 
 
 class _PendingFrame:
@@ -263,7 +285,7 @@ class _PendingFrame:
     incomplete), and returns (maps, lazy): eval_to_cpu -> host maps + device raw / occ for LazyHostRet, else the device dict."""
     def __init__(self, renderer, lane, call, cap, keep):
         self.r, self.lane, self.call, self.cap, self.keep = renderer, lane, call, cap, keep
-        self.out = self.stats_host = self.event = self.host = None
+        self.out = self.stats_host = self.event = None
         self._res = None
 
     def launch(self):
@@ -280,15 +302,12 @@ class _PendingFrame:
         finally:
             lane.ws, net._ws = net._ws, prev
         with torch.cuda.stream(lane.stream):
-            self.stats_host = torch.empty(out['stats'].shape, dtype=out['stats'].dtype, pin_memory=True)
+            # only the 64-byte statistics block follows the render asynchronously (the lane's own page-locked buffer: the frame that
+            # used it last was joined before the lane rendered again).  The image maps are copied when the frame is JOINED
+            # (result()): into ordinary host tensors — per-frame page-locked allocations stalled for 25 .. 90 ms in some allocator
+            # states, and page-locked memory is uncached for the CPU here (a consumer reads a 3 MB map in 4.6 ms instead of 0.03)
+            self.stats_host = lane.stats_buffer(out['stats'])
             self.stats_host.copy_(out['stats'], non_blocking=True)
-            self.host = {}
-            if r.eval_to_cpu:                 # the image maps follow the render on the lane's stream: on the host when the event fires
-                for k in ('rgb_map', 'acc_map'):
-                    v = out[k][None]
-                    h = torch.empty(v.shape, dtype=v.dtype, device='cpu', pin_memory=r.pin_host)
-                    h.copy_(v, non_blocking=True)
-                    self.host[k] = h
             self.event = torch.cuda.Event()
             self.event.record(lane.stream)
         return out
@@ -307,7 +326,7 @@ class _PendingFrame:
             self.out = self._run(0)
             lane.stream.synchronize()
             lane.ws = None          # ~1150 B per ray-sample: the next frame of this lane gets one sized from the new survivor count
-        st = self.stats_host
+        st = self.stats_host.clone()                                      # (the lane's buffer is reused by its next frame)
         if int(st[6]) != 0:
             raise RuntimeError('invr_render_fwd reported stats[6] = %d: workspace overflow' % int(st[6]))
         # grow-only: the K lanes' workspaces settle at ONE size — the largest frame seen — after a few frames.  (Following every
@@ -328,7 +347,9 @@ class _PendingFrame:
         self.keep = self.call = None           # the frame's inputs may go
         if r.eval_to_cpu:
             lazy = {k: dev[k] for k in ('raw', 'occ') if k in dev}
-            host = dict(self.host)
+            maps = LazyHostRet({}, {k: dev[k] for k in ('rgb_map', 'acc_map')}, r.pin_host)          # 4 MB, now: the frame is complete, the
+            maps._fetch(('rgb_map', 'acc_map'))                                                       # other lanes keep rendering beside the copy
+            host = dict(maps)
             if not r.lazy_host:
                 tmp = LazyHostRet(host, lazy, r.pin_host)
                 tmp._fetch(tuple(lazy))
@@ -336,7 +357,7 @@ class _PendingFrame:
             self._res = (host, lazy)
         else:
             self._res = (dev, {})
-        self.out = self.host = None
+        self.out = None
         return self._res
 
 
@@ -348,9 +369,10 @@ class Renderer:
         self.eval_to_cpu = True        # reference moves every eval output to the CPU (:199-200)
         self.want_raw = True           # reference always returns raw/occ
         self.adaptive_cap = True       # size the workspace from the previous frame's survivor count (eval_to_cpu only)
-        self.pin_host = True           # eval_to_cpu: page-locked host tensors for the outputs (False: ordinary pageable tensors; note
-                                       # that torch's caching host allocator keeps page-locked blocks: a caller that retains the raw /
-                                       # occ of many frames pins that much host memory)
+        self.pin_host = False          # eval_to_cpu: True = page-locked host tensors for the outputs (a faster copy: 26 instead of ~100 ms for
+                                       # the 656 MB of raw + occ) — off by default since round 5: torch's page-locked memory is UNCACHED for
+                                       # the CPU on this platform, a consumer reads it at ~1 GB/s (4.6 ms per pass over a 3 MB rgb_map,
+                                       # 0.03 ms from an ordinary tensor), which costs a caller more than the copy saved
         self.lazy_host = True          # eval_to_cpu: raw / occ reach the host on first access (LazyHostRet); False: with the maps
         # Frames in flight across render() calls (cfg.render_in_flight, default 1 = every call on the caller's stream as before).
         # K > 1: eval frame f is launched on lane f % K — a stream and a workspace of its own — and render() returns at once with a
@@ -442,8 +464,10 @@ class Renderer:
             lane.pending.result()              # the frame rendered here K calls ago (long done): releases its inputs, updates the cap hint
         n_samp = ray_o.shape[0] * S
         cap = min(n_samp, max(self._cap_hint if self._cap_hint is not None else n_samp // 4, 65536)) if self.adaptive_cap else 0
+        self._raw_numel = max(getattr(self, '_raw_numel', 0), n_samp * 4)          # grow-only, renderer-wide: every lane's raw buffer fits the largest frame seen
         ctx = self.net.prepare(batch)          # on the caller's stream: a stale row-sum table is rebuilt in front of every lane
-        call = lambda c, st: self.net.render_rays(ctx, ray_o, ray_d, near, far, S, jitter=jitter, want_raw=self.want_raw, max_active=c, stream=st)
+        call = lambda c, st: self.net.render_rays(ctx, ray_o, ray_d, near, far, S, jitter=jitter, want_raw=self.want_raw, max_active=c, stream=st,
+                                                  raw_out=lane.raw_buffer(self._raw_numel, dev) if self.want_raw else None)
         pend = _PendingFrame(self, lane, call, cap, (batch, ctx, ray_o, ray_d, near, far, jitter))
         pend.launch()
         lane.pending = pend
@@ -486,7 +510,7 @@ class Renderer:
             if lane.pending is not None:
                 lane.pending.result()
             if release:
-                lane.ws = None
+                lane.ws = lane.raw_buf = None
 
     def _jitter(self, shape, device):
         return torch.rand(shape, device=device, dtype=torch.float32)

@@ -40,4 +40,4 @@ for rep in range(2):
     t0 = time.perf_counter(); sweep(40); dt = (time.perf_counter() - t0) / 40 * 1e3
     print('to_cpu', to_cpu, 'ms per frame %.3f' % dt, 'allocated GB %.1f' % (torch.cuda.memory_allocated() / 1e9), 'reserved GB %.1f' % (torch.cuda.memory_reserved() / 1e9),
           {k: '%.2f / max %.1f' % (sum(v) / max(len(v), 1), max(v) if v else 0) for k, v in ph.items()}, flush=True)
-    r.flush(release=True); del r; torch.cuda.synchronize(); torch.cuda.empty_cache()
+    r.flush(); del r; torch.cuda.synchronize()
