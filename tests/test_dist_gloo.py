@@ -221,3 +221,11 @@ def test_grad_reducer_world8_averages_every_block():
     ret = mgr.dict()
     mp.spawn(_reduce_worker, args=(8, _free_port(), ret), nprocs=8, join=True)
     assert all(ret[r] for r in range(8)), dict(ret)
+
+
+def test_tile_indices_rank_beyond_the_tile_count_is_empty():
+    """(the world-8 FrameSet test's bug: torch.arange(rank, n_tiles, world) raises for rank > n_tiles)"""
+    for n, world, tile in ((30, 8, 64), (1, 8, 512), (130, 8, 64), (0, 4, 64)):
+        got = [idist.tile_indices(n, r, world, tile) for r in range(world)]
+        assert sorted(torch.cat(got).tolist()) == list(range(n))
+        assert all(g.dtype == torch.int64 for g in got)

@@ -80,3 +80,21 @@ def test_lazy_train_ret_dict_views_see_thunks_and_lazy_tensors():
         assert type(d) is dict and set(d) == {'rgb_map', 'resd', 'tocc', 'offset_loss'} and float(d['offset_loss']) == 2.0
     r = mk()
     assert float(r.pop('offset_loss')) == 2.0 and 'offset_loss' not in r and len(r) == 3
+
+
+def test_lane_raw_buffer_is_reused_only_when_unreferenced():
+    """Renderer lanes (in_flight > 1) hand the previous frame's raw buffer to the next frame only when no dict / tensor views it any
+    more (storage use count) — a caller that kept `ret['raw']` keeps its data."""
+    from invr.renderer import _Lane
+    lane = _Lane.__new__(_Lane)
+    lane.raw_buf = None
+    dev = torch.device('cpu')
+    a = lane.raw_buffer(1000, dev)
+    assert a.numel() >= 1000 and lane.raw_buffer(900, dev) is a                     # nobody else references it: reused
+    view = a[:400].view(100, 4)                                                    # (what a returned dict holds)
+    b = lane.raw_buffer(900, dev)
+    assert b is not a and b.untyped_storage().data_ptr() != a.untyped_storage().data_ptr()
+    del view, a
+    assert lane.raw_buffer(900, dev) is b
+    c = lane.raw_buffer(10 * b.numel(), dev)                                       # a larger frame: a larger buffer
+    assert c is not b and c.numel() >= 10 * b.numel()
