@@ -60,8 +60,14 @@ def full_net():
     from invr.network import Network
     dev = 'cuda:0'
     cfg = make_cfg(N_samples=128)
-    with torch.device(dev):
-        net = Network(cfg=cfg)
+    # the MLP weights come from torch's default initialisers on the device: SEEDED here (round 5) — this torch seeds its default
+    # generators randomly per process (torch.cuda.initial_seed() differs from run to run), so the "shared full-size model" was a
+    # different model in every run, and the tests that compare it with the host's fp32 oracle passed or failed with the draw (the
+    # deformer's pair-term gradient of test_configs4 ranged over 2.6e-5 .. 3e-3 in scale between runs)
+    with torch.random.fork_rng(devices=[0]):
+        torch.manual_seed(20240928)
+        with torch.device(dev):
+            net = Network(cfg=cfg)
     net = net.to(dev).eval()
     g = torch.Generator(device=dev).manual_seed(0)
     with torch.no_grad():
