@@ -13,7 +13,8 @@ task=$1; T=${2:-$1}; shift 2 2>/dev/null
 OUT=gpurun_out/$T; mkdir -p $OUT
 case $task in
   tests)
-    timeout 1700 python -m pytest ${@:-tests} -q -m gpu --durations=8 > $OUT/pytest.log 2>&1; tail -25 $OUT/pytest.log ;;
+    if [ $# -eq 0 ]; then set -- tests; fi          # ("$@": a -k expression with spaces stays one argument)
+    timeout 1700 python -m pytest "$@" -q -m gpu --durations=8 > $OUT/pytest.log 2>&1; tail -25 $OUT/pytest.log ;;
   trace)
     cd /tmp
     B="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-variants --no-graph --train-iters 0"
