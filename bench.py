@@ -648,7 +648,7 @@ def main():
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             ok = int(flag.item())
         if ok:
-            mode_name = name
+            mode_name = name if world > 1 else ('graph' if cap else 'eager')          # (one GPU: nothing to exchange)
             break
         fs = None
         torch.cuda.empty_cache()
