@@ -230,6 +230,28 @@ def frame_set(net, batches, S, rank, world, shard_of=0, want_raw=True, capture=T
     return fs
 
 
+def replay_bit_exact(fs, net, S, want_raw):
+    """The frames the LAST timed replay left in `fs.local` against one separate eager render of each frame (same rays, same survivor
+    capacity, a scratch workspace of its own), bit for bit: rgb_map, acc_map and raw.  The headline is timed with K frames in flight;
+    round 5 saw one such replay differ once (profiles/r6_replay_mismatch.md has the cause) — a differing frame must never go
+    unnoticed in the line that reports the rate.  -> (bool, detail)"""
+    keys = ('rgb_map', 'acc_map') + (('raw',) if want_raw else ())
+    scratch = None
+    bad = []
+    for k, (ctx, a, ws) in enumerate(fs._keep):
+        cap = fs.local[k]['_ws'][3]
+        if scratch is None or scratch.numel() < ws.numel():
+            scratch = torch.empty(ws.numel(), dtype=torch.uint8, device=ws.device)
+        net._ws = scratch
+        ref = net.render_rays(ctx, a[0], a[1], a[2], a[3], S, want_raw=want_raw, max_active=cap)
+        for key in keys:
+            if not torch.equal(ref[key], fs.local[k][key]):
+                ne = ref[key].view(torch.int32) != fs.local[k][key].view(torch.int32)
+                bad.append({'frame': k, 'tensor': key, 'differing_elements': int(ne.sum())})
+    net._ws = None
+    return not bad, {'frames_compared': len(fs._keep), 'tensors': list(keys), 'differing': bad}
+
+
 def time_frames(fn, frames, min_time=0.0, max_regions=200):
     """ms per call of fn(): regions of exactly `frames` calls between two synchronisations, repeated until min_time seconds."""
     fn()
@@ -683,6 +705,12 @@ def main():
         assert fs.full[k] is not None and fs.full[k].shape[0] == (rays_per_frame[k] if not args.shard_of else fs.full[k].shape[0])
         assert bool(torch.isfinite(fs.full[k]).all())
     frame_stats = [o['stats'].cpu().numpy().astype('int64') for o in fs.local]
+    # what the last timed replay produced, against separate renders of the same frames, bit for bit (every rank its own shards)
+    bit_exact, bit_detail = replay_bit_exact(fs, net, S, want_raw)
+    if world > 1:
+        flag = torch.tensor([1 if bit_exact else 0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        bit_exact = bool(int(flag.item()))
     # the exchange alone (N > 1): the captured all-gather + index_selects replayed without the renders
     exchange_ms = None
     exchange_captured = bool(fs.exchange and fs.exchange_captured)
@@ -846,6 +874,7 @@ def main():
                             'above the HBM peak'},
                 'note': 'the frame is issue-bound: KNN = VALU, part MLPs = MFMA + transcendental issue, encoder = VALU index math + L2-miss '
                         'latency; see roofline / roofline_other counters'},
+            'replay_bit_exact': bit_exact, 'replay_check': bit_detail,
             'counters_stale': counters_stale, 'csrc_digest': csrc_digest(),
             'stage_ms_per_step': {k: v / per for k, v in stage_ms.items()},
             'stage_note': 'HIP-event stage times of frame 0 rendered ALONE (eager launches after the timed region); with %d frames in flight '

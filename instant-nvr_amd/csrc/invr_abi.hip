@@ -259,6 +259,7 @@ static size_t carve(Workspace& w, void* base, int64_t N, int64_t cap) {
     w.pdist = c.take<float>(lc * INVR_NUM_PARTS);          // (last: every older offset of invr_workspace_layout is unchanged)
     w.cullmask_d1 = c.take<uint8_t>(CULL_MASK_MAX);
     w.use_d1 = 0;
+    w.knn.srow = c.take<uint16_t>((size_t)INVR_NUM_PARTS * w.knn.mpad);
     return align_up(c.off, 256);
 }
 

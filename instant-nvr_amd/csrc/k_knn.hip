@@ -332,18 +332,20 @@ __device__ __forceinline__ void part_prepare_body(const SceneDev& s, const KnnIn
         __syncthreads();
     }
     KP(2)
-    // 4. sorted vertices, pair-interleaved {x0,x1,y0,y1} {z0,z1,row0,row1} (packed-fp32 distance math reads
-    //    two vertices per register pair), clusters of 64 and their four 16-vertex sub-clusters
+    // 4. sorted vertices, pair-interleaved {x0,x1,y0,y1} {z0,z1,n0,n1} with n = |v|^2 (packed-fp32 distance math reads two
+    //    vertices per register pair; n feeds the sweep's |v|^2 - 2 q.v prefilter), their rows inside the part as 16-bit entries of
+    //    a separate array (only read on an insert), clusters of 64 and their four 16-vertex sub-clusters
     const int64_t voff = (int64_t)p * ix.mpad;
     const int lenp = (len + 63) & ~63;
     float* svf = reinterpret_cast<float*>(ix.sverts + voff);
     for (int j = threadIdx.x; j < lenp; j += PREP_T) {
         // sentinel: infinitely far, never enters a top-4 -> clusters are always scanned as 64
-        float x = 1e30f, y = 1e30f, z = 1e30f;              // squared distance overflows to +inf
+        float x = 1e30f, y = 1e30f, z = 1e30f;              // squared distance and |v|^2 overflow to +inf
         int o = 0;
         if (j < len) { o = (int)(keys[j] & 8191u); x = v[o * 3]; y = v[o * 3 + 1]; z = v[o * 3 + 2]; }
         float* b = svf + (j >> 1) * 8 + (j & 1);
-        b[0] = x; b[2] = y; b[4] = z; b[6] = __int_as_float(o);
+        b[0] = x; b[2] = y; b[4] = z; b[6] = (x * x + y * y) + z * z;
+        ix.srow[voff + j] = (uint16_t)o;                    // (PREP_MAX = 8192 rows: 13 bits)
     }
     KP(3)
     const int ncl = (len + 63) >> 6;
@@ -407,7 +409,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // reads are issued together; the squared distances of two vertices are formed with packed fp32 ops
 // (v_pk_add/mul_f32 — each component is the same IEEE op sequence as ((p1-p2)**2).sum(-1)); one fp32
 // compare against the current 4th best guards the exact 64-bit-key inserts of both.
-__device__ __forceinline__ void scan_sub16(const float4* sv, v2f px, v2f py, v2f pz, Top4& t KP_SCAN_ARG) {
+__device__ __forceinline__ void scan_sub16(const float4* sv, const unsigned* rw, v2f px, v2f py, v2f pz, Top4& t KP_SCAN_ARG) {
 #pragma unroll
     for (int m0 = 0; m0 < 8; m0 += 4) {
         float4 A[4], B[4];
@@ -419,8 +421,56 @@ __device__ __forceinline__ void scan_sub16(const float4* sv, v2f px, v2f py, v2f
             const v2f d2 = (dx * dx + dy * dy) + dz * dz;
             KP_INS(fminf(d2.x, d2.y) <= t.worst())
             if (fminf(d2.x, d2.y) <= t.worst()) {
-                t.push_net(d2.x, __float_as_int(B[k].z));
-                t.push_net(d2.y, __float_as_int(B[k].w));
+                const unsigned r = rw[m0 + k];                                     // rows of the two vertices, 16 bits each
+                t.push_net(d2.x, (int)(r & 0xFFFFu));
+                t.push_net(d2.y, (int)(r >> 16));
+            }
+        }
+    }
+}
+
+// The sweep's form of scan_sub16 (round 6).  |q - v|^2 = |v|^2 - 2 q.v + |q|^2: with n = |v|^2 in the record, s = n + a.v (a = -2q,
+// three packed FMAs for two vertices) decides against thr = worst - |q|^2 + delta whether a vertex CAN be among the lane's four
+// nearest; only then the exact squared distance — the reference's ((p1 - p2)**2).sum(-1) operation for operation — is formed and
+// inserted, so the kept keys are those of scan_sub16 bit for bit (a vertex whose exact key is below the lane's fourth is never
+// skipped; pushing a vertex that is not is a no-op of the min / max network).
+// Error budget, u = 2^-24, M = |q| + max |v| of the part: n carries <= 3u |v|^2, the FMA chain <= 3u (|v|^2 + 2 |q||v|), Q = fl(|q|^2)
+// <= 3u |q|^2, the exact path |D - T| <= 5u T, forming thr <= 4u M^2  ->  <= 19u M^2 in total; delta = 32u M^2 = 2^-19 M^2
+// (1.2e-5 m^2 for M = 2.5 m: 1-5 % of a near pair's 4th-best squared distance, nothing for a band pair's).  A sentinel vertex
+// (n = +inf) gives s = +inf: it passes only while thr is still +inf, and its exact distance +inf leaves the list unchanged as before.
+// 5 instead of 11 VALU instructions per pair record that holds no candidate (74 % of the records, tools/knn_order_model.py counters).
+__device__ __forceinline__ void scan_sub16_pf(const float4* sv, const unsigned* rw, v2f ax, v2f ay, v2f az, v2f px, v2f py, v2f pz,
+                                              const float qd, float& thr, Top4& t KP_SCAN_ARG) {
+#pragma unroll
+    for (int m0 = 0; m0 < 8; m0 += 4) {
+        float4 A[4], B[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { A[k] = sv[(m0 + k) * 2]; B[k] = sv[(m0 + k) * 2 + 1]; }   // wave-uniform addresses
+        v2f s[4];                                // the four records' chains interleaved: no wait state between dependent packed FMAs
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[k] = __builtin_elementwise_fma(az, (v2f){B[k].x, B[k].y}, (v2f){B[k].z, B[k].w});
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[k] = __builtin_elementwise_fma(ay, (v2f){A[k].z, A[k].w}, s[k]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[k] = __builtin_elementwise_fma(ax, (v2f){A[k].x, A[k].y}, s[k]);
+        // (the empty statement keeps the twelve FMAs in front of the first test — the optimizer sinks each chain to its use otherwise;
+        // v_min_f32 spelled out: fminf of a value that came through the statement is canonicalized first, two more instructions per
+        // record — s is never a NaN: finite operands, or +inf from a sentinel's |v|^2)
+        asm volatile("" : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float smin;
+            asm("v_min_f32 %0, %1, %2" : "=v"(smin) : "v"(s[k].x), "v"(s[k].y));
+            if (smin <= thr) {
+                const v2f dx = px - (v2f){A[k].x, A[k].y}, dy = py - (v2f){A[k].z, A[k].w}, dz = pz - (v2f){B[k].x, B[k].y};
+                const v2f d2 = (dx * dx + dy * dy) + dz * dz;
+                KP_INS(fminf(d2.x, d2.y) <= t.worst())
+                if (fminf(d2.x, d2.y) <= t.worst()) {
+                    const unsigned r = rw[m0 + k];                                 // rows of the two vertices, 16 bits each
+                    t.push_net(d2.x, (int)(r & 0xFFFFu));
+                    t.push_net(d2.y, (int)(r >> 16));
+                    thr = t.worst() - qd;
+                }
             }
         }
     }
@@ -432,10 +482,10 @@ __device__ __forceinline__ void scan_sub16(const float4* sv, v2f px, v2f py, v2f
 // wave-uniform (broadcast) ds_read_b128.  (The scalar-cache path was tried first: with a working set
 // of ~7x the 16 KB scalar cache its miss path throttled the kernel to ~30 % VALU utilisation.)
 #define KNN_T 1024
-#define KNN_LDS_MAX_V 8192          // float4 vertex slots (131 KB) + 11 record float4 per cluster must fit 160 KB
+#define KNN_LDS_MAX_V 7680          // float4 vertex slots (123 KB) + 2 bytes of row per slot + 11 record float4 per cluster must fit 160 KB
 
 #define KNN_LDS_HDR 8               // float4: the LDS carve table (offsets / lengths of the five parts)
-#define KNN_LDS_FLOAT4 (KNN_LDS_HDR + KNN_LDS_MAX_V + (KNN_LDS_MAX_V / 64 + INVR_NUM_PARTS) * 11)
+#define KNN_LDS_FLOAT4 (KNN_LDS_HDR + KNN_LDS_MAX_V + KNN_LDS_MAX_V / 8 + (KNN_LDS_MAX_V / 64 + INVR_NUM_PARTS) * 11)
 
 // Fallback when the posed vertex sets of the five parts do not fit the LDS-resident index together (> 8192 vertex slots, e.g.
 // SMPL-X): brute force per (survivor, part) over LDS tiles of the part's vertices — the arithmetic of k_knn_dense, the outputs of
@@ -518,6 +568,7 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w) 
     KP_DECL
     // LDS carve from the (device-resident) part lengths: [vertices of part 0..4 | records of part 0..4]
     KnnLds L;
+    int roff = 0;
     {
         int off = 0;
         for (int p = 0; p < INVR_NUM_PARTS; ++p) {
@@ -529,6 +580,8 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w) 
             knn_pairs_bf<KNN_T>(a, w, lds);
             return;
         }
+        roff = off;                                      // the 16-bit rows of all vertex slots: slot j of part p at 2-byte entry voff[p] + j
+        off += off / 8;
         for (int p = 0; p < INVR_NUM_PARTS; ++p) { L.coff[p] = off; off += (L.len[p] + 63) / 64 * 3; }
         for (int p = 0; p < INVR_NUM_PARTS; ++p) { L.soff[p] = off; off += (L.len[p] + 63) / 64 * 8; }
         if (threadIdx.x == 0)
@@ -540,6 +593,8 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w) 
     for (int p = 0; p < INVR_NUM_PARTS; ++p) {
         const int len = L.len[p], ncl = (len + 63) >> 6;
         for (int j = threadIdx.x; j < ncl * 64; j += KNN_T) lds[L.voff[p] + j] = ix.sverts[(int64_t)p * ix.mpad + j];
+        for (int j = threadIdx.x; j < ncl * 8; j += KNN_T)            // (64 rows of 2 bytes = 8 float4 per cluster; mpad is a multiple of 64)
+            lds[roff + L.voff[p] / 8 + j] = reinterpret_cast<const float4*>(ix.srow + (int64_t)p * ix.mpad)[j];
         for (int j = threadIdx.x; j < ncl * 3; j += KNN_T) lds[L.coff[p] + j] = ix.cl[(int64_t)p * ix.cpad * 3 + j];
         for (int j = threadIdx.x; j < ncl * 8; j += KNN_T) lds[L.soff[p] + j] = ix.sub[(int64_t)p * ix.cpad * 8 + j];
     }
@@ -617,6 +672,7 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w) 
             const int ncl = (len + 63) >> 6;
             const float4* cl = lds + L_coff;                       // records {lo, hi, rep}
             const float4* sv = lds + L_voff;
+            const unsigned* rw = reinterpret_cast<const unsigned*>(lds + roff) + L_voff / 2;      // two 16-bit rows per pair record
             // candidate clusters of the wave: OR of the lattice-cell masks of its undecided lanes (all ones when a lane is
             // outside the lattice, the masks are off or the part has more than 64 clusters).  Lanes in decided cells take the
             // cell's class and request nothing.
@@ -681,8 +737,17 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w) 
             const int seed_c = __builtin_amdgcn_readlane(seed, __ffsll((long long)__ballot(scan)) - 1);
             if (full) {                                  // no bound to start from: the seed cluster is scanned unconditionally
 #pragma unroll 1
-                for (int s4 = 0; s4 < 4; ++s4) scan_sub16(sv + seed_c * 64 + s4 * 16, px2, py2, pz2, t KP_SCAN_PASS);
+                for (int s4 = 0; s4 < 4; ++s4) scan_sub16(sv + seed_c * 64 + s4 * 16, rw + seed_c * 32 + s4 * 8, px2, py2, pz2, t KP_SCAN_PASS);
             }
+            // prefilter constants of this (lane, part): a = -2 q, qd = |q|^2 - delta with delta = 2^-19 (|q| + max |v|)^2 (scan_sub16_pf)
+            const v2f ax2 = {-2.0f * px, -2.0f * px}, ay2 = {-2.0f * py, -2.0f * py}, az2 = {-2.0f * pz, -2.0f * pz};
+            const float q2 = (px * px + py * py) + pz * pz;
+            const float vmx = fmaxf(fabsf(bb[0]), fabsf(bb[3])), vmy = fmaxf(fabsf(bb[1]), fabsf(bb[4])), vmz = fmaxf(fabsf(bb[2]), fabsf(bb[5]));
+            const float mm = sqrtf(q2) + sqrtf((vmx * vmx + vmy * vmy) + vmz * vmz);
+            const float qd = q2 - mm * mm * 1.9073486328125e-06f;
+            // (lanes that do not scan this part — decided cell, far, provably unflagged — never pass the prefilter: they used to keep a
+            // top-4 of their own and pulled the wave into the insert branch for it)
+            float thr = scan ? t.worst() - qd : -__builtin_inff();
 #pragma unroll 1
             for (int k = full ? 1 : 0; (seed_c + k < ncl || seed_c - k >= 0) && !(dbg & 2); ++k) {
 #pragma unroll 1
@@ -698,7 +763,7 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w) 
                         const bool need_s = need && aabb_dist2(px, py, pz, lds_ld4(sb + c * 8 + s4 * 2), lds_ld4(sb + c * 8 + s4 * 2 + 1)) <= t.worst();
                         if (__ballot(need_s) == 0) continue;
                         KP_CNT(11)
-                        scan_sub16(sv + c * 64 + s4 * 16, px2, py2, pz2, t KP_SCAN_PASS);
+                        scan_sub16_pf(sv + c * 64 + s4 * 16, rw + c * 32 + s4 * 8, ax2, ay2, az2, px2, py2, pz2, qd, thr, t KP_SCAN_PASS);
                     }
                 }
             }
@@ -740,6 +805,12 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w) 
         for (int p = 0; p < INVR_NUM_PARTS; ++p)
             if (far_cnt[p]) atomicAdd(&w.counters[CNT_FAR + p], far_cnt[p]);
     KP_FLUSH
+    // The 16 waves of a workgroup leave together (round 6).  A workgroup fills its CU's LDS and its four SIMDs' registers (4 x 128), so
+    // no wave of another kernel ever runs beside this kernel's packed-fp32 sweep — except in the tail, when waves that ran out of
+    // tickets exited and freed their registers while their neighbours were still sweeping.  Packed-fp32 sequences beside waves of
+    // other kernels are what produced the wrong lanes of profiles/r6_replay_mismatch.md in k_warp_pairs; this kernel never showed
+    // them (0 differing neighbour rows / weights in 30,000 stressed frames), and the barrier keeps it that way by construction.
+    __syncthreads();
 }
 
 // The per-part pair lists from the flag bytes k_knn_pairs left per survivor: l_slot[p][0..count) = the survivors flagged for

@@ -152,36 +152,43 @@ int launch_vertex_mats(const RenderArgs& a, const Workspace& w, hipStream_t st) 
     return 0;
 }
 
+// canonical point / direction of pair i of part p's list
+__device__ __forceinline__ void warp_pair(const RenderArgs& a, const Workspace& w, const float4* __restrict__ vm, const int p, const int64_t i,
+                                          float* xb, float* db) {
+    const int slot = w.l_slot[p][i];
+    const int4 nn = reinterpret_cast<const int4*>(w.l_nn[p])[slot];       // (stored per survivor slot by k_knn_pairs)
+    const float4 wt = reinterpret_cast<const float4*>(w.l_w[p])[slot];
+    const float4* r0 = vm + (int64_t)nn.x * 6;
+    const float4* r1 = vm + (int64_t)nn.y * 6;
+    const float4* r2 = vm + (int64_t)nn.z * 6;
+    const float4* r3 = vm + (int64_t)nn.w * 6;
+    Mat34 Aw, Bw;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const float4 v0 = r0[j], v1 = r1[j], v2 = r2[j], v3 = r3[j];
+        float* o = j < 3 ? Aw.m + j * 4 : Bw.m + (j - 3) * 4;
+        o[0] = fmaf(wt.w, v3.x, fmaf(wt.z, v2.x, fmaf(wt.y, v1.x, wt.x * v0.x)));
+        o[1] = fmaf(wt.w, v3.y, fmaf(wt.z, v2.y, fmaf(wt.y, v1.y, wt.x * v0.y)));
+        o[2] = fmaf(wt.w, v3.z, fmaf(wt.z, v2.z, fmaf(wt.y, v1.z, wt.x * v0.z)));
+        o[3] = fmaf(wt.w, v3.w, fmaf(wt.z, v2.w, fmaf(wt.y, v1.w, wt.x * v0.w)));
+    }
+    float pp[3], pd[3];
+    sample_pose_point(a, w.active_idx[slot], pp[0], pp[1], pp[2], nullptr, pd);
+    warp_with_mats(Aw, Bw, pp, pd, xb, db);
+    if (!a.scene.tpose_viewdir) {                       // cfg.tpose_viewdir False: world view dir
+        int64_t ray = w.active_idx[slot] / a.S;
+        const float* vd = a.wpts ? a.wdirs : a.ray_d;
+        db[0] = vd[ray * 3]; db[1] = vd[ray * 3 + 1]; db[2] = vd[ray * 3 + 2];
+    }
+}
+
 __global__ __launch_bounds__(WARP_BLOCK) void k_warp_pairs(RenderArgs a, Workspace w) {
     const int p = blockIdx.y;
     const int cnt = w.counters[CNT_PAIRS + p];
     const float4* __restrict__ vm = w.knn.vmat + (int64_t)p * w.knn.mpad * 6;
     for (int64_t i = (int64_t)blockIdx.x * WARP_BLOCK + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * WARP_BLOCK) {
-        const int slot = w.l_slot[p][i];
-        const int4 nn = reinterpret_cast<const int4*>(w.l_nn[p])[slot];       // (stored per survivor slot by k_knn_pairs)
-        const float4 wt = reinterpret_cast<const float4*>(w.l_w[p])[slot];
-        const float4* r0 = vm + (int64_t)nn.x * 6;
-        const float4* r1 = vm + (int64_t)nn.y * 6;
-        const float4* r2 = vm + (int64_t)nn.z * 6;
-        const float4* r3 = vm + (int64_t)nn.w * 6;
-        Mat34 Aw, Bw;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const float4 v0 = r0[j], v1 = r1[j], v2 = r2[j], v3 = r3[j];
-            float* o = j < 3 ? Aw.m + j * 4 : Bw.m + (j - 3) * 4;
-            o[0] = fmaf(wt.w, v3.x, fmaf(wt.z, v2.x, fmaf(wt.y, v1.x, wt.x * v0.x)));
-            o[1] = fmaf(wt.w, v3.y, fmaf(wt.z, v2.y, fmaf(wt.y, v1.y, wt.x * v0.y)));
-            o[2] = fmaf(wt.w, v3.z, fmaf(wt.z, v2.z, fmaf(wt.y, v1.z, wt.x * v0.z)));
-            o[3] = fmaf(wt.w, v3.w, fmaf(wt.z, v2.w, fmaf(wt.y, v1.w, wt.x * v0.w)));
-        }
-        float pp[3], pd[3], xb[3], db[3];
-        sample_pose_point(a, w.active_idx[slot], pp[0], pp[1], pp[2], nullptr, pd);
-        warp_with_mats(Aw, Bw, pp, pd, xb, db);
-        if (!a.scene.tpose_viewdir) {                       // cfg.tpose_viewdir False: world view dir
-            int64_t ray = w.active_idx[slot] / a.S;
-            const float* vd = a.wpts ? a.wdirs : a.ray_d;
-            db[0] = vd[ray * 3]; db[1] = vd[ray * 3 + 1]; db[2] = vd[ray * 3 + 2];
-        }
+        float xb[3], db[3];
+        warp_pair(a, w, vm, p, i, xb, db);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             w.l_x[p][c * w.lcap + i] = xb[c];                // init_bigpose
@@ -189,6 +196,7 @@ __global__ __launch_bounds__(WARP_BLOCK) void k_warp_pairs(RenderArgs a, Workspa
         }
     }
 }
+
 
 // Residual deformer of the pair lists on the fp32 matrix cores (same D^T = W . X^T orientation as
 // k_part_mlp: 16 pairs = the N columns of v_mfma_f32_16x16x4_f32, accumulators of one layer are the B

@@ -30,7 +30,8 @@ struct RenderArgs {
 
 // per-frame KNN acceleration index built by k_part_prepare
 struct KnnIndex {
-    float4* sverts;      // P*mpad : Morton-sorted vertices, two per float4 pair: {x0,x1,y0,y1} {z0,z1,row0,row1}
+    float4* sverts;      // P*mpad : Morton-sorted vertices, two per float4 pair: {x0,x1,y0,y1} {z0,z1,|v0|^2,|v1|^2}
+    uint16_t* srow;      // P*mpad : row of every sorted vertex slot inside its part (0 for the padding sentinels)
     float4* sub;         // P*cpad*8 : AABB {min, max} of the four 16-vertex sub-clusters of every cluster
     float4* cl;          // P*cpad*3 : per 64-vertex cluster {AABB min, AABB max, first vertex (an upper
                          //            bound of the nearest distance)}

@@ -29,15 +29,33 @@ def assemble_image(values, batch):
     return img
 
 
-def run_evaluate(net, batches, device='cuda', in_flight=8, renderer=None, keep_maps=False):
+def _lanes_that_fit(want, device):
+    """Frames in flight the free device memory carries: a lane holds a workspace (~5 GB for a 512x512x128 frame at the survivor
+    bound Renderer keeps) and a raw buffer (0.5 GB); leave half of what is free to the caller."""
+    try:
+        free, _ = torch.cuda.mem_get_info(torch.device(device))
+    except Exception:
+        return want
+    return max(1, min(want, int(free * 0.5 // (6 << 30))))
+
+
+def run_evaluate(net, batches, device='cuda', in_flight=None, renderer=None, keep_maps=False):
     """-> dict(psnr=[...], mse=[...]) over an iterable of collated batches (CPU or device tensors): the loop of run.py:61-90 with
     `in_flight` frames kept on the GPU — frame f is submitted (Renderer.render returns at once, Renderer.in_flight lanes) and the
     metrics of frame f - in_flight + 1 are computed while the younger frames render; the values are those of one frame at a time
     (same kernels, a workspace per lane).  in_flight = 1: strictly render -> metrics -> next batch, as the reference.
+    in_flight = None: cfg.render_in_flight when the config sets it, else 8 — capped by the free device memory.  A renderer the caller
+    passed in gets its own in_flight back on return and its lanes' workspaces / raw buffers are released.
     keep_maps: also return the host rgb_map of every frame (tests)."""
     from collections import deque
     net.eval()
     renderer = renderer or Renderer(net)
+    if in_flight is None:
+        cfg_v = getattr(net, 'cfg', {}).get('render_in_flight', None) if hasattr(getattr(net, 'cfg', None), 'get') else None
+        in_flight = int(cfg_v) if cfg_v else 8
+    prev_in_flight = renderer.in_flight
+    if torch.device(device).type == 'cuda' and torch.cuda.is_available():
+        in_flight = _lanes_that_fit(max(1, int(in_flight)), device)
     renderer.in_flight = max(1, int(in_flight))
     out = {'psnr': [], 'mse': []}
     if keep_maps:
@@ -53,15 +71,20 @@ def run_evaluate(net, batches, device='cuda', in_flight=8, renderer=None, keep_m
         if keep_maps:
             out['rgb_map'].append(rgb)
 
-    for batch in batches:
-        batch = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
-        with torch.no_grad():
-            ret = renderer.render(batch)
-        queue.append((ret, batch))
-        while len(queue) >= renderer.in_flight:
+    try:
+        for batch in batches:
+            batch = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+            with torch.no_grad():
+                ret = renderer.render(batch)
+            queue.append((ret, batch))
+            while len(queue) >= renderer.in_flight:
+                finish(*queue.popleft())
+        while queue:
             finish(*queue.popleft())
-    while queue:
-        finish(*queue.popleft())
+    finally:
+        renderer.in_flight = prev_in_flight
+        if hasattr(renderer, 'flush'):
+            renderer.flush(release=True)
     return out
 
 

@@ -154,9 +154,11 @@ class FrameSet:
                 self.streams[k].wait_stream(cur)          # (inputs made on the caller's stream; with an exchange: the previous replay's gather)
                 with torch.cuda.stream(self.streams[k]):
                     self._render(k)
+            # the caller's stream is ordered behind the K chains in every case: what replay() leaves in `local` / `full`
+            # may be read on the current stream right away, as after a graph replay or the eager loop (K event waits, no host wait)
+            for k in range(self.K):
+                cur.wait_stream(self.streams[k])
             if self.exchange:
-                for k in range(self.K):
-                    cur.wait_stream(self.streams[k])
                 self._exchange()
             return
         for k in range(self.K):

@@ -164,6 +164,11 @@ class FusedAdam(torch.optim.Optimizer):
         return loss
 
 
+# Adam variants the fused step does not implement: such an optimizer is left alone (decoupled_weight_decay: torch >= 2.7 accepts it on
+# plain torch.optim.Adam = AdamW semantics; the fused kernel applies L2 weight decay)
+_UNSUPPORTED_ADAM_FLAGS = ('amsgrad', 'maximize', 'capturable', 'differentiable', 'decoupled_weight_decay')
+
+
 def fuse(optimizer, net=None):
     """One line for a host that builds its optimiser the reference's way (lib/train/optimizer.py:13-31 -> torch.optim.Adam, one
     group per tensor):  `optimizer = invr.optim.fuse(optimizer, network)`  after make_optimizer.  Returns a FusedAdam over the SAME
@@ -173,7 +178,7 @@ def fuse(optimizer, net=None):
     if isinstance(optimizer, FusedAdam) or type(optimizer) is not torch.optim.Adam:
         return optimizer
     groups = optimizer.param_groups
-    if any(g.get('amsgrad') or g.get('maximize') or g.get('capturable') or g.get('differentiable') for g in groups):
+    if any(g.get(k) for g in groups for k in _UNSUPPORTED_ADAM_FLAGS):
         return optimizer
     if len({(tuple(g['betas']), g['eps']) for g in groups}) != 1:
         return optimizer
@@ -223,7 +228,7 @@ def _adam_matches(opt, net):
     if type(opt) is not torch.optim.Adam or getattr(opt, '_invr_inner', None) is not None:
         return False
     groups = opt.param_groups
-    if any(g.get('amsgrad') or g.get('maximize') or g.get('capturable') or g.get('differentiable') for g in groups):
+    if any(g.get(k) for g in groups for k in _UNSUPPORTED_ADAM_FLAGS):
         return False
     if len({(tuple(g['betas']), g['eps']) for g in groups}) != 1:
         return False
@@ -232,6 +237,40 @@ def _adam_matches(opt, net):
     if {id(p) for p in theirs} != mine:
         return False
     return all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in theirs)
+
+
+def _adoption_supported():
+    """The adoption rebinds step / zero_grad / state_dict / load_state_dict of the host's optimizer OBJECT and sets two marks torch's
+    lr_scheduler looks for (`step._wrapped_by_lr_sched`, `opt._opt_called`): torch-private names, checked here against the running
+    torch instead of assumed.  False -> the host's Adam is left alone (torch's own step: correct, slower) with ONE loud warning."""
+    import inspect
+    import warnings
+    ok, why = True, ''
+    try:
+        from torch.optim import lr_scheduler as _ls
+        src = inspect.getsource(_ls)
+        for mark in ('_wrapped_by_lr_sched', '_opt_called'):
+            if mark not in src:
+                ok, why = False, 'torch.optim.lr_scheduler no longer uses %r' % mark
+        sig = inspect.signature(torch.optim.Adam.zero_grad)
+        if 'set_to_none' not in sig.parameters:
+            ok, why = False, 'Optimizer.zero_grad lost set_to_none'
+        for name in ('step', 'zero_grad', 'state_dict', 'load_state_dict'):
+            if not callable(getattr(torch.optim.Adam, name, None)):
+                ok, why = False, 'torch.optim.Adam.%s missing' % name
+    except Exception as e:                                  # (no source available: a frozen build — trust the attribute checks alone)
+        if not all(callable(getattr(torch.optim.Adam, n, None)) for n in ('step', 'zero_grad', 'state_dict', 'load_state_dict')):
+            ok, why = False, repr(e)
+    if not ok and not _WARNED[0]:
+        _WARNED[0] = True
+        warnings.warn('invr.optim: torch %s changed the optimizer internals the zero-edit adoption relies on (%s): the host\'s '
+                      'torch.optim.Adam keeps its own step (dense table gradients, ~3x slower per iteration); use invr.driver.make_optimizer '
+                      'or invr.optim.fuse() for the fused step' % (torch.__version__, why), RuntimeWarning)
+    return ok
+
+
+_WARNED = [False]
+_SUPPORTED = [None]
 
 
 def adopt(opt, net, attach=None):
@@ -276,6 +315,14 @@ def adopt(opt, net, attach=None):
 
 def _step_pre_hook(opt, args, kwargs):
     if not _ADOPT_NETS or type(opt) is not torch.optim.Adam or getattr(opt, '_invr_inner', None) is not None:
+        return None
+    if (args and args[0] is not None) or kwargs.get('closure') is not None:
+        # step(closure): torch's own step runs the closure AFTER this hook — adopting now would attach the arena in front of a backward
+        # whose table gradients this step then never applies.  Leave this step to torch; a later closure-free step adopts.
+        return None
+    if _SUPPORTED[0] is None:
+        _SUPPORTED[0] = _adoption_supported()
+    if not _SUPPORTED[0]:
         return None
     for net in list(_ADOPT_NETS):
         if _adam_matches(opt, net):

@@ -99,6 +99,11 @@ class LazyHostRet(dict):
         if on_dev:
             torch.cuda.current_stream().synchronize()
 
+    def _fetch_all(self):
+        # join the frame FIRST: while it is in flight `_lazy` is still empty, and tuple(self._lazy) taken before the join would fetch nothing
+        self._settle()
+        self._fetch(tuple(self._lazy))
+
     def __contains__(self, k):
         if self._pending is not None:
             return k in self._keys
@@ -117,19 +122,19 @@ class LazyHostRet(dict):
         return dict.__len__(self) + len(self._lazy)
 
     def __iter__(self):
-        self._fetch(tuple(self._lazy))
+        self._fetch_all()
         return dict.__iter__(self)
 
     def keys(self):
-        self._fetch(tuple(self._lazy))
+        self._fetch_all()
         return dict.keys(self)
 
     def items(self):
-        self._fetch(tuple(self._lazy))
+        self._fetch_all()
         return dict.items(self)
 
     def values(self):
-        self._fetch(tuple(self._lazy))
+        self._fetch_all()
         return dict.values(self)
 
     def pop(self, k, *default):
@@ -137,10 +142,11 @@ class LazyHostRet(dict):
         return dict.pop(self, k, *default)
 
     def copy(self):
-        return dict(self)                       # (the plain all-host dict)
+        self._fetch_all()
+        return dict(dict.items(self))           # (the plain all-host dict)
 
     def __eq__(self, other):
-        self._fetch(tuple(self._lazy))
+        self._fetch_all()
         return dict.__eq__(self, other)
 
     __hash__ = None
@@ -151,7 +157,8 @@ class LazyHostRet(dict):
         return 'LazyHostRet(%s%s)' % (dict.__repr__(self), ''.join(', %s: <on the device>' % k for k in self._lazy))
 
     def __reduce__(self):                       # pickle / copy.deepcopy: the plain all-host dict
-        return (dict, (dict(self),))
+        self._fetch_all()
+        return (dict, (dict(dict.items(self)),))
 
     def pending(self):
         """keys whose host copy has not been made yet"""
@@ -172,7 +179,7 @@ class LazyHostRet(dict):
 
     def fetch(self):
         """make every entry a host tensor now (releases the device tensors)"""
-        self._fetch(tuple(self._lazy) if self._pending is None else self._keys)
+        self._fetch_all()
 
     def in_flight(self):
         """True while the frame behind this dict has not been joined (Renderer.in_flight > 1)"""

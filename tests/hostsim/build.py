@@ -37,9 +37,33 @@ REWRITES = [
      r'\1* \2 = reinterpret_cast<\1*>(hostsim::dyn_lds());'),
     (re.compile(r'asm\("v_min_f64 %0, %1, %2" : "=v"\((\w+)\) : "v"\((\w+)\), "v"\((\w+)\)\);'), r'\1 = fmin(\2, \3);'),
     (re.compile(r'asm\("v_max_f64 %0, %1, %2" : "=v"\((\w+)\) : "v"\((\w+)\), "v"\((\w+)\)\);'), r'\1 = fmax(\2, \3);'),
+    (re.compile(r'asm\("v_min_f32 %0, %1, %2" : "=v"\((\w+)\) : "v"\(([^)]+)\), "v"\(([^)]+)\)\);'), r'\1 = fminf(\2, \3);'),
     (re.compile(r'asm volatile\("" : [^;]*\);'), r''),
     (re.compile(r'__attribute__\(\(amdgpu_waves_per_eu\([^)]*\)\)\)'), r''),        # (an occupancy request of the device compiler)
 ]
+
+
+def strip_experiments(text):
+    """Drop the device-only experiment regions of a source (`#if WARP_EXP ...` with its `#else` branch kept, `#ifdef WARP_VERIFY`,
+    `#if defined(WARP_VERIFY) ...`): debug kernels of investigation builds that read hardware registers; the host build is the product's."""
+    out, stack = [], []          # stack entries: [is_experiment, keep_now]
+    for line in text.split('\n'):
+        t = line.strip()
+        if t.startswith('#if'):
+            exp = ('WARP_EXP' in t or 'WARP_VERIFY' in t) and not t.startswith('#ifndef')
+            stack.append([exp, not exp])
+            if exp:
+                continue
+        elif t.startswith('#else') and stack and stack[-1][0]:
+            stack[-1][1] = True
+            continue
+        elif t.startswith('#endif') and stack:
+            exp, _ = stack.pop()
+            if exp:
+                continue
+        if all(keep for _, keep in stack):
+            out.append(line)
+    return '\n'.join(out)
 
 
 # sanitizer builds only: a poisoned 256-byte red zone behind every array carved out of a caller's workspace (invr_abi.hip: Carver), so
@@ -65,6 +89,7 @@ def knn_perm_rewrite(text, name):
 def transform(text, name, asan=False, knn_perm=False):
     if knn_perm:
         text = knn_perm_rewrite(text, name)
+    text = strip_experiments(text)
     for rx, rep in REWRITES + (ASAN_REWRITES if asan else []):
         text = rx.sub(rep, text)
     code = re.sub(r'//[^\n]*', '', text)

@@ -43,17 +43,10 @@ def test_frame_set_equals_separate_renders_and_replays_deterministically():
             torch.cuda.synchronize()
             assert iframes.check_overflow(fs)
             bad = mismatches()
-            if bad:
-                # Seen ONCE in the ~15 full-suite runs of round 5 (never in isolation, never reproduced: 8 loops, suite-order subsets):
-                # say exactly what differed, then distinguish a transient (the same replay again is clean -> warn) from a defect
-                # (it differs again -> fail).
-                detail = [(k, key, int((fs.local[k][key] != refs[k][key]).sum()), float((fs.local[k][key] - refs[k][key]).abs().max())) for k, key in bad]
-                fs.replay()
-                torch.cuda.synchronize()
-                again = mismatches()
-                assert not again, (world, rep, detail, again)
-                import warnings
-                warnings.warn('FrameSet replay %d of world %d differed once from the separate renders and not on the next replay: %r' % (rep, world, detail))
+            # hard again (round 6): the one-off mismatch round 5 turned into a warning was real — compiler-packed fp32 math in k_warp_pairs
+            # returned wrong lanes beside the waves of other frames' kernels (profiles/r6_replay_mismatch.md); the library is built
+            # without such instructions now and tests/test_gpu_frames.py::test_frames_in_flight_stress_* pins it at the bench shape
+            assert not bad, (world, rep, [(k, key, int((fs.local[k][key] != refs[k][key]).sum()), float((fs.local[k][key] - refs[k][key]).abs().max())) for k, key in bad])
             for k in range(4):
                 assert torch.equal(fs.full[k][:, :3], refs[k]['rgb_map']) and torch.equal(fs.full[k][:, 3], refs[k]['acc_map'])
         assert refs[0]['rgb_map'].shape != refs[1]['rgb_map'].shape or not torch.equal(refs[0]['rgb_map'], refs[1]['rgb_map'])   # the poses do differ
@@ -152,3 +145,73 @@ def test_run_evaluate_in_flight_equals_one_frame_at_a_time():
             for k in ('rgb_map', 'acc_map', 'raw', 'occ'):
                 assert got[k].is_cuda and torch.equal(got[k].cpu(), ref[k]), k
         r.flush()
+
+
+def _bench_frames(K):
+    """the bench's model and its K-frame sequence (bench.build_model / bench.frame_batches: 512 x 512 x 128, the full 1.09 GB tables)"""
+    import bench
+    from invr.config import make_cfg
+    dev = torch.device('cuda', 0)
+    cfg = make_cfg(N_samples=128)
+    cfg['eval_row_sums'] = True
+    net = bench.build_model(cfg, dev)
+    _, batches = bench.frame_batches(512, 1.8, K, dev)
+    refs = []
+    for b in batches:
+        net._ws = None
+        o = net.render_rays(b, b['ray_o'][0], b['ray_d'][0], b['near'][0], b['far'][0], 128, want_raw=True)
+        refs.append({k: o[k].clone() for k in ('rgb_map', 'acc_map', 'raw')})
+    net._ws = None
+    return net, batches, refs, dev
+
+
+def _first_difference(got, ref, what):
+    ne = (got.reshape(ref.shape).view(torch.int32) != ref.view(torch.int32))
+    idx = ne.reshape(-1).nonzero()[:4, 0].tolist()
+    return '%s: %d differing elements, first at %r: got %r, expected %r' % (
+        what, int(ne.sum()), idx, [float(got.reshape(-1)[i]) for i in idx], [float(ref.reshape(-1)[i]) for i in idx])
+
+
+def test_frames_in_flight_stress_graph_at_the_bench_shape():
+    """the mode the headline is timed in — 10 frames of the 512 x 512 x 128 sequence as branches of one hipGraph, full
+    tables — replayed 250 times; every replay, every frame, rgb_map / acc_map / raw bit for bit what a separate render gives.  Fails on
+    the first differing element.  (Round 5's library failed this in ~1 of 30 replays; tools/stress_replay.py is the long form and names
+    the kernel stage that diverged.)"""
+    from invr import frames as iframes
+    net, batches, refs, dev = _bench_frames(10)
+    fns, n_rays, keep = iframes.shard_render_fns(net, batches, 128, 0, 1, want_raw=True)
+    fs = iframes.FrameSet(fns, n_rays, device=dev)
+    assert fs.graph is not None and fs.K == 10
+    for rep in range(250):
+        fs.replay()
+        torch.cuda.synchronize()
+        for k in range(10):
+            for key in ('rgb_map', 'acc_map', 'raw'):
+                if not torch.equal(fs.local[k][key], refs[k][key]):
+                    pytest.fail('replay %d, frame %d, %s' % (rep, k, _first_difference(fs.local[k][key], refs[k][key], key)))
+    assert iframes.check_overflow(fs)
+
+
+def test_frames_in_flight_stress_renderer_lanes_at_the_bench_shape():
+    """... and the drop-in call: Renderer.render with in_flight = 8 (eager launch chains on 8 streams, workspaces reused by the frames
+    that land on a lane) over 40 passes of the 10-frame sequence, device outputs, read 7 calls later as driver.run_evaluate does."""
+    from collections import deque
+    from invr.renderer import Renderer
+    net, batches, refs, dev = _bench_frames(10)
+    r = Renderer(net)
+    r.in_flight, r.eval_to_cpu = 8, False
+    q = deque()
+
+    def check(o, k, n):
+        for key in ('rgb_map', 'acc_map', 'raw'):
+            got = o[key][0]
+            if not torch.equal(got, refs[k][key]):
+                pytest.fail('frame %d of the run (frame %d of the sequence), %s' % (n, k, _first_difference(got, refs[k][key], key)))
+    for n in range(400):
+        k = n % 10
+        q.append((r.render(dict(batches[k])), k, n))
+        while len(q) >= r.in_flight:
+            check(*q.popleft())
+    while q:
+        check(*q.popleft())
+    r.flush(release=True)

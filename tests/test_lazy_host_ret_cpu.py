@@ -98,3 +98,39 @@ def test_lane_raw_buffer_is_reused_only_when_unreferenced():
     assert lane.raw_buffer(900, dev) is b
     c = lane.raw_buffer(10 * b.numel(), dev)                                       # a larger frame: a larger buffer
     assert c is not b and c.numel() >= 10 * b.numel()
+
+
+class _StubPending:
+    """a frame still in flight (what Renderer.in_flight > 1 hands to LazyHostRet): result() joins it"""
+    def __init__(self):
+        self.joined = 0
+
+    def done(self):
+        return self.joined > 0
+
+    def result(self):
+        self.joined += 1
+        raw = torch.arange(8.).reshape(1, 2, 4)
+        return {'rgb_map': torch.arange(6.).reshape(1, 2, 3), 'acc_map': torch.ones(1, 2)}, {'raw': raw, 'occ': raw[..., 3:]}
+
+
+def test_first_whole_dict_access_of_a_frame_in_flight_has_every_key():
+    """keys() / items() / values() / iteration / dict(ret) / == / copy / pickling on a dict whose frame is still in flight
+    must join the frame BEFORE deciding what to fetch — the first such access used to return rgb_map / acc_map only."""
+    full = {'rgb_map', 'acc_map', 'raw', 'occ'}
+    uses = (lambda r: dict(r), lambda r: dict(r.items()), lambda r: {k: r[k] for k in r}, lambda r: r.copy(), lambda r: dict(zip(r.keys(), r.values())),
+            lambda r: copy.deepcopy(r), lambda r: pickle.loads(pickle.dumps(r)), lambda r: dict(zip(list(r), r.values())))
+    for use in uses:
+        p = _StubPending()
+        r = LazyHostRet({}, {}, pin=False, pending=p, keys=sorted(full))
+        assert len(r) == 4 and r.in_flight() and set(r.pending()) == full and p.joined == 0
+        d = use(r)
+        assert p.joined == 1 and type(d) is dict and set(d) == full, (set(d), full)
+        assert all(not v.is_cuda for v in d.values()) and r.pending() == ()
+    p = _StubPending()
+    r = LazyHostRet({}, {}, pin=False, pending=p, keys=sorted(full))
+    r2, _, _ = make()
+    assert set(r.keys()) == full and (r == r) and set(r2.keys()) == full
+    r = LazyHostRet({}, {}, pin=False, pending=_StubPending(), keys=sorted(full))
+    r.fetch()
+    assert r.pending() == () and set(dict.keys(r)) == full

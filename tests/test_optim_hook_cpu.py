@@ -41,3 +41,48 @@ def test_hook_can_be_switched_off(monkeypatch):
     cfg['fused_optimizer_hook'] = False
     net2 = Network(cfg=cfg)
     assert optim.adopt_on_first_step(net2) is False
+
+
+def test_unsupported_variants_and_closures_are_left_to_torch(monkeypatch):
+    """decoupled_weight_decay (AdamW semantics on torch.optim.Adam, torch >= 2.7) must not be adopted or fused — the kernel
+    applies L2 decay —, and a step(closure) is never the adopting step (torch runs the closure after the hook)."""
+    import inspect
+    net = Network(cfg=make_cfg(table_log2=6)).train()
+    params = [p for p in net.parameters() if p.requires_grad]
+    monkeypatch.setattr(optim, '_adam_matches', lambda opt, n, _orig=optim._adam_matches: _orig(opt, n))
+    if 'decoupled_weight_decay' in inspect.signature(torch.optim.Adam.__init__).parameters:
+        opt = torch.optim.Adam([{'params': [p]} for p in params], 1e-3, weight_decay=1e-2, decoupled_weight_decay=True)
+        assert not optim._adam_matches(opt, net) and optim.fuse(opt, net) is opt
+    # a group dict carrying the flag is refused whatever torch's constructor accepts
+    opt = torch.optim.Adam([{'params': [p]} for p in params], 1e-3)
+    opt.param_groups[3]['decoupled_weight_decay'] = True
+    assert not optim._adam_matches(opt, net) and optim.fuse(opt, net) is opt
+    # step(closure): the hook returns before looking at the optimizer at all
+    optim.adopt_on_first_step(net)
+    called = []
+    monkeypatch.setattr(optim, 'adopt', lambda *a, **k: called.append(1))
+    monkeypatch.setattr(optim, '_adam_matches', lambda *a: True)
+    opt = torch.optim.Adam(params[-2:], 1e-3)
+    assert optim._step_pre_hook(opt, (lambda: None,), {}) is None and optim._step_pre_hook(opt, (), {'closure': lambda: None}) is None
+    assert not called
+
+
+def test_adoption_guard_reads_the_running_torch():
+    """the private marks the adoption sets exist in this torch (else the guard says no, warns once and torch's own step is kept)"""
+    assert optim._adoption_supported() is True
+    import warnings
+    from torch.optim import lr_scheduler
+    src_has = hasattr(lr_scheduler, 'LRScheduler')
+    assert src_has
+    import inspect
+    real = inspect.getsource
+    try:
+        inspect.getsource = lambda m: 'nothing of the kind'
+        optim._WARNED[0] = False
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter('always')
+            assert optim._adoption_supported() is False
+            assert any('adoption' in str(x.message) for x in w)
+    finally:
+        inspect.getsource = real
+        optim._WARNED[0] = False

@@ -3,9 +3,9 @@
 # (git-ignored, travels to the GPU box with gpurun; A/B against the product build: bash tools/gpu.sh ab <tag> instant-nvr_amd/libinvr.so variants/libinvr_<name>.so 2)
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd); N=$1; shift
-O=$R/variants/obj_$N; mkdir -p $O
+O=$R/variants/obj_$N; rm -rf $O; mkdir -p $O
 for f in $R/instant-nvr_amd/csrc/*.hip; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-function "$@" -c $f -o $O/$(basename $f .hip).o &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -Wno-unused-function "$@" -c $f -o $O/$(basename $f .hip).o &
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $O/*.o -o $R/variants/libinvr_$N.so
