@@ -319,6 +319,18 @@ def variant_lines(net, cfg, batches, dev, S, in_flight=1):
     out['mid_density'] = {'ms_per_frame': ms, 'ray_samples_per_sec': mean_rays * S / (ms * 1e-3), 'smpl_thresh': 0.1,
                           'active_fraction': float(sum(int(s[0]) for s in st)) / (mean_rays * S * len(st)),
                           'pairs_per_active_sample': float(sum(int(s[1:6].sum()) for s in st)) / max(1, sum(int(s[0]) for s in st))}
+    # (3a) the survey's own camera (3 m): the body fills a third of the frame, fewer rays hit its box, a larger share of
+    #      their samples survives the cull — the headline's 1.8 m is the camera at which the body fills the 512 x 512 frame
+    _, bs3 = frame_batches(512, 3.0, len(batches), dev)
+    ms, st = frames_ms(S, 20, bs=bs3)
+    rays3 = sum(int(b['ray_o'].shape[1]) for b in bs3) / len(bs3)
+    na3 = float(sum(int(s_[0]) for s_ in st)) / len(st)
+    out['survey_cam'] = {'cam_dist_m': 3.0, 'ms_per_frame': ms, 'rays': int(round(rays3)), 'ray_samples_per_sec': rays3 * S / (ms * 1e-3),
+                         'active_samples': int(na3), 'active_fraction': na3 / (rays3 * S), 'survivors_per_sec': na3 / (ms * 1e-3),
+                         'pairs_per_active_sample': float(sum(int(s_[1:6].sum()) for s_ in st)) / max(1.0, na3 * len(st)),
+                         'note': 'SURVEY.md 8(d)\'s camera: 3 m from the body (f = 555 px at 512^2): only the rays that hit the body AABB are rendered, as in '
+                                 'the reference (if_nerf_data_utils.py:298-308); same sequence of %d poses, %d frames per graph replay' % (len(bs3), len(bs3))}
+    del bs3
     # (3b) cfg.aggr = 'mean' (inb_part_network_multiassign.py:236-239): every listed pair needs its colour, not only each survivor's winner
     acfg = copy.deepcopy(cfg)
     acfg['aggr'] = 'mean'
@@ -408,6 +420,8 @@ def variant_lines(net, cfg, batches, dev, S, in_flight=1):
         sweep(4 * len(batches))
         api[key] = (time.perf_counter() - t0) / (4 * len(batches)) * 1e3
         api[key.replace('_ms', '_reserved_gb')] = torch.cuda.memory_reserved() / 1e9
+        api[key.replace('_ms', '_lane_gb')] = [round(((l.ws.numel() if l.ws is not None else 0) + (l.raw_buf.numel() * 4 if l.raw_buf is not None else 0)) / 1e9, 2)
+                                               for l in r._lanes]
     r.flush(release=True)
     del r
     torch.cuda.synchronize()
@@ -798,6 +812,7 @@ def main():
         binding = lambda k: counters.get(k)
         line = {
             'metric': 'ray-samples/sec', 'value': value, 'unit': 'ray-samples/s', 'n_gpus': world,
+            'survivors_per_sec': float(stats_all[0]) * args.steps / dt,      # co-headline: the samples that survive the cull and reach the networks
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step, 'repeats': repeats, 'timed_region_s': sum(region), 'higher_is_better': True,
             'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {
@@ -820,9 +835,11 @@ def main():
                                if world > 1 else 'one GPU: whole frames',
                 'exchange_only_ms_per_replay': exchange_ms, 'exchange_captured_in_graph': exchange_captured,
                 'rays_per_sec': mean_rays * args.steps / dt,
-                'note': 'value counts every ray-sample of the frames; %.1f %% of them survive the near-surface cull (the camera sits at %.1f m so '
-                        'that the body fills the frame) — survivors_per_sec is the rate of the samples that reach the networks; mid_density is '
-                        'the same sequence at smpl_thresh 0.1' % (100.0 * float(stats_all[0]) / total_samples, args.cam_dist),
+                'note': 'value counts every ray-sample of the frames; %.1f %% of them survive the near-surface cull.  The camera sits at %.1f m '
+                        '(default) because BASELINE configs[1] is a 512 x 512 frame of rays: at SURVEY 8d\'s 3 m only ~1/3 of the pixels hit the '
+                        'body AABB (the reference renders only those), so the workload would be a third of a frame — survey_cam reports that '
+                        'camera, survivors_per_sec the rate of the samples that reach the networks, mid_density the same sequence at '
+                        'smpl_thresh 0.1' % (100.0 * float(stats_all[0]) / total_samples, args.cam_dist),
             },
             # dominant roofline-bound stage: the tiny MLPs of all five parts on the fp32 matrix cores
             'roofline': {
@@ -883,6 +900,8 @@ def main():
         if world == 1 and not args.no_variants and headline:
             try:
                 del fs
+                out = None                   # (the eager profile frame holds a full-capacity workspace: 37.6 GB)
+                net._ws = None
                 torch.cuda.empty_cache()
                 line.update(variant_lines(net, cfg, batches, dev, S, K))
             except Exception as e:          # informational: never lose the bench line over a variant

@@ -601,7 +601,14 @@ __device__ __forceinline__ void level_corners_fast(float x, float cell, float rc
     c1 = min(max(b, 0), res - 1);
     t = f - (float)c0;
 }
-template <bool FASTDIV = false>
+// Round 6: the coarse dense level of a workgroup's level pair in LDS (k_part_encode_rs_xcd).  A workgroup of the XCD kernel serves ONE
+// level pair {lg, 15 - lg} of one part at a time; when level lg is dense and small — levels 0..6 of the base-2 parts (8 .. 2197 rows)
+// and level 0 of the body (4096 rows) — its row-sum table is staged once per part into ENC_LDS_ROWS floats of LDS and its 4 pair
+// look-ups per point become ds_read2_b32 instead of vector-memory requests (the kernel is bound by those, not by bytes): for the
+// base-2 parts 7 of the 16 levels leave the L1 / L2 request path.  LDSTAB = this level reads g_enc_tab; same arithmetic, same bits.
+#define ENC_LDS_ROWS 4096
+__shared__ float g_enc_tab[ENC_LDS_ROWS + 2];
+template <bool FASTDIV = false, bool LDSTAB = false>
 __device__ __forceinline__ float level_rowsum(const GridDev& g, const float* __restrict__ rs, int hstart, int l, float x, float y, float z) {
     const int res = g.res[l];
     const float cell = g.cell[l];
@@ -688,8 +695,13 @@ __device__ __forceinline__ float level_rowsum(const GridDev& g, const float* __r
         // all four pair loads are issued before the first use; the rare reload of a far second corner comes after them (inside
         // the loop its predicated load made the compiler wait for every pair load in turn: four serial round trips per level)
         float2 pr[4];
+        if (LDSTAB) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pr[j] = make_float2(g_enc_tab[bb[j] + z0], g_enc_tab[bb[j] + z0 + 1u]);       // ds_read2_b32
+        } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) __builtin_memcpy(&pr[j], tab + bb[j] + z0, sizeof(float2));   // 4-byte aligned 8-byte load (global_load_dwordx2)
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             vv[2 * j] = s0 ? pr[j].y : pr[j].x;
@@ -697,7 +709,7 @@ __device__ __forceinline__ float level_rowsum(const GridDev& g, const float* __r
         }
         if (far1) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) vv[2 * j + 1] = tab[bb[j] + (unsigned)c1z];
+            for (int j = 0; j < 4; ++j) vv[2 * j + 1] = LDSTAB ? g_enc_tab[bb[j] + (unsigned)c1z] : tab[bb[j] + (unsigned)c1z];
         }
         const float ux = 1.0f - tx, uy = 1.0f - ty, uz = 1.0f - tz;
         float acc = 0.0f;
@@ -780,6 +792,7 @@ __global__ __launch_bounds__(RS_BLOCK) void k_part_encode_rs_all(EncodeAllArgs a
 // its own 4 MB L2.  Level group lg = blockIdx.x & 7 handles levels {lg, 15 - lg} (rotated per part so that the
 // heavier hashed pairs do not always land on the same XCD) of EVERY pair tile: an XCD's L2 then only ever sees one
 // eighth of the row-sum tables (8.5 MB of 68 MB) instead of all of them.
+template <bool use_lds>
 __global__ __launch_bounds__(RS_BLOCK) void k_part_encode_rs_xcd(EncodeAllArgs a) {
     const int xcd = blockIdx.x & 7;
     const int tstride = gridDim.x >> 3;
@@ -798,6 +811,17 @@ __global__ __launch_bounds__(RS_BLOCK) void k_part_encode_rs_xcd(EncodeAllArgs a
         const float b0x = g.bounds[0], b0y = g.bounds[1], b0z = g.bounds[2];
         const float ex = g.bounds[3] - b0x, ey = g.bounds[4] - b0y, ez = g.bounds[5] - b0z;
         const int hstart = g.separate_dense ? g.start_hash : 0;
+        // level la in LDS when it is a dense level of at most ENC_LDS_ROWS rows (wave-uniform; res^3 rows, (:124-129))
+        const int res_a = g.res[la];
+        const bool lds_a = use_lds && la < g.start_hash && (int64_t)res_a * res_a * res_a <= ENC_LDS_ROWS && tile0 * RS_BLOCK < cnt;
+        if (use_lds) __syncthreads();                 // (the previous part's look-ups are done before its table is replaced)
+        if (lds_a) {
+            const float* __restrict__ src = g.separate_dense ? rs + g.dense_off[la] : rs + (int64_t)la * g.T;
+            const int rows = res_a * res_a * res_a;
+            for (int t = threadIdx.x; t < rows; t += RS_BLOCK) g_enc_tab[t] = src[t];
+            if (threadIdx.x < 2) g_enc_tab[rows + threadIdx.x] = 0.0f;          // (the pair read of the last row's z0 = res - 2 ends at rows - 1: never read, kept defined)
+        }
+        if (use_lds) __syncthreads();
         for (int64_t i = tile0 * RS_BLOCK + threadIdx.x; i < cnt; i += (int64_t)tstride * RS_BLOCK) {
             const float x = (xs[i] - b0x) / ex, y = (xs[a.stride + i] - b0y) / ey, z = (xs[2 * a.stride + i] - b0z) / ez;   // :112
             if (lg < 3) emb[(int64_t)lg * a.cap + i] = lg == 0 ? x : (lg == 1 ? y : z);
@@ -806,6 +830,10 @@ __global__ __launch_bounds__(RS_BLOCK) void k_part_encode_rs_xcd(EncodeAllArgs a
             // div_exact's range test, once per tile instead of once per quotient (the coordinates are the same for every level)
             const bool okp = fabsf(x) > 8.7e-19f && fabsf(x) < 1.0e6f && fabsf(y) > 8.7e-19f && fabsf(y) < 1.0e6f && fabsf(z) > 8.7e-19f && fabsf(z) < 1.0e6f;
             const bool fast = __ballot(!okp) == 0ull;
+            if (lds_a) {
+                if (fast && g.rcell[la] != 0.0f) emb[(int64_t)(3 + la) * a.cap + i] = level_rowsum<true, true>(g, rs, hstart, la, x, y, z);
+                else emb[(int64_t)(3 + la) * a.cap + i] = level_rowsum<false, true>(g, rs, hstart, la, x, y, z);
+            } else
             if (fast && g.rcell[la] != 0.0f) emb[(int64_t)(3 + la) * a.cap + i] = level_rowsum<true>(g, rs, hstart, la, x, y, z);
             else emb[(int64_t)(3 + la) * a.cap + i] = level_rowsum<false>(g, rs, hstart, la, x, y, z);
             if (fast && g.rcell[lb] != 0.0f) emb[(int64_t)(3 + lb) * a.cap + i] = level_rowsum<true>(g, rs, hstart, lb, x, y, z);
@@ -879,7 +907,9 @@ int launch_part_encode_all(const EncodeAllArgs& a, hipStream_t st) {
     static const int xcd_mode = getenv("INVR_ENC_XCD") ? atoi(getenv("INVR_ENC_XCD")) : 1;
     if (xcd_mode) {
         unsigned gx = (unsigned)(tiles * 8 < 256 * 8 ? (tiles > 0 ? tiles * 8 : 8) : 256 * 8);      // a multiple of 8
-        hipLaunchKernelGGL(k_part_encode_rs_xcd, dim3(gx), dim3(RS_BLOCK), 0, st, a);
+        static const bool no_lds = getenv("INVR_ENC_NOLDS") != nullptr;                 // (A/B switch)
+        if (no_lds) hipLaunchKernelGGL(k_part_encode_rs_xcd<false>, dim3(gx), dim3(RS_BLOCK), 0, st, a);
+        else hipLaunchKernelGGL(k_part_encode_rs_xcd<true>, dim3(gx), dim3(RS_BLOCK), 0, st, a);
     } else {
         hipLaunchKernelGGL(k_part_encode_rs_all, dim3(grid), dim3(RS_BLOCK), 0, st, a);
     }

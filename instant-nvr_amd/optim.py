@@ -316,7 +316,8 @@ def adopt(opt, net, attach=None):
 def _step_pre_hook(opt, args, kwargs):
     if not _ADOPT_NETS or type(opt) is not torch.optim.Adam or getattr(opt, '_invr_inner', None) is not None:
         return None
-    if (args and args[0] is not None) or kwargs.get('closure') is not None:
+    # (torch hands the hook the wrapper's own positional arguments: args[0] is the optimizer, a positional closure is args[1])
+    if (len(args) > 1 and args[1] is not None) or kwargs.get('closure') is not None:
         # step(closure): torch's own step runs the closure AFTER this hook — adopting now would attach the arena in front of a backward
         # whose table gradients this step then never applies.  Leave this step to torch; a later closure-free step adopts.
         return None

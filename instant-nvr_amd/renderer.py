@@ -339,7 +339,9 @@ class _PendingFrame:
         # grow-only: the K lanes' workspaces settle at ONE size — the largest frame seen — after a few frames.  (Following every
         # frame's own count made a lane reallocate whenever a denser frame than any before landed on it: a multi-GB hipMalloc,
         # ~1 s each on this runtime, for the first LCM(K, sequence period) frames.)
-        r._cap_hint = max(r._cap_hint or 0, int(1.5 * int(st[0])) + 65536)
+        # (1.25 x the largest frame seen; the FIRST frame of a sequence adds its own head-room in _render_in_flight.  Round 5 took 1.5 x
+        # here and 1.25 x on top of it there: 1.9 x the survivors, 6.5 GB per lane)
+        r._cap_hint = max(r._cap_hint or 0, int(1.25 * int(st[0])) + 65536)
         r.last_stats = self.out['stats']
         out = self.out
         cur = torch.cuda.current_stream(out['rgb_map'].device)
@@ -471,6 +473,12 @@ class Renderer:
             lane.pending.result()              # the frame rendered here K calls ago (long done): releases its inputs, updates the cap hint
         n_samp = ray_o.shape[0] * S
         cap = min(n_samp, max(self._cap_hint if self._cap_hint is not None else n_samp // 4, 65536)) if self.adaptive_cap else 0
+        if lane.ws is not None and lane.ws.numel() < _abi.lib().invr_workspace_bytes(ray_o.shape[0], S, cap):
+            # the survivor bound grew past this lane's workspace: give the old block back to the DRIVER before the larger one is
+            # allocated — the caching allocator would keep it (a 4 GB block nobody can reuse, per lane and regrowth: 176 GB reserved
+            # for 8 lanes in round 5).  Rare (the bound is grow-only), and the regrowth costs a multi-GB hipMalloc anyway.
+            lane.ws = None
+            torch.cuda.empty_cache()
         self._raw_numel = max(getattr(self, '_raw_numel', 0), n_samp * 4)          # grow-only, renderer-wide: every lane's raw buffer fits the largest frame seen
         ctx = self.net.prepare(batch)          # on the caller's stream: a stale row-sum table is rebuilt in front of every lane
         call = lambda c, st: self.net.render_rays(ctx, ray_o, ray_d, near, far, S, jitter=jitter, want_raw=self.want_raw, max_active=c, stream=st,
@@ -485,7 +493,7 @@ class Renderer:
             if lane.ws is not None and self._cap_hint is not None and cap > 2 * self._cap_hint:
                 lane.ws = None
             if self._cap_hint is not None:
-                self._cap_hint = int(1.25 * self._cap_hint)          # head-room over the first frame: later frames of a sequence rarely force a regrowth
+                self._cap_hint = int(1.2 * self._cap_hint)           # head-room over the first frame (1.5 x its survivors in all): later frames of a sequence rarely force a regrowth
         keys = ('rgb_map', 'acc_map') + (('raw', 'occ') if self.want_raw else ())
         if self.eval_to_cpu:
             return self._track_lazy(LazyHostRet({}, {}, self.pin_host, pending=pend, keys=keys))

@@ -7,6 +7,16 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+def _tol_report(line):
+    """INVR_TOL_REPORT=<file>: the measured headroom of a widened tolerance, one line per check (tools/gpu.sh tol: five runs -> the bounds in
+    the comments next to the asserts)"""
+    import os
+    f = os.environ.get('INVR_TOL_REPORT')
+    if f:
+        with open(f, 'a') as fh:
+            fh.write(line + '\n')
+
+
 from oracle import nvr_oracle as O          # noqa: E402  (checker only)
 from invr import scene                      # noqa: E402
 from invr.config import make_cfg            # noqa: E402
@@ -97,7 +107,8 @@ def test_full_size_spot_check_vs_oracle(full):
     from tests.conditioning import pixel_noise
     err_ref = pixel_noise(O, O.Model(sd64, cfg), b64, exact, 128, ref32=ref['rgb_map'][0],
                           rerun32=lambda ch: O.render(O.Model(sd, cfg), b, n_samples=128, chunk=ch)['rgb_map'][0])
-    assert bool((err_gpu <= 1e-4 + 8 * err_ref).all()), (float(err_gpu.max()), float(err_ref.max()))        # (8 x: heavy-tailed noise scale, tests/conditioning.py)
+    _tol_report('spot check: needed multiple of the noise scale max((err - 1e-4) / noise) = %.3f' % float(((err_gpu - 1e-4) / err_ref.clamp(min=1e-12)).max()))
+    assert bool((err_gpu <= 1e-4 + 4 * err_ref).all()), (float(err_gpu.max()), float(err_ref.max()))        # (4 x; five runs of round 6 needed none: gpurun_out/r6tol)
     assert float(err_gpu.median()) < 2e-6
     well = err_ref < 2e-6                                    # well-conditioned pixels: plain fp32 bar
     assert int(well.sum()) >= 32 and float(err_gpu[well].max()) < 1e-4

@@ -24,6 +24,16 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+def _tol_report(line):
+    """INVR_TOL_REPORT=<file>: the measured headroom of a widened tolerance, one line per check (tools/gpu.sh tol: five runs -> the bounds in
+    the comments next to the asserts)"""
+    import os
+    f = os.environ.get('INVR_TOL_REPORT')
+    if f:
+        with open(f, 'a') as fh:
+            fh.write(line + '\n')
+
+
 from oracle import nvr_oracle as O          # noqa: E402  (checker only)
 from invr import _abi, scene, stages        # noqa: E402
 
@@ -289,7 +299,7 @@ def test_render_strict_1e4_on_well_conditioned_pixels(fr):
     flag decisions identical.  Every pixel whose reference arithmetic is well conditioned (the oracle's own fp32 result
     is within 2e-6 of its fp64 result AND the fp64 result moves by less than 2e-6 under an fp32-ulp perturbation of the
     rays) must meet the plain 1e-4 bar with no allowance; the remaining pixels (far / band pairs extrapolated by the
-    encoder with 1e3..1e6 weights) may deviate from the fp64 result by 1e-4 + 8x that noise scale."""
+    encoder with 1e3..1e6 weights) may deviate from the fp64 result by 1e-4 + 4x that noise scale."""
     f, k = fr, fr['k']
     net, bc, gb, cfg = f['net'], f['bc'], f['gb'], f['cfg']
     n = gb['ray_o'].shape[1]
@@ -322,9 +332,15 @@ def test_render_strict_1e4_on_well_conditioned_pixels(fr):
           % (k, int(well.sum()), well.numel(), float(err_gpu[well].max()) if bool(well.any()) else 0.0, float(err_gpu.max()), float(noise.max())))
     assert int(well.sum()) >= WELL_FLOOR * well.numel(), int(well.sum())
     assert float(err_gpu[well].max()) <= 1e-4, ('strict', float(err_gpu[well].max()))           # strict, no allowance
-    # (8 x: the noise scale of such a pixel is heavy-tailed — one host's samples of it differed by 6 x from another's, round 5)
-    worst = (err_gpu - (1e-4 + 8 * noise)).argmax()
-    assert bool((err_gpu <= 1e-4 + 8 * noise).all()), ('ill-conditioned', float(err_gpu[worst]), float(err_ref[worst]), float(sens[worst]))
+    # (4 x again, round 6: with the noise scale taken over the extra fp32 re-runs of tests/conditioning.py no pixel of the five poses
+    # needed ANY allowance in five runs — max((err - 1e-4) / noise) = -1.5 .. -7.0, profiles/r6_tolerance_headroom.txt; round 5 had
+    # let it out to 8 x)
+    ill = ~well
+    if bool(ill.any()):
+        _tol_report('strict pose %d: ill-conditioned pixels %d, needed multiple of the noise scale max((err - 1e-4) / noise) = %.3f'
+                    % (k, int(ill.sum()), float(((err_gpu[ill] - 1e-4) / noise[ill]).max())))
+    worst = (err_gpu - (1e-4 + 4 * noise)).argmax()
+    assert bool((err_gpu <= 1e-4 + 4 * noise).all()), ('ill-conditioned', float(err_gpu[worst]), float(err_ref[worst]), float(sens[worst]))
     assert float(err_gpu.median()) < 2e-6
 
 

@@ -15,6 +15,16 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+def _tol_report(line):
+    """INVR_TOL_REPORT=<file>: the measured headroom of a widened tolerance, one line per check (tools/gpu.sh tol: five runs -> the bounds in
+    the comments next to the asserts)"""
+    import os
+    f = os.environ.get('INVR_TOL_REPORT')
+    if f:
+        with open(f, 'a') as fh:
+            fh.write(line + '\n')
+
+
 from invr import scene, params, driver                 # noqa: E402
 from invr.config import make_cfg                        # noqa: E402
 from invr.network import Network                        # noqa: E402
@@ -84,9 +94,13 @@ def test_configs4_full_size_iteration_vs_oracle_autograd(full_net):
                 checked += 1
                 continue
             scale = max(float(rg.abs().max()), 1e-6)
-            tol = 3e-2 if k.startswith('tpose_deformer') else 2e-4           # pair term: arbitrated in float64 by test_pair_term_gradient_float64_arbitration
-                                                                             # (measured 2e-3 .. > 1e-2 of the tensor's scale from run to run — the regulariser differentiates a
-                                                                             #  difference of nearly equal unit vectors; float atomics + the host's fp32 oracle decide the last digits)
+            # deformer tensors: the pair term differentiates a difference of nearly equal unit vectors (arbitrated in float64 by
+            # test_pair_term_gradient_float64_arbitration); with the fixture seeded (round 5) the error no longer moves from run to run —
+            # five runs, round 6 (gpurun_out/r6tol, tools/gpu.sh tol): worst tensor mlp.4.weight 2.11e-3 .. 2.14e-3 of its scale,
+            # mlp.2.bias 7.8e-4 .. 1.1e-3, every other one <= 3.8e-4 — so 5e-3 (2.3 x the worst seen; round 5 had let it out to 3e-2)
+            tol = 5e-3 if k.startswith('tpose_deformer') else 2e-4
+            if k.startswith('tpose_deformer'):
+                _tol_report('configs4 %s: max |grad - oracle| / scale = %.3e (scale %.3e)' % (k, float((got - rg).abs().max()) / scale, scale))
             assert float((got - rg).abs().max()) <= tol * scale + 2e-7, (k, float((got - rg).abs().max()), scale)
             checked += 1
         for i, pn in enumerate(net.tpose_human.part_networks):

@@ -63,7 +63,18 @@ def test_unsupported_variants_and_closures_are_left_to_torch(monkeypatch):
     monkeypatch.setattr(optim, 'adopt', lambda *a, **k: called.append(1))
     monkeypatch.setattr(optim, '_adam_matches', lambda *a: True)
     opt = torch.optim.Adam(params[-2:], 1e-3)
-    assert optim._step_pre_hook(opt, (lambda: None,), {}) is None and optim._step_pre_hook(opt, (), {'closure': lambda: None}) is None
+    # (torch's convention: args = the step wrapper's positional arguments, the optimizer itself first)
+    assert optim._step_pre_hook(opt, (opt, lambda: None), {}) is None and optim._step_pre_hook(opt, (opt,), {'closure': lambda: None}) is None
+    assert not called
+    # ... and through the real hook path: a closure-free step() of a matching optimizer DOES reach adopt (the guard must not eat it)
+    monkeypatch.setattr(optim, 'adopt', lambda o, n: (called.append(2), type('I', (), {'step': lambda self: None})())[1])
+    for p_ in params[-2:]:
+        p_.grad = torch.zeros_like(p_)
+    opt.step()
+    assert called == [2]
+    called.clear()
+    opt2 = torch.optim.Adam(params[-2:], 1e-3)
+    opt2.step(lambda: 0.0)
     assert not called
 
 

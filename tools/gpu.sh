@@ -15,6 +15,13 @@ case $task in
   tests)
     if [ $# -eq 0 ]; then set -- tests; fi          # ("$@": a -k expression with spaces stays one argument)
     timeout 1700 python -m pytest "$@" -q -m gpu --durations=8 > $OUT/pytest.log 2>&1; tail -25 $OUT/pytest.log ;;
+  tol)
+    # the headroom of the widened tolerances, five runs: INVR_TOL_REPORT lines of the three tests that carry them
+    export INVR_TOL_REPORT=$GRAFT_REPO_ROOT/$OUT/tol_report.txt; rm -f $INVR_TOL_REPORT
+    for i in 1 2 3 4 5; do
+      timeout 900 python -m pytest tests/test_gpu_training.py tests/test_gpu_production_kernels.py tests/test_gpu_fullsize.py -q -m gpu -k "configs4 or strict_1e4 or spot" > $OUT/pytest_$i.log 2>&1; tail -2 $OUT/pytest_$i.log
+    done
+    sort $INVR_TOL_REPORT | uniq -c | sort -k2 | head -80 ;;
   trace)
     cd /tmp
     B="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-variants --no-graph --train-iters 0"
