@@ -9,6 +9,10 @@
 #include "pipeline.h"
 
 #define CMP_BLOCK 256
+#ifndef COMP_NT
+#define COMP_NT 1
+#endif
+typedef float cmp_v4 __attribute__((ext_vector_type(4)));
 
 // Wave-wide inclusive product scan and sum on the DPP network (row_shr 1 / 2 / 4 / 8 inside the 16-lane rows, then row_bcast:15 and
 // row_bcast:31 across rows — the sequence LLVM's own wave scans use on gfx9): six full-rate VALU instructions per scan.  The
@@ -82,7 +86,14 @@ __global__ __launch_bounds__(CMP_BLOCK) void k_composite(Src src, int64_t R, int
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (live) {
             v = src.get(ray * S + s);
+#if COMP_NT
+            // raw is the frame's largest output (16 B per ray-sample, 93 % zeros) and nothing on the device reads it again: stored
+            // nontemporal so that its 0.5 GB per frame do not displace the row-sum tables and pair arrays of the frames in flight
+            // from the L2 / Infinity Cache
+            if (raw_out) __builtin_nontemporal_store((cmp_v4){v.x, v.y, v.z, v.w}, reinterpret_cast<cmp_v4*>(raw_out) + (ray * S + s));
+#else
             if (raw_out) raw_out[ray * S + s] = v;
+#endif
             if (occ_out) occ_out[ray * S + s] = v.w;
         }
         const float alpha = v.w;

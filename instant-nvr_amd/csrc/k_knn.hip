@@ -558,7 +558,14 @@ struct KnnLds { int voff[INVR_NUM_PARTS], coff[INVR_NUM_PARTS], soff[INVR_NUM_PA
 #ifndef KNN_DBG
 #define KNN_DBG 0
 #endif
+#ifndef KNN_SUB4
+#define KNN_SUB4 2
+#endif
+#ifdef KNN_WPE          // experiment: a register budget that leaves room for another kernel's wave beside the workgroup's four per SIMD
+__global__ __launch_bounds__(KNN_T) __attribute__((amdgpu_waves_per_eu(KNN_WPE, KNN_WPE))) void k_knn_pairs(RenderArgs a, Workspace w) {
+#else
 __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w) {
+#endif
     constexpr int dbg = KNN_DBG;
     // all LDS is dynamic (a static __shared__ in front would misalign the float4 region, guide G17): vertices, then cluster records
     extern __shared__ __attribute__((aligned(16))) float4 lds_raw[];
@@ -596,7 +603,17 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w) 
         for (int j = threadIdx.x; j < ncl * 8; j += KNN_T)            // (64 rows of 2 bytes = 8 float4 per cluster; mpad is a multiple of 64)
             lds[roff + L.voff[p] / 8 + j] = reinterpret_cast<const float4*>(ix.srow + (int64_t)p * ix.mpad)[j];
         for (int j = threadIdx.x; j < ncl * 3; j += KNN_T) lds[L.coff[p] + j] = ix.cl[(int64_t)p * ix.cpad * 3 + j];
+#if KNN_SUB4
+        // the four sub-cluster boxes of a cluster TRANSPOSED, {lo.x[4], lo.y[4], lo.z[4], hi.x[4], hi.y[4], hi.z[4]} (6 of the cluster's 8
+        // float4 slots): the sweep tests all four with packed-fp32 arithmetic, two boxes per instruction
+        for (int j = threadIdx.x; j < ncl * 6; j += KNN_T) {
+            const int c = j / 6, r = j - c * 6, ax = r % 3, hi = r / 3;
+            const float* g = reinterpret_cast<const float*>(ix.sub + (int64_t)p * ix.cpad * 8 + c * 8 + hi) + ax;     // box s at + s * 8 floats
+            lds[L.soff[p] + c * 8 + r] = make_float4(g[0], g[8], g[16], g[24]);
+        }
+#else
         for (int j = threadIdx.x; j < ncl * 8; j += KNN_T) lds[L.soff[p] + j] = ix.sub[(int64_t)p * ix.cpad * 8 + j];
+#endif
     }
     __syncthreads();
     KP(6)
@@ -758,6 +775,42 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w) 
                     const bool need = scan && aabb_dist2(px, py, pz, lds_ld4(cl + c * 3), lds_ld4(cl + c * 3 + 1)) <= t.worst();
                     if (__ballot(need) == 0) continue;
                     KP_CNT(10)
+#if KNN_SUB4
+                    // the box distances of the cluster's four sub-clusters at once: six record reads in flight instead of four round
+                    // trips of two, two boxes per packed instruction — each value the operations of aabb_dist2 in its order, so a
+                    // sub-cluster is scanned exactly when the one-at-a-time test (against the 4th-best of that moment) scans it
+                    float lbs[4];
+                    {
+                        const float4 LX = lds_ld4(sb + c * 8), LY = lds_ld4(sb + c * 8 + 1), LZ = lds_ld4(sb + c * 8 + 2);
+                        const float4 HX = lds_ld4(sb + c * 8 + 3), HY = lds_ld4(sb + c * 8 + 4), HZ = lds_ld4(sb + c * 8 + 5);
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const v2f lx = h ? (v2f){LX.z, LX.w} : (v2f){LX.x, LX.y}, hx = h ? (v2f){HX.z, HX.w} : (v2f){HX.x, HX.y};
+                            const v2f ly = h ? (v2f){LY.z, LY.w} : (v2f){LY.x, LY.y}, hy = h ? (v2f){HY.z, HY.w} : (v2f){HY.x, HY.y};
+                            const v2f lz = h ? (v2f){LZ.z, LZ.w} : (v2f){LZ.x, LZ.y}, hz = h ? (v2f){HZ.z, HZ.w} : (v2f){HZ.x, HZ.y};
+                            const v2f a0 = lx - px2, b0 = px2 - hx, a1 = ly - py2, b1 = py2 - hy, a2 = lz - pz2, b2 = pz2 - hz;
+                            const v2f ex = {fmaxf(fmaxf(a0.x, b0.x), 0.0f), fmaxf(fmaxf(a0.y, b0.y), 0.0f)};
+                            const v2f ey = {fmaxf(fmaxf(a1.x, b1.x), 0.0f), fmaxf(fmaxf(a1.y, b1.y), 0.0f)};
+                            const v2f ez = {fmaxf(fmaxf(a2.x, b2.x), 0.0f), fmaxf(fmaxf(a2.y, b2.y), 0.0f)};
+                            const v2f l2 = (ex * ex + ey * ey) + ez * ez;
+                            lbs[2 * h] = l2.x; lbs[2 * h + 1] = l2.y;
+                        }
+                    }
+                    // (rolled: four inlined copies of the scan are +40 % code in a kernel that sits at the instruction cache's size;
+                    // s4 is wave-uniform, the select is three scalar-conditioned moves)
+#if KNN_SUB4 == 2
+#pragma unroll
+#else
+#pragma unroll 1
+#endif
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        const float lb_s = s4 == 0 ? lbs[0] : s4 == 1 ? lbs[1] : s4 == 2 ? lbs[2] : lbs[3];
+                        const bool need_s = need && lb_s <= t.worst();
+                        if (__ballot(need_s) == 0) continue;
+                        KP_CNT(11)
+                        scan_sub16_pf(sv + c * 64 + s4 * 16, rw + c * 32 + s4 * 8, ax2, ay2, az2, px2, py2, pz2, qd, thr, t KP_SCAN_PASS);
+                    }
+#else
 #pragma unroll 1
                     for (int s4 = 0; s4 < 4; ++s4) {
                         const bool need_s = need && aabb_dist2(px, py, pz, lds_ld4(sb + c * 8 + s4 * 2), lds_ld4(sb + c * 8 + s4 * 2 + 1)) <= t.worst();
@@ -765,6 +818,7 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w) 
                         KP_CNT(11)
                         scan_sub16_pf(sv + c * 64 + s4 * 16, rw + c * 32 + s4 * 8, ax2, ay2, az2, px2, py2, pz2, qd, thr, t KP_SCAN_PASS);
                     }
+#endif
                 }
             }
             KP(3)

@@ -409,8 +409,9 @@ __device__ __forceinline__ void lane_level_slice(const float2* S, const LaneSlic
     // stage 0.495 -> 0.513 ms, gpurun_out/r5l — not kept)
     level_corners(x, L.cell, L.res, c0x, c1x, tx);
     level_corners(y, L.cell, L.res, c0y, c1y, ty);
-    const float2* row0 = S + L.off + c0x * L.res;
-    const float2* row1 = S + L.off + c1x * L.res;
+    // (24-bit multiplies: 0 <= c < res <= the slice budget's 64 — v_mul_lo_u32 is a quarter-rate instruction)
+    const float2* row0 = S + L.off + (int)__umul24((unsigned)c0x, (unsigned)L.res);
+    const float2* row1 = S + L.off + (int)__umul24((unsigned)c1x, (unsigned)L.res);
     const float2 s00 = row0[c0y], s01 = row0[c1y], s10 = row1[c0y], s11 = row1[c1y];
     const float ux = 1.0f - tx, uy = 1.0f - ty;
     const float w00 = ux * uy, w01 = ux * ty, w10 = tx * uy, w11 = tx * ty;
@@ -424,8 +425,11 @@ __device__ __forceinline__ void lane_level_slice(const float2* S, const LaneSlic
 // scaled.  {min, exp2, add, log2} = 4 instructions per value instead of the 7 of softplus_f; 64 values per pair.
 __device__ __forceinline__ float softplus_log2(float a) { return log2_raw(1.0f + exp2_raw(fminf(a, 126.0f))); }
 
-template <int DF_CB>
-__global__ __launch_bounds__(DF_BLOCK) void k_deform_pairs_slice(RenderArgs a, Workspace w, GridDev dg, DfSliceInfo si,
+#ifndef DF_WPE
+#define DF_WPE 3
+#endif
+template <int DF_CB, bool VSMALL>        // VSMALL: the UV volume qualifies for 24-bit index math (volume_is_small, common.h)
+__global__ __launch_bounds__(DF_BLOCK) __attribute__((amdgpu_waves_per_eu(DF_WPE, DF_WPE))) void k_deform_pairs_slice(RenderArgs a, Workspace w, GridDev dg, DfSliceInfo si,
                                                                  const float* __restrict__ W0, const float* __restrict__ B0,
                                                                  const float* __restrict__ W1, const float* __restrict__ B1,
                                                                  const float* __restrict__ W2, const float* __restrict__ B2) {
@@ -471,7 +475,7 @@ __global__ __launch_bounds__(DF_BLOCK) void k_deform_pairs_slice(RenderArgs a, W
         float xb[3], uv[2];
 #pragma unroll
         for (int c = 0; c < 3; ++c) xb[c] = lx[c * w.lcap + i];
-        sample_volume_dev<2>(a.scene.tuv, 0, xb[0], xb[1], xb[2], uv);
+        sample_volume_dev<2, VSMALL>(a.scene.tuv, 0, xb[0], xb[1], xb[2], uv);
         const float un = (uv[0] - gb0) / ge0, vn = (uv[1] - gb1) / ge1;
         float r3[3] = {0.f, 0.f, 0.f};
 #pragma unroll
@@ -659,12 +663,11 @@ int launch_warp_pairs(const RenderArgs& a, const Workspace& w, const GridDev& dg
     DfSliceInfo si;
     if (deform_slices_fit(dg, si, cbv)) {                 // slices built by launch_deform_slice
         const size_t lds_bytes = (size_t)DF_LDS * sizeof(float) + (size_t)si.off[8] * sizeof(float2);
-        if (cbv == 1)
-            hipLaunchKernelGGL(k_deform_pairs_slice<1>, dim3(dgx, INVR_NUM_PARTS), dim3(DF_BLOCK), lds_bytes, st, a, w, dg, si, dm.w[0], dm.b[0],
-                               dm.w[1], dm.b[1], dm.w[2], dm.b[2]);
-        else
-            hipLaunchKernelGGL(k_deform_pairs_slice<2>, dim3(dgx, INVR_NUM_PARTS), dim3(DF_BLOCK), lds_bytes, st, a, w, dg, si, dm.w[0], dm.b[0],
-                               dm.w[1], dm.b[1], dm.w[2], dm.b[2]);
+        const bool vs = volume_is_small(a.scene.tuv);
+        auto kern = cbv == 1 ? (vs ? k_deform_pairs_slice<1, true> : k_deform_pairs_slice<1, false>)
+                             : (vs ? k_deform_pairs_slice<2, true> : k_deform_pairs_slice<2, false>);
+        hipLaunchKernelGGL(kern, dim3(dgx, INVR_NUM_PARTS), dim3(DF_BLOCK), lds_bytes, st, a, w, dg, si, dm.w[0], dm.b[0],
+                           dm.w[1], dm.b[1], dm.w[2], dm.b[2]);
         INVR_LAUNCH_CHECK();
         return 0;
     }

@@ -4,7 +4,8 @@
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd); N=$1; shift
 O=$R/variants/obj_$N; rm -rf $O; mkdir -p $O
-for f in $R/instant-nvr_amd/csrc/*.hip; do
+SRC=${SRC:-$R/instant-nvr_amd/csrc}          # (SRC=<dir>: another source tree, e.g. `git archive HEAD instant-nvr_amd/csrc include | tar -x -C /tmp/base` for the committed baseline)
+for f in $SRC/*.hip; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -Wno-unused-function "$@" -c $f -o $O/$(basename $f .hip).o &
 done
 wait

@@ -7,6 +7,7 @@
 #   api [tag]                   Renderer.render with frames in flight across calls: ms per frame, allocator footprint (tools/exp_inflight_diag.py)
 #   world8 [tag]                8 gloo ranks on this one GPU through bench.py --gpus 8 (eval) and --train --gpus 8
 #   ab [tag] libA libB [n] [bench args]    alternating A/B of two library builds on this box (tools/build_variant.sh); "--train" for the training line
+#   abn [tag] n lib1 lib2 ...             the same for any number of builds
 #   final [tag]                 tests + prof + a default bench line: the closing run of a round
 cd $GRAFT_REPO_ROOT && export TMPDIR=/tmp
 task=$1; T=${2:-$1}; shift 2 2>/dev/null
@@ -61,6 +62,14 @@ print('$L %.3f ms/iter  k_adam %.3f ms  %.0f GB/s' % (d['ms_per_step'], r['kerne
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$L %.4f ms' % d['ms_per_step'], {k: round(v,3) for k,v in d['stage_ms_per_step'].items() if v})"
       fi
+    done; done 2>&1 | tee $OUT/ab.log ;;
+  abn)
+    # abn [tag] n lib1 lib2 ...: alternating runs of any number of library builds on this box
+    N=$1; shift
+    for i in $(seq $N); do for L in "$@"; do
+      INVR_LIB_PATH=$GRAFT_REPO_ROOT/$L timeout 300 python bench.py --steps 20 --warmup 5 --train-iters 0 --no-cpu-baseline --no-variants 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$L %.4f ms' % d['ms_per_step'], d.get('replay_bit_exact'), {k: round(v,3) for k,v in d['stage_ms_per_step'].items() if v})"
     done; done 2>&1 | tee $OUT/ab.log ;;
   final)
     timeout 1700 python -m pytest tests -q -m gpu --durations=8 > $OUT/pytest.log 2>&1; tail -12 $OUT/pytest.log
