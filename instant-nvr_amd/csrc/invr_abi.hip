@@ -311,7 +311,7 @@ static PartMlpDev make_part_mlp(const InvrModel* m, int p, const int64_t* latent
 }
 
 // library-owned streams for the five per-part chains of the training forward / backward (one set per device and host thread)
-struct PartStreams { hipStream_t s[INVR_NUM_PARTS] = {}; hipEvent_t fork = nullptr, done[INVR_NUM_PARTS] = {}; };
+struct PartStreams { hipStream_t s[INVR_NUM_PARTS] = {}; hipEvent_t fork = nullptr, dfork = nullptr, djoin = nullptr, done[INVR_NUM_PARTS] = {}, done2[INVR_NUM_PARTS] = {}; };
 static PartStreams* part_streams() {
     static thread_local std::vector<PartStreams> of_device;
     int dev_id = 0;
@@ -319,10 +319,12 @@ static PartStreams* part_streams() {
     if ((size_t)dev_id >= of_device.size()) of_device.resize((size_t)dev_id + 1);
     PartStreams& ps = of_device[dev_id];
     if (!ps.fork) {
-        if (hipEventCreateWithFlags(&ps.fork, hipEventDisableTiming) != hipSuccess) { invr_set_error("invr: event creation failed"); return nullptr; }
+        if (hipEventCreateWithFlags(&ps.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ps.dfork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ps.djoin, hipEventDisableTiming) != hipSuccess) { invr_set_error("invr: event creation failed"); return nullptr; }
         for (int p = 0; p < INVR_NUM_PARTS; ++p)
             if (hipStreamCreateWithFlags(&ps.s[p], hipStreamNonBlocking) != hipSuccess ||
-                hipEventCreateWithFlags(&ps.done[p], hipEventDisableTiming) != hipSuccess) { invr_set_error("invr: stream creation failed"); return nullptr; }
+                hipEventCreateWithFlags(&ps.done[p], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&ps.done2[p], hipEventDisableTiming) != hipSuccess) { invr_set_error("invr: stream creation failed"); return nullptr; }
     }
     return &ps;
 }
@@ -873,9 +875,9 @@ extern "C" int invr_train_bwd(const InvrScene* scene, const InvrModel* model, in
         const int32_t* count = w.counters + CNT_PAIRS + p;
         MlpBwdOut o{t.g_emb[p], t.gz[p], t.a[p], lcap, G.rgb_latent, 1};
         if (launch_part_mlp_bwd(pm, w.emb[p], w.l_d[p], lcap, lcap, count, reinterpret_cast<const float*>(t.g_raws), w.l_slot[p], p, o, sp)) return 1;
-        float* dW[5] = {G.occ_w[0], G.occ_w[1], G.rgb_w[0], n_rgb == 3 ? G.rgb_w[1] : nullptr, G.rgb_w[n_rgb - 1]};
-        float* db[5] = {G.occ_b[0], G.occ_b[1], G.rgb_b[0], n_rgb == 3 ? G.rgb_b[1] : nullptr, G.rgb_b[n_rgb - 1]};
-        if (launch_part_wgrad(t.gz[p], t.a[p], lcap, n_rgb, dW, db, count, sp)) return 1;
+        // encoder^T first: the deformer stage below waits for every part's g_x, while the weight gradients are only read by the
+        // optimizer — they follow on the part's stream and the caller's stream joins them at the END of this call, behind the
+        // deformer stage (round 6; they sat between MLP^T and encoder^T: 100 - 350 us on the backward's critical chain)
         GridDev g = make_grid_dev(&model->part[p].grid);
         if (launch_part_encode_bwd_lists(g, w.l_x[p], t.g_emb[p], t.g_x[p], lcap, lcap, count, G.row_grad, sp)) return 1;
         if (ps) {
@@ -883,8 +885,26 @@ extern "C" int invr_train_bwd(const InvrScene* scene, const InvrModel* model, in
             INVR_HIP(hipStreamWaitEvent(st, ps->done[p], 0));
         }
     }
+    // (a second pass: the library's streams share the device's few hardware queues, and a queue runs what it is handed in order —
+    // a part's weight gradients submitted before the next part's MLP^T / encoder^T would sit in front of them)
+    for (int p = 0; p < INVR_NUM_PARTS; ++p) {
+        if (!(stages & INVR_BWD_PART(p))) continue;
+        hipStream_t sp = ps ? ps->s[p] : st;
+        const InvrPartGrads& G = grads->part[p];
+        const int n_rgb = model->part[p].rgb.n_linear;
+        float* dW[5] = {G.occ_w[0], G.occ_w[1], G.rgb_w[0], n_rgb == 3 ? G.rgb_w[1] : nullptr, G.rgb_w[n_rgb - 1]};
+        float* db[5] = {G.occ_b[0], G.occ_b[1], G.rgb_b[0], n_rgb == 3 ? G.rgb_b[1] : nullptr, G.rgb_b[n_rgb - 1]};
+        if (launch_part_wgrad(t.gz[p], t.a[p], lcap, n_rgb, dW, db, w.counters + CNT_PAIRS + p, sp)) return 1;
+        if (ps) INVR_HIP(hipEventRecord(ps->done2[p], sp));
+    }
+    auto join_wgrads = [&]() -> int {
+        if (!ps) return 0;
+        for (int p = 0; p < INVR_NUM_PARTS; ++p)
+            if (stages & INVR_BWD_PART(p)) INVR_HIP(hipStreamWaitEvent(st, ps->done2[p], 0));
+        return 0;
+    };
     // deformer^T over the listed pairs and the pair-regulariser neighbours (needs the g_x of every part)
-    if (!(stages & INVR_BWD_DEFORMER)) return 0;
+    if (!(stages & INVR_BWD_DEFORMER)) return join_wgrads();
     if (check_grid(&model->deform_grid, "deformer grid") || check_mlp_deform(&model->deform_mlp)) return 1;
     INVR_CHECK(grads->deform_hash && (!model->deform_grid.separate_dense || grads->deform_dense) && grads->deform_w[0] && grads->deform_w[1] &&
                grads->deform_w[2] && grads->deform_b[0] && grads->deform_b[1] && grads->deform_b[2], "invr_train_bwd: null deformer gradient pointer");
@@ -894,7 +914,13 @@ extern "C" int invr_train_bwd(const InvrScene* scene, const InvrModel* model, in
     memset(&a, 0, sizeof(a));
     a.scene = make_scene_dev(scene);
     a.R = n_rays; a.S = n_samples; a.N = N;
-    return launch_deform_bwd(a, w, t, make_grid_dev(&model->deform_grid), make_mlp_dev(&model->deform_mlp), g_offset_sum, g_pair_sum, DG, st);
+    // (the deformer's own weight gradients on a library stream beside its grid^T: the stream after the LAST part's, which is free
+    // here or busy with the smallest part's weight gradients)
+    PartStreams* ds = ps ? ps : part_streams();
+    if (!ds) return 1;
+    if (launch_deform_bwd(a, w, t, make_grid_dev(&model->deform_grid), make_mlp_dev(&model->deform_mlp), g_offset_sum, g_pair_sum, DG, st,
+                          ds->s[INVR_NUM_PARTS - 1], ds->dfork, ds->djoin)) return 1;
+    return join_wgrads();
 }
 
 __global__ void k_expand_row_grad(const float* __restrict__ rg, int64_t rows, int F, float* __restrict__ out) {

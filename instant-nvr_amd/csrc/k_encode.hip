@@ -347,6 +347,9 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_part_encode_rows_all(EncodeAllArg
 //   d out_l / d t_a             = sum_k (+-)(w_b w_c) S_k,  S_k = sum_f table[row_k][f]   (needs the rows again)
 // Small dense levels (<= BWD_SMALL_ROWS rows) are accumulated per workgroup in LDS: a training patch
 // sends ~1e5 pairs through 8..1000-row coarse levels and would serialise on global atomics.
+#ifndef ENCB_EXP
+#define ENCB_EXP 0
+#endif
 #define BWD_SMALL_ROWS 1100
 #define BWD_SMALL_FLOATS 6144
 #define BWD_CACHE 4096
@@ -446,9 +449,16 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_part_encode_bwd(GridDev g, EncBwd
                 const unsigned old = atomicCAS(&ckey[slot], 0xFFFFFFFFu, key);
                 if (old == 0xFFFFFFFFu || old == key) { atomicAdd(&cval[slot], vsum); return; }
             }
+#if ENCB_EXP == 1          // experiment (WRONG results): no global atomics — the kernel's floor without them
+            return;
+#elif ENCB_EXP == 2        // experiment (results only right if one XCD owns the row): the add performed in the issuing XCD's L2
+            __hip_atomic_fetch_add(gtb + (size_t)r * gstride, vsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            return;
+#endif
             unsafeAtomicAdd(gtb + (size_t)r * gstride, vsum);               // column 0 = row scalar
         };
-        for (int j = 0; j < m; ++j) {
+        // the rows and corner weights of point j (quad-shared index math), and its eight row quarters
+        auto prep = [&](int j, unsigned* row, float* tq) {
             const float x = rdlane(xi, j), y = rdlane(yi, j), z = rdlane(zi, j);
             int c0, c1;
             float t;
@@ -457,7 +467,7 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_part_encode_bwd(GridDev g, EncBwd
             const int c0x = quad_bcast_i<0>(c0), c1x = quad_bcast_i<0>(c1);
             const int c0y = quad_bcast_i<1>(c0), c1y = quad_bcast_i<1>(c1);
             const int c0z = quad_bcast_i<2>(c0), c1z = quad_bcast_i<2>(c1);
-            const float tx = quad_bcast_f<0>(t), ty = quad_bcast_f<1>(t), tz = quad_bcast_f<2>(t);
+            tq[0] = quad_bcast_f<0>(t); tq[1] = quad_bcast_f<1>(t); tq[2] = quad_bcast_f<2>(t);
             const int cx = (q & 2) ? c1x : c0x, cy = (q & 1) ? c1y : c0y;
             unsigned r0, r1;
             if (L.hashed) {
@@ -469,16 +479,35 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_part_encode_bwd(GridDev g, EncBwd
                 r0 = rb + (unsigned)c0z;
                 r1 = rb + (unsigned)c1z;
             }
-            unsigned row[8];
             row[0] = (unsigned)quad_bcast_i<0>((int)r0); row[1] = (unsigned)quad_bcast_i<0>((int)r1);
             row[2] = (unsigned)quad_bcast_i<1>((int)r0); row[3] = (unsigned)quad_bcast_i<1>((int)r1);
             row[4] = (unsigned)quad_bcast_i<2>((int)r0); row[5] = (unsigned)quad_bcast_i<2>((int)r1);
             row[6] = (unsigned)quad_bcast_i<3>((int)r0); row[7] = (unsigned)quad_bcast_i<3>((int)r1);
+        };
+        // Software pipeline (round 6): the 8 row gathers of point j + 1 are in flight while point j is reduced and scattered.  The
+        // wave walks its points one after the other, and each point used to be a full dependent round trip — index math, 8 KB of
+        // random 64-byte rows out of a 1 GB table, reductions, atomics: ~8 us per point at two waves per SIMD, which is what the
+        // kernel cost for 1e4 pairs as for 5e4 (profiles/r6_training_step.md).
+        unsigned rowc[8];
+        float tc[3];
+        float4 v[8];
+        prep(0, rowc, tc);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = L.tab[(size_t)rowc[k] * 4];
+        for (int j = 0; j < m; ++j) {
+            unsigned rown[8];
+            float tn[3];
+            float4 vn[8];
+            const bool more = j + 1 < m;                  // (wave-uniform)
+            if (more) {
+                prep(j + 1, rown, tn);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) vn[k] = L.tab[(size_t)rown[k] * 4];
+            }
+            const unsigned* row = rowc;
+            const float tx = tc[0], ty = tc[1], tz = tc[2];
             const float ux = 1.0f - tx, uy = 1.0f - ty, uz = 1.0f - tz;
             const float gl = sgo[wv][j][3 + level];
-            float4 v[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = L.tab[(size_t)row[k] * 4];
             float gtx = 0.f, gty = 0.f, gtz = 0.f;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -502,6 +531,11 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_part_encode_bwd(GridDev g, EncBwd
 #pragma unroll
             for (int d = 4; d < 64; d <<= 1) { ax += __shfl_xor(ax, d); ay += __shfl_xor(ay, d); az += __shfl_xor(az, d); }
             if (lane == 0) { sgx[wv][j][0] = ax; sgx[wv][j][1] = ay; sgx[wv][j][2] = az; }
+            if (more) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { rowc[k] = rown[k]; v[k] = vn[k]; }
+                tc[0] = tn[0]; tc[1] = tn[1]; tc[2] = tn[2];
+            }
         }
         if (q == 0) {
 #pragma unroll

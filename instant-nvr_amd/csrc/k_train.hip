@@ -252,10 +252,19 @@ __global__ __launch_bounds__(256) void k_merge_bwd(Workspace w, const float4* __
 // ---- weight gradients dW = gz^T a over the rows of a device-counted list, on the matrix cores -------------------------
 // gz (rows, ldg) holds the gradient w.r.t. a layer's outputs (O used columns), a (rows, lda) the layer's inputs (I used
 // columns).  A wave accumulates a 64 x 80 tile of dW (4 x 5 MFMA tiles; column I is a virtual all-ones input = the bias
-// gradient) over its slab of rows and adds it to the gradient tensors with atomics.  Input column j of
-// `a` may be a k-slot of the part MLPs' rgb layer 1 (slot_order: rgb1_col maps it to the weight column, < 0 = padding).
+// gradient) over its slabs of rows.  Input column j of `a` may be a k-slot of the part MLPs' rgb layer 1 (slot_order: rgb1_col
+// maps it to the weight column, < 0 = padding).
+// Round 6: a PERSISTENT grid of WG_GRID workgroups of WG_WAVES waves per job.  A wave keeps its tile in registers over all its
+// slabs, the workgroup's waves add their tiles into one LDS image, and that image goes to the gradient tensors with ONE atomic per
+// element and workgroup.  (One wave per 256-row slab used to add its own tile: 200 slabs x 5 jobs x 5120 elements for the body's
+// 51 k pairs of a training patch — a million same-address float atomics, 200 deep per address: 140 - 350 us per part on the
+// backward's critical chain for 20 us of matrix work.)
 typedef float wg4 __attribute__((ext_vector_type(4)));
 #define WG_SLAB 256
+#define WG_WAVES 4
+#define WG_GRID 48
+#define WG_TILE_O 64
+#define WG_TILE_I 80
 struct WgradJob {
     const float* gz; const float* a;
     float* dW; float* db;
@@ -264,72 +273,80 @@ struct WgradJob {
 };
 struct WgradJobs { WgradJob j[5]; int n; };
 
-__global__ __launch_bounds__(64) void k_wgrad(WgradJobs jobs, const int32_t* __restrict__ count, int64_t n_host) {
+__global__ __launch_bounds__(64 * WG_WAVES) void k_wgrad(WgradJobs jobs, const int32_t* __restrict__ count, int64_t n_host) {
+    __shared__ float red[WG_TILE_O * WG_TILE_I];               // the workgroup's dW tile (20 KB)
     const WgradJob J = jobs.j[blockIdx.y];
     const int64_t n = count ? (int64_t)*count : n_host;
-    const int64_t r0 = (int64_t)blockIdx.x * WG_SLAB;
-    if (r0 >= n) return;
-    const int64_t r1 = min(r0 + WG_SLAB, n);
-    const int lane = threadIdx.x, g = lane >> 4, i = lane & 15;
+    if ((int64_t)blockIdx.x * WG_WAVES * WG_SLAB >= n) return;  // (block-uniform: no slab for any of this workgroup's waves)
+    for (int e = threadIdx.x; e < WG_TILE_O * WG_TILE_I; e += 64 * WG_WAVES) red[e] = 0.0f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, i = lane & 15;
     const int MT = (J.O + 15) >> 4, NT = (J.I + 1 + 15) >> 4;       // +1: the ones column
     wg4 acc[4][5];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 5; ++nt) acc[mt][nt] = (wg4){0.f, 0.f, 0.f, 0.f};
-    // operands of one k-step (4 rows): loaded one step ahead of the MFMAs that consume them
-    auto load = [&](int64_t r, float* av, float* bv) {
-        const int64_t row = r + g;
-        const bool live = row < r1;
+    for (int64_t slab = (int64_t)blockIdx.x * WG_WAVES + wv; slab * WG_SLAB < n; slab += (int64_t)gridDim.x * WG_WAVES) {
+        const int64_t r0 = slab * WG_SLAB, r1 = min(r0 + WG_SLAB, n);
+        // operands of one k-step (4 rows): loaded one step ahead of the MFMAs that consume them
+        auto load = [&](int64_t r, float* av, float* bv) {
+            const int64_t row = r + g;
+            const bool live = row < r1;
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const int o = 16 * mt + i;
-            av[mt] = (live && mt < MT && o < J.O) ? J.gz[row * J.ldg + o] : 0.0f;
-        }
-#pragma unroll
-        for (int nt = 0; nt < 5; ++nt) {
-            const int c = 16 * nt + i;
-            bv[nt] = (live && nt < NT) ? (c < J.I ? J.a[row * J.lda + c] : (c == J.I ? 1.0f : 0.0f)) : 0.0f;
-        }
-    };
-    float av[4], bv[5], an[4], bn[5];
-    load(r0, av, bv);
-    for (int64_t r = r0; r < r1; r += 4) {
-        load(r + 4, an, bn);                               // rows >= r1 load as zeros
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            if (mt >= MT) continue;
+            for (int mt = 0; mt < 4; ++mt) {
+                const int o = 16 * mt + i;
+                av[mt] = (live && mt < MT && o < J.O) ? J.gz[row * J.ldg + o] : 0.0f;
+            }
 #pragma unroll
             for (int nt = 0; nt < 5; ++nt) {
-                if (nt >= NT) continue;
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+                const int c = 16 * nt + i;
+                bv[nt] = (live && nt < NT) ? (c < J.I ? J.a[row * J.lda + c] : (c == J.I ? 1.0f : 0.0f)) : 0.0f;
             }
+        };
+        float av[4], bv[5], an[4], bn[5];
+        load(r0, av, bv);
+        for (int64_t r = r0; r < r1; r += 4) {
+            load(r + 4, an, bn);                               // rows >= r1 load as zeros
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                if (mt >= MT) continue;
+#pragma unroll
+                for (int nt = 0; nt < 5; ++nt) {
+                    if (nt >= NT) continue;
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) av[mt] = an[mt];
+#pragma unroll
+            for (int nt = 0; nt < 5; ++nt) bv[nt] = bn[nt];
         }
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) av[mt] = an[mt];
-#pragma unroll
-        for (int nt = 0; nt < 5; ++nt) bv[nt] = bn[nt];
     }
-    // D[row = 4g + r][col = i] of tile (mt, nt) = dW[16 mt + 4g + r][16 nt + i]
+    // D[row = 4g + r][col = i] of tile (mt, nt) = dW[16 mt + 4g + r][16 nt + i]: the waves' tiles summed in LDS
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         if (mt >= MT) continue;
 #pragma unroll
         for (int nt = 0; nt < 5; ++nt) {
             if (nt >= NT) continue;
-            const int c = 16 * nt + i;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int o = 16 * mt + 4 * g + r;
                 const float v = acc[mt][nt][r];
-                if (o >= J.O || v == 0.0f) continue;
-                if (c < J.I) {
-                    const int wc = J.slot_order ? rgb1_col(c >> 2, c & 3) : c;
-                    if (wc >= 0) unsafeAtomicAdd(J.dW + (int64_t)o * J.ldw + wc, v);
-                } else if (c == J.I) {
-                    unsafeAtomicAdd(J.db + o, v);
-                }
+                if (v != 0.0f) atomicAdd(&red[(16 * mt + 4 * g + r) * WG_TILE_I + 16 * nt + i], v);
             }
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < WG_TILE_O * WG_TILE_I; e += 64 * WG_WAVES) {
+        const int o = e / WG_TILE_I, c = e - o * WG_TILE_I;
+        const float v = red[e];
+        if (o >= J.O || v == 0.0f) continue;
+        if (c < J.I) {
+            const int wc = J.slot_order ? rgb1_col(c >> 2, c & 3) : c;
+            if (wc >= 0) unsafeAtomicAdd(J.dW + (int64_t)o * J.ldw + wc, v);
+        } else if (c == J.I) {
+            unsafeAtomicAdd(J.db + o, v);
         }
     }
 }
@@ -355,7 +372,8 @@ int launch_part_wgrad(const float* gz, const float* a, int64_t lcap, int n_rgb, 
 
 int launch_wgrad(const WgradJobs& jobs, const int32_t* count, int64_t n_max, hipStream_t st) {
     if (n_max <= 0 || jobs.n == 0) return 0;
-    hipLaunchKernelGGL(k_wgrad, dim3((unsigned)cdiv(n_max, WG_SLAB), jobs.n), dim3(64), 0, st, jobs, count, n_max);
+    const int64_t groups = cdiv(n_max, (int64_t)WG_SLAB * WG_WAVES);
+    hipLaunchKernelGGL(k_wgrad, dim3((unsigned)(groups < WG_GRID ? groups : WG_GRID), jobs.n), dim3(64 * WG_WAVES), 0, st, jobs, count, n_max);
     INVR_LAUNCH_CHECK();
     return 0;
 }
@@ -483,7 +501,8 @@ __global__ __launch_bounds__(128) void k_deform_bwd(SceneDev s, GridDev dg, MlpD
 }
 
 int launch_deform_bwd(const RenderArgs& a, const Workspace& w, const TrainWs& t, const GridDev& dg, const MlpDev& dm,
-                      const float* g_off_sum, const float* g_pair_sum, const DeformGrads& G, hipStream_t st) {
+                      const float* g_off_sum, const float* g_pair_sum, const DeformGrads& G, hipStream_t st, hipStream_t side,
+                      hipEvent_t ev_fork, hipEvent_t ev_join) {
     int64_t tiles = cdiv(w.lcap, 256);
     unsigned gx = (unsigned)(tiles < 512 ? (tiles > 0 ? tiles : 1) : 512);
     hipLaunchKernelGGL(k_deform_list_pairs, dim3(gx, INVR_NUM_PARTS), dim3(256), 0, st, w, t, g_off_sum);
@@ -499,11 +518,20 @@ int launch_deform_bwd(const RenderArgs& a, const Workspace& w, const TrainWs& t,
     jobs.j[0] = WgradJob{t.d_gz1, t.d_a0, G.w[0], G.b[0], 0, 32, 20, 32, 19, 19};
     jobs.j[1] = WgradJob{t.d_gz2, t.d_a1, G.w[1], G.b[1], 0, 32, 32, 32, 32, 32};
     jobs.j[2] = WgradJob{t.d_gz3, t.d_a2, G.w[2], G.b[2], 0, 4, 32, 3, 32, 32};
-    if (launch_wgrad(jobs, w.counters + CNT_DTOT, t.DM, st)) return 1;
+    // the weight gradients and the grid^T below both read what k_deform_bwd wrote and nothing of each other: with a side stream
+    // (round 6) they run side by side — two latency-bound launches of ~100 us each
+    const bool fork = side && ev_fork && ev_join;
+    if (fork) {
+        INVR_HIP(hipEventRecord(ev_fork, st));
+        INVR_HIP(hipStreamWaitEvent(side, ev_fork, 0));
+    }
+    if (launch_wgrad(jobs, w.counters + CNT_DTOT, t.DM, fork ? side : st)) return 1;
+    if (fork) INVR_HIP(hipEventRecord(ev_join, side));
     // grid^T: table gradients of the deformer's 8 x 2 grid (the (u,v,t) input carries no gradient)
-    const int rc = launch_deform_slice_bwd(dg, a.scene.frame_dim, t.d_uvt, t.d_gfeat, t.DM, w.counters + CNT_DTOT, G.dense, G.hash, st);
-    if (rc >= 0) return rc;
-    return launch_grid_encode_bwd_generic(dg, t.d_uvt, t.d_gfeat, t.DM, G.dense, G.hash, nullptr, st, w.counters + CNT_DTOT);
+    int rc = launch_deform_slice_bwd(dg, a.scene.frame_dim, t.d_uvt, t.d_gfeat, t.DM, w.counters + CNT_DTOT, G.dense, G.hash, st);
+    if (rc < 0) rc = launch_grid_encode_bwd_generic(dg, t.d_uvt, t.d_gfeat, t.DM, G.dense, G.hash, nullptr, st, w.counters + CNT_DTOT);
+    if (fork) INVR_HIP(hipStreamWaitEvent(st, ev_join, 0));
+    return rc;
 }
 
 // ---- the training objective of NetworkWrapper.forward (inb_trainer.py:40-98, 176-214 with the plain MSE image term) in ONE launch --------

@@ -30,7 +30,7 @@ int launch_train_terms(const RenderArgs& a, const Workspace& w, const TrainWs& t
 int launch_distortion_bwd(const float* weights, const float* z, const float* g_dist, int64_t R, int S, float* g_w, hipStream_t st);
 int launch_merge_bwd(const Workspace& w, int aggr, const float4* g_rawfull, float4* g_raws, hipStream_t st);
 int launch_deform_bwd(const RenderArgs& a, const Workspace& w, const TrainWs& t, const GridDev& dg, const MlpDev& dm,
-                      const float* g_off_sum, const float* g_pair_sum, const DeformGrads& G, hipStream_t st);
+                      const float* g_off_sum, const float* g_pair_sum, const DeformGrads& G, hipStream_t st, hipStream_t side = nullptr, hipEvent_t ev_fork = nullptr, hipEvent_t ev_join = nullptr);
 struct WgradJob;
 struct WgradJobs;
 int launch_part_wgrad(const float* gz, const float* a, int64_t lcap, int n_rgb, float* const* dW, float* const* db,
