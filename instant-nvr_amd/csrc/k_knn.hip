@@ -554,7 +554,8 @@ struct KnnLds { int voff[INVR_NUM_PARTS], coff[INVR_NUM_PARTS], soff[INVR_NUM_PA
 // come near — 29 % of the kernel's wave time on a whole frame and 51 % on a 1/8 shard, tools/knn_phase_prof.py.  Now a wave
 // never waits for another one.)
 // KNN_DBG: ablation switch of the profiling builds only (tools/knn_phase_prof.sh: -DKNN_DBG=1 no exact scans, 2 seed cluster
-// only — WRONG results); the shipped library is compiled without it.
+// only, 4 the sweep's box tests without its vertex scans, 8 vertex scans whose prefilter never passes — WRONG results); the shipped
+// library is compiled without it.
 #ifndef KNN_DBG
 #define KNN_DBG 0
 #endif
@@ -764,7 +765,7 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w) 
             const float qd = q2 - mm * mm * 1.9073486328125e-06f;
             // (lanes that do not scan this part — decided cell, far, provably unflagged — never pass the prefilter: they used to keep a
             // top-4 of their own and pulled the wave into the insert branch for it)
-            float thr = scan ? t.worst() - qd : -__builtin_inff();
+            float thr = (scan && !(dbg & 8)) ? t.worst() - qd : -__builtin_inff();
 #pragma unroll 1
             for (int k = full ? 1 : 0; (seed_c + k < ncl || seed_c - k >= 0) && !(dbg & 2); ++k) {
 #pragma unroll 1
@@ -808,6 +809,7 @@ __global__ __launch_bounds__(KNN_T) void k_knn_pairs(RenderArgs a, Workspace w) 
                         const bool need_s = need && lb_s <= t.worst();
                         if (__ballot(need_s) == 0) continue;
                         KP_CNT(11)
+                        if (dbg & 4) continue;
                         scan_sub16_pf(sv + c * 64 + s4 * 16, rw + c * 32 + s4 * 8, ax2, ay2, az2, px2, py2, pz2, qd, thr, t KP_SCAN_PASS);
                     }
 #else
