@@ -415,7 +415,16 @@ def variant_lines(net, cfg, batches, dev, S, in_flight=1):
                 o = q.popleft()
                 _ = o['rgb_map'], o['acc_map']
             torch.cuda.synchronize()
-        sweep(3 * len(batches))
+        # warm until a whole sweep allocates nothing: lanes take their workspaces / raw buffers as the frames come (grow-only survivor
+        # bound, a second raw buffer while a caller still holds the lane's previous dict), and behind the variants above — 28 GB
+        # blocks given back to the driver — a multi-GB hipMalloc takes 0.1 - 0.5 s on this runtime: round 6's first line carried
+        # one of those in the timed sweep (13 ms per frame; tools/exp_api_order.py shows the steady state is reached in 2 - 3 sweeps)
+        for _warm in range(8):
+            before = torch.cuda.memory_reserved()
+            sweep(2 * len(batches))
+            if _warm >= 1 and torch.cuda.memory_reserved() == before:
+                break
+        api[key.replace('_ms', '_warm_sweeps')] = _warm + 1
         t0 = time.perf_counter()
         sweep(4 * len(batches))
         api[key] = (time.perf_counter() - t0) / (4 * len(batches)) * 1e3
