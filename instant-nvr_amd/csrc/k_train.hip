@@ -90,15 +90,14 @@ __global__ __launch_bounds__(TR_BLOCK) void k_train_terms(Workspace w, TrainWs t
 template <bool BWD> struct DeformActT { float feat[19]; float h1[32]; float h2[32]; float th[3]; float s1[BWD ? 32 : 1]; float s2[BWD ? 32 : 1]; };
 typedef DeformActT<false> DeformAct;
 
+// (the weights through any pointers: the MlpDev's global tensors, or a workgroup's LDS copy — same operations, same order)
 template <bool BWD>
-__device__ __forceinline__ void deform_fwd_act(const SceneDev& s, const GridDev& dg, const MlpDev& dm, const float* xb, float* uvt,
-                                               DeformActT<BWD>& a) {
+__device__ __forceinline__ void deform_fwd_act_w(const SceneDev& s, const GridDev& dg, const float* W0, const float* B0, const float* W1,
+                                                 const float* B1, const float* W2, const float* B2, const float* xb, float* uvt,
+                                                 DeformActT<BWD>& a) {
     sample_volume_dev<2>(s.tuv, 0, xb[0], xb[1], xb[2], uvt);
     uvt[2] = s.frame_dim[0];
     grid_encode_concat<8, 2>(dg, uvt, a.feat);
-    const float* __restrict__ W0 = dm.w[0]; const float* __restrict__ B0 = dm.b[0];
-    const float* __restrict__ W1 = dm.w[1]; const float* __restrict__ B1 = dm.b[1];
-    const float* __restrict__ W2 = dm.w[2]; const float* __restrict__ B2 = dm.b[2];
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
         float acc = B0[j];
@@ -106,6 +105,7 @@ __device__ __forceinline__ void deform_fwd_act(const SceneDev& s, const GridDev&
         for (int i = 0; i < 19; ++i) acc = fmaf(W0[j * 19 + i], a.feat[i], acc);
         a.h1[j] = softplus_f(acc);
         if (BWD) a.s1[j] = sigmoid_acc(acc);
+        if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);       // (keeps the weight loads of later neurons from being hoisted: registers)
     }
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
@@ -114,6 +114,7 @@ __device__ __forceinline__ void deform_fwd_act(const SceneDev& s, const GridDev&
         for (int i = 0; i < 32; ++i) acc = fmaf(W1[j * 32 + i], a.h1[i], acc);
         a.h2[j] = softplus_f(acc);
         if (BWD) a.s2[j] = sigmoid_acc(acc);
+        if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -123,17 +124,37 @@ __device__ __forceinline__ void deform_fwd_act(const SceneDev& s, const GridDev&
         a.th[j] = tanhf(acc);
     }
 }
+template <bool BWD>
+__device__ __forceinline__ void deform_fwd_act(const SceneDev& s, const GridDev& dg, const MlpDev& dm, const float* xb, float* uvt,
+                                               DeformActT<BWD>& a) {
+    deform_fwd_act_w<BWD>(s, dg, dm.w[0], dm.b[0], dm.w[1], dm.b[1], dm.w[2], dm.b[2], xb, uvt, a);
+}
 
 // neighbours of the selected rows through the deformer; pair term of crit.reg_raw_crit (crit.py:8-18):
 // || v_nb / (|v_nb| + 1e-8) - v_self / (|v_self| + 1e-8) ||, summed (the mean's divisor n stays on the device)
+// (round 6: the MLP's weights from an LDS copy, as k_deform_bwd — they were ~1100 wave-uniform vector loads per thread)
+#define PT_O_B0 (32 * 19)
+#define PT_O_W1 (PT_O_B0 + 32)
+#define PT_O_B1 (PT_O_W1 + 32 * 32)
+#define PT_O_W2 (PT_O_B1 + 32)
+#define PT_O_B2 (PT_O_W2 + 3 * 32)
 __global__ __launch_bounds__(128) void k_pair_term_fwd(SceneDev s, GridDev dg, MlpDev dm, Workspace w, TrainWs t) {
     __shared__ float red[TR_BLOCK / 64];
+    __shared__ __attribute__((aligned(16))) float lw[PT_O_B2 + 4];
     const int nsel = min(w.counters[CNT_NB], (int)t.NB);
     float acc = 0.0f;
+    if ((int)(blockIdx.x * blockDim.x) < nsel) {            // (block-uniform: workgroups without a row stage nothing)
+        for (int k = threadIdx.x; k < 32 * 19; k += blockDim.x) lw[k] = dm.w[0][k];
+        for (int k = threadIdx.x; k < 32 * 32; k += blockDim.x) lw[PT_O_W1 + k] = dm.w[1][k];
+        if (threadIdx.x < 96) lw[PT_O_W2 + threadIdx.x] = dm.w[2][threadIdx.x];
+        if (threadIdx.x < 32) { lw[PT_O_B0 + threadIdx.x] = dm.b[0][threadIdx.x]; lw[PT_O_B1 + threadIdx.x] = dm.b[1][threadIdx.x]; }
+        if (threadIdx.x < 3) lw[PT_O_B2 + threadIdx.x] = dm.b[2][threadIdx.x];
+    }
+    __syncthreads();
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nsel; k += gridDim.x * blockDim.x) {
         float xb[3] = {t.nb_x[(int64_t)k * 3], t.nb_x[(int64_t)k * 3 + 1], t.nb_x[(int64_t)k * 3 + 2]}, uvt[3];
         DeformAct a;
-        deform_fwd_act<false>(s, dg, dm, xb, uvt, a);
+        deform_fwd_act_w<false>(s, dg, lw, lw + PT_O_B0, lw + PT_O_W1, lw + PT_O_B1, lw + PT_O_W2, lw + PT_O_B2, xb, uvt, a);
         float vn[3], vs[3];
         const int ref = t.nb_ref[k], p = ref >> 28, i = ref & 0x0FFFFFFF;
 #pragma unroll
@@ -456,45 +477,88 @@ __global__ __launch_bounds__(256) void k_pair_term_bwd(Workspace w, TrainWs t, c
 // thread-per-entry backward of 0.05 tanh(MLP(grid(uv(x), t))): recomputes the forward, writes the per-layer (gz, a)
 // matrices for the weight-gradient GEMMs and (uvt, g_feat) for the grid backward.  Canonical points carry no gradient
 // (the warp is gradient-free in the reference, inb_part_network_multiassign.py:87-90).
-__global__ __launch_bounds__(128) void k_deform_bwd(SceneDev s, GridDev dg, MlpDev dm, Workspace w, TrainWs t) {
+// Round 6: the MLP's 1795 weights staged in LDS once per workgroup (they were 2200 wave-uniform VECTOR loads per thread: 1 KB of L1
+// traffic per 16 bytes of weights), 256 registers per thread instead of 128 + 151 spilled dwords, the row-major (gz, a) rows stored
+// as float4 (a lane's row is contiguous: 8 stores instead of 32 per 32-wide row).  Same operations in the same order: same bits.
+#define DB_BLOCK 256
+#define DB_O_W0 0                       // 32 x 19
+#define DB_O_B0 (DB_O_W0 + 32 * 19)
+#define DB_O_W1 (DB_O_B0 + 32)          // 32 x 32
+#define DB_O_B1 (DB_O_W1 + 32 * 32)
+#define DB_O_W2 (DB_O_B1 + 32)          // 3 x 32
+#define DB_O_B2 (DB_O_W2 + 3 * 32)
+#define DB_O_W0P (DB_O_B2 + 4)          // 32 x 20: W0 with rows padded to 20 (16-byte aligned rows for the W0^T product)
+#define DB_LDS (DB_O_W0P + 32 * 20)
+__device__ __forceinline__ void store_row4(float* dst, const float* v, int n4) {
+#pragma unroll
+    for (int k = 0; k < n4; ++k) reinterpret_cast<float4*>(dst)[k] = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+}
+__global__ __launch_bounds__(DB_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_deform_bwd(SceneDev s, GridDev dg, MlpDev dm, Workspace w, TrainWs t) {
+    __shared__ __attribute__((aligned(16))) float lw[DB_LDS];
     const int n = w.counters[CNT_DTOT];
-    const float* __restrict__ W0 = dm.w[0]; const float* __restrict__ W1 = dm.w[1]; const float* __restrict__ W2 = dm.w[2];
+    if ((int64_t)blockIdx.x * DB_BLOCK >= n) return;
+    for (int k = threadIdx.x; k < 32 * 19; k += DB_BLOCK) lw[DB_O_W0 + k] = dm.w[0][k];
+    for (int k = threadIdx.x; k < 32 * 20; k += DB_BLOCK) lw[DB_O_W0P + k] = (k % 20) < 19 ? dm.w[0][(k / 20) * 19 + k % 20] : 0.0f;
+    for (int k = threadIdx.x; k < 32 * 32; k += DB_BLOCK) lw[DB_O_W1 + k] = dm.w[1][k];
+    if (threadIdx.x < 96) lw[DB_O_W2 + threadIdx.x] = dm.w[2][threadIdx.x];
+    if (threadIdx.x < 32) { lw[DB_O_B0 + threadIdx.x] = dm.b[0][threadIdx.x]; lw[DB_O_B1 + threadIdx.x] = dm.b[1][threadIdx.x]; }
+    if (threadIdx.x < 3) lw[DB_O_B2 + threadIdx.x] = dm.b[2][threadIdx.x];
+    __syncthreads();
+    const float* W0 = lw + DB_O_W0; const float* W1 = lw + DB_O_W1; const float* W2 = lw + DB_O_W2;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
         float xb[3] = {t.d_pts[(int64_t)e * 3], t.d_pts[(int64_t)e * 3 + 1], t.d_pts[(int64_t)e * 3 + 2]}, uvt[3];
         DeformActT<true> a;
-        deform_fwd_act<true>(s, dg, dm, xb, uvt, a);
-        float gz3[3];
+        deform_fwd_act_w<true>(s, dg, W0, lw + DB_O_B0, W1, lw + DB_O_B1, W2, lw + DB_O_B2, xb, uvt, a);
+        float gz3[4];
 #pragma unroll
         for (int c = 0; c < 3; ++c) gz3[c] = t.d_g[(int64_t)e * 3 + c] * 0.05f * (1.0f - a.th[c] * a.th[c]);
-        float* q3 = t.d_gz3 + (int64_t)e * 4;
-        q3[0] = gz3[0]; q3[1] = gz3[1]; q3[2] = gz3[2]; q3[3] = 0.0f;
+        gz3[3] = 0.0f;
+        store_row4(t.d_gz3 + (int64_t)e * 4, gz3, 1);
         float gz2[32];
 #pragma unroll
         for (int j = 0; j < 32; ++j) {
             const float gh = W2[j] * gz3[0] + W2[32 + j] * gz3[1] + W2[64 + j] * gz3[2];
             gz2[j] = gh * a.s2[j];                                               // softplus'(z) = sigmoid(z)
-            t.d_gz2[(int64_t)e * 32 + j] = gz2[j];
-            t.d_a2[(int64_t)e * 32 + j] = a.h2[j];
         }
+        store_row4(t.d_gz2 + (int64_t)e * 32, gz2, 8);
+        store_row4(t.d_a2 + (int64_t)e * 32, a.h2, 8);
+        store_row4(t.d_a1 + (int64_t)e * 32, a.h1, 8);
+        // W^T products four outputs at a time: one 16-byte LDS read W[j][4 ib .. 4 ib + 3] feeds four accumulators (every accumulator
+        // still sums over j ascending: the element-by-element form's bits)
         float gz1[32];
 #pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            float gh = 0.0f;
+        for (int ib = 0; ib < 8; ++ib) {
+            float gh[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-            for (int j = 0; j < 32; ++j) gh = fmaf(W1[j * 32 + i], gz2[j], gh);
-            gz1[i] = gh * a.s1[i];
-            t.d_gz1[(int64_t)e * 32 + i] = gz1[i];
-            t.d_a1[(int64_t)e * 32 + i] = a.h1[i];
+            for (int j = 0; j < 32; ++j) {
+                const float4 wv = *reinterpret_cast<const float4*>(W1 + j * 32 + 4 * ib);
+                gh[0] = fmaf(wv.x, gz2[j], gh[0]); gh[1] = fmaf(wv.y, gz2[j], gh[1]);
+                gh[2] = fmaf(wv.z, gz2[j], gh[2]); gh[3] = fmaf(wv.w, gz2[j], gh[3]);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) gz1[4 * ib + q] = gh[q] * a.s1[4 * ib + q];
+            __builtin_amdgcn_sched_barrier(0);
         }
+        store_row4(t.d_gz1 + (int64_t)e * 32, gz1, 8);
+        float a0[20];
 #pragma unroll
-        for (int i = 0; i < 19; ++i) {
-            float gf = 0.0f;
+        for (int i = 0; i < 19; ++i) a0[i] = a.feat[i];
+        a0[19] = 0.0f;
+        store_row4(t.d_a0 + (int64_t)e * 20, a0, 5);
 #pragma unroll
-            for (int j = 0; j < 32; ++j) gf = fmaf(W0[j * 19 + i], gz1[j], gf);
-            t.d_gfeat[(int64_t)e * 19 + i] = gf;
-            t.d_a0[(int64_t)e * 20 + i] = a.feat[i];
+        for (int ib = 0; ib < 5; ++ib) {
+            float gf[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                const float4 wv = *reinterpret_cast<const float4*>(lw + DB_O_W0P + j * 20 + 4 * ib);      // (padded rows: column 19 = 0)
+                gf[0] = fmaf(wv.x, gz1[j], gf[0]); gf[1] = fmaf(wv.y, gz1[j], gf[1]);
+                gf[2] = fmaf(wv.z, gz1[j], gf[2]); gf[3] = fmaf(wv.w, gz1[j], gf[3]);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (4 * ib + q < 19) t.d_gfeat[(int64_t)e * 19 + 4 * ib + q] = gf[q];
+            __builtin_amdgcn_sched_barrier(0);
         }
-        t.d_a0[(int64_t)e * 20 + 19] = 0.0f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) t.d_uvt[(int64_t)e * 3 + c] = uvt[c];
     }
@@ -509,8 +573,8 @@ int launch_deform_bwd(const RenderArgs& a, const Workspace& w, const TrainWs& t,
     INVR_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_pair_term_bwd, dim3(256), dim3(256), 0, st, w, t, g_pair_sum);
     INVR_LAUNCH_CHECK();
-    int64_t et = cdiv(t.DM, 128);
-    hipLaunchKernelGGL(k_deform_bwd, dim3((unsigned)(et < 2048 ? (et > 0 ? et : 1) : 2048)), dim3(128), 0, st, a.scene, dg, dm, w, t);
+    int64_t et = cdiv(t.DM, DB_BLOCK);
+    hipLaunchKernelGGL(k_deform_bwd, dim3((unsigned)(et < 2048 ? (et > 0 ? et : 1) : 2048)), dim3(DB_BLOCK), 0, st, a.scene, dg, dm, w, t);
     INVR_LAUNCH_CHECK();
     WgradJobs jobs;
     memset(&jobs, 0, sizeof(jobs));
