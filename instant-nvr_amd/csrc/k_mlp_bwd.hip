@@ -22,6 +22,23 @@
 // The rgb1 input is stored in k-slot order (column 4 s + g, rgb1_col in mlp_common.h).  g_latent (8) is accumulated
 // with atomics (pre-zeroed by the caller).
 
+// Phase timers (profiling builds only, -DMLPB_PROF: tools/exp_mlpb_prof.py; not part of libinvr.so)
+#ifdef MLPB_PROF
+__device__ unsigned long long g_mlpb_prof[16];
+extern "C" int invr_debug_mlpb_prof(unsigned long long* out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mlpb_prof), sizeof(g_mlpb_prof)) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_mlpb_prof), z, sizeof(z)) != hipSuccess) return 1; }
+    return 0;
+}
+#define MP_DECL long long mp_t0 = clock64(); long long mp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define MP(i) { const long long mp_now = clock64(); mp_acc[i] += mp_now - mp_t0; mp_t0 = mp_now; }
+#define MP_FLUSH if ((threadIdx.x & 63) == 0) { for (int mp_i = 0; mp_i < 8; ++mp_i) atomicAdd(&g_mlpb_prof[mp_i], (unsigned long long)mp_acc[mp_i]); atomicAdd(&g_mlpb_prof[8], 1ull); }
+#else
+#define MP_DECL
+#define MP(i)
+#define MP_FLUSH
+#endif
+
 __device__ __forceinline__ f32x4 dsoftplus4(f32x4 gin, f32x4 act) {    // softplus'(z) = sigmoid(z) = 1 - exp(-softplus(z))
     f32x4 r;
 #pragma unroll
@@ -41,8 +58,10 @@ __global__ __launch_bounds__(MLP_BLOCK, 1) void k_part_mlp_bwd(PartMlpDev pm, co
     const int64_t n = count ? (int64_t)*count : n_host;
     __shared__ float lds[LDS_FLOATS];
     if ((int64_t)blockIdx.x * ((MLP_BLOCK / 64) * 16) >= n) return;       // (the grid is sized from an upper bound: no staging for nothing)
+    MP_DECL
     stage_weights<NRGB>(pm, lds);
     __syncthreads();
+    MP(0)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, col = lane & 15;
     const int i = col;                                       // as the row index of A operands
     const float* lat = pm.rgb_latent + pm.latent_index[0] * pm.latent_dim;
@@ -59,6 +78,7 @@ __global__ __launch_bounds__(MLP_BLOCK, 1) void k_part_mlp_bwd(PartMlpDev pm, co
     for (int64_t t0 = (int64_t)blockIdx.x * per_block + (int64_t)wv * 16; t0 < n; t0 += (int64_t)gridDim.x * per_block) {
         const int64_t pair = min(t0 + col, n - 1);
         const bool live = t0 + col < n;
+        MP(7)
         // ---------------- forward recompute (k_part_mlp, one column block) ----------------
         float eb[EMB_STEPS], dv[3];
 #pragma unroll
@@ -68,6 +88,10 @@ __global__ __launch_bounds__(MLP_BLOCK, 1) void k_part_mlp_bwd(PartMlpDev pm, co
         f32x4 h1[4];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) h1[mt] = bias4(lds + O_B_OCC1, mt, g);
+#ifdef MLPB_PROF
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        MP(1)
 #pragma unroll
         for (int s = 0; s < EMB_STEPS; ++s)
 #pragma unroll
@@ -128,6 +152,7 @@ __global__ __launch_bounds__(MLP_BLOCK, 1) void k_part_mlp_bwd(PartMlpDev pm, co
 #pragma unroll
         for (int c = 0; c < 3; ++c) rgb[c] = sigmoid_f(head_dot(hl, lds + O_V_OUT + c * 64, g) + lds[O_V_OUT + 3 * 64 + c]);
 
+        MP(2)
         // ---------------- backward ----------------
         const float4 gr = live ? (l_slot ? g_raw[(int64_t)l_slot[pair] * INVR_NUM_PARTS + part] : g_raw[pair]) : make_float4(0.f, 0.f, 0.f, 0.f);
         float go[3] = {gr.x * rgb[0] * (1.0f - rgb[0]), gr.y * rgb[1] * (1.0f - rgb[1]), gr.z * rgb[2] * (1.0f - rgb[2])};
@@ -174,6 +199,7 @@ __global__ __launch_bounds__(MLP_BLOCK, 1) void k_part_mlp_bwd(PartMlpDev pm, co
                 }
             }
         }
+        MP(3)
         // rgb1^T: embedding slots (2 tiles, row 4g+r of tile mi <-> k-slot (s = 4 mi + r, g)), feature tile (row = feature
         // index), latent tile (row = latent index)
         f32x4 ge[2], gfeat = {0.f, 0.f, 0.f, 0.f}, glat = {0.f, 0.f, 0.f, 0.f};
@@ -228,6 +254,7 @@ __global__ __launch_bounds__(MLP_BLOCK, 1) void k_part_mlp_bwd(PartMlpDev pm, co
             for (int s = 0; s < EMB_STEPS; ++s)
                 if (4 * s + g < 19) o.g_emb[(int64_t)(4 * s + g) * stride + pair] = ge[s >> 2][s & 3];
         }
+        MP(4)
     }
     // latent-code gradient: rows 4g+r (< 8) of the latent tile, summed over this wave's pairs and the 16 columns
 #pragma unroll
@@ -237,6 +264,8 @@ __global__ __launch_bounds__(MLP_BLOCK, 1) void k_part_mlp_bwd(PartMlpDev pm, co
         for (int d = 1; d < 16; d <<= 1) v += __shfl_xor(v, d);
         if (col == 0 && g < 2) atomicAdd(o.g_latent + (o.latent_full ? pm.latent_index[0] * pm.latent_dim : 0) + 4 * g + r, v);
     }
+    MP(5)
+    MP_FLUSH
 }
 
 #undef G
