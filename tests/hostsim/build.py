@@ -45,12 +45,12 @@ REWRITES = [
 
 def strip_experiments(text):
     """Drop the device-only experiment regions of a source (`#if WARP_EXP ...` with its `#else` branch kept, `#ifdef WARP_VERIFY`,
-    `#if defined(WARP_VERIFY) ...`): debug kernels of investigation builds that read hardware registers; the host build is the product's."""
+    `#if defined(WARP_VERIFY) ...`, `#ifdef MLPB_PROF`): debug kernels of investigation builds that read hardware registers; the host build is the product's."""
     out, stack = [], []          # stack entries: [is_experiment, keep_now]
     for line in text.split('\n'):
         t = line.strip()
         if t.startswith('#if'):
-            exp = ('WARP_EXP' in t or 'WARP_VERIFY' in t) and not t.startswith('#ifndef')
+            exp = ('WARP_EXP' in t or 'WARP_VERIFY' in t or 'MLPB_PROF' in t) and not t.startswith('#ifndef')
             stack.append([exp, not exp])
             if exp:
                 continue
