@@ -162,12 +162,12 @@ def train_probe(net, dev, S, iters, fused=None):
     opt = driver.make_optimizer(net, fused=fused)
     opt_name = '%s.%s' % (type(opt).__module__, type(opt).__name__)
     adopted = lambda: getattr(opt, '_invr_inner', None) is not None
-    for i in range(4):
+    for i in range(8):                   # (plan build, arena, allocator and clocks settled: the probe runs behind the eval variants)
         driver.train_step(wrap, opt, batch, i + 2)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(iters):
-        loss, _ = driver.train_step(wrap, opt, batch, i + 6)
+        loss, _ = driver.train_step(wrap, opt, batch, i + 10)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / iters
     # where the iteration goes: forward / backward / optimizer step, synchronised (3 extra iterations)
@@ -600,7 +600,7 @@ def main():
     ap.add_argument('--min-time', type=float, default=1.0, help='repeat the timed K-step region until this many seconds are timed in total')
     ap.add_argument('--full-rows', action='store_true', help='read the trainable 64-byte table rows instead of the eval-mode row-sum tables')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--train-iters', type=int, default=10, help='iterations of the informational training-step probe (0 = skip; N=1 only)')
+    ap.add_argument('--train-iters', type=int, default=30, help='iterations of the informational training-step probe (0 = skip; N=1 only)')
     ap.add_argument('--no-graph', action='store_true', help='launch the ~25 kernels of a frame eagerly instead of replaying one captured hipGraph')
     ap.add_argument('--in-flight', type=int, default=10, help='frames of the sequence rendered side by side by one hipGraph replay (invr.frames); reduced to a divisor of --steps; 1 = strictly one frame at a time')
     ap.add_argument('--no-variants', action='store_true', help='skip the S=64 / dense / full-row / shard-projection / API-frame variants of the default line')
