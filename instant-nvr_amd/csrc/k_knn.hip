@@ -481,9 +481,7 @@ __device__ __forceinline__ void scan_sub16_pf(const float4* sv, const unsigned* 
 // 1024-thread workgroups (one per CU, 4 waves/SIMD); every vertex / cluster record is then a
 // wave-uniform (broadcast) ds_read_b128.  (The scalar-cache path was tried first: with a working set
 // of ~7x the 16 KB scalar cache its miss path throttled the kernel to ~30 % VALU utilisation.)
-#ifndef KNN_T
 #define KNN_T 1024
-#endif
 #define KNN_LDS_MAX_V 7680          // float4 vertex slots (123 KB) + 2 bytes of row per slot + 11 record float4 per cluster must fit 160 KB
 
 #define KNN_LDS_HDR 8               // float4: the LDS carve table (offsets / lengths of the five parts)
