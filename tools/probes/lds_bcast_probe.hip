@@ -30,11 +30,17 @@ __global__ __launch_bounds__(1024) void k(float* out, long long* cyc, int stride
 }
 template <int KIND> void run(const char* name, float* out, long long* cyc) {
     for (int threads : {256, 512, 1024}) {
+        hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        hipLaunchKernelGGL(k<KIND>, dim3(256), dim3(threads), 65536, 0, out, cyc, 2);      // warm
+        (void)hipEventRecord(e0, 0);
         hipLaunchKernelGGL(k<KIND>, dim3(256), dim3(threads), 65536, 0, out, cyc, 2);
+        (void)hipEventRecord(e1, 0);
         (void)hipDeviceSynchronize();
-        long long c; (void)hipMemcpy(&c, cyc, sizeof(c), hipMemcpyDeviceToHost);
-        const double per_wave = (double)c / (ITERS * 8.0), waves = threads / 64.0;
-        printf("%-34s %2d waves/CU: %7.2f ticks per read per wave = %6.2f CU ticks per wave-instruction\n", name, threads / 64, per_wave, per_wave / waves);
+        float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+        const double waves = threads / 64.0, reads = ITERS * 8.0;
+        // wall clock (clock64 of one wave is biased: the oldest wave keeps its slots): ns of CU time per wave-instruction
+        printf("%-34s %2d waves/CU: wall %8.1f us = %6.2f ns of CU time per wave-instruction (%5.1f ns per read per wave)\n", name, threads / 64,
+               ms * 1e3, ms * 1e6 / (reads * waves), ms * 1e6 / reads);
     }
 }
 int main() {

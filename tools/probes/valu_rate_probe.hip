@@ -79,11 +79,18 @@ __global__ __launch_bounds__(1024) void k(float* out, long long* cyc, float seed
 
 template <int KIND> void run(const char* name, float* out, long long* cyc, int per_issue) {
     for (int threads : {256, 1024}) {               // 1 and 4 waves per SIMD (one workgroup per CU: 304 >= CUs workgroups would queue; 256 = one each)
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        hipLaunchKernelGGL(k<KIND>, dim3(256), dim3(threads), 0, 0, out, cyc, 1.0f);      // warm
+        hipEventRecord(e0, 0);
         hipLaunchKernelGGL(k<KIND>, dim3(256), dim3(threads), 0, 0, out, cyc, 1.0f);
+        hipEventRecord(e1, 0);
         hipDeviceSynchronize();
+        float ms = 0; hipEventElapsedTime(&ms, e0, e1);
         long long c; hipMemcpy(&c, cyc, sizeof(c), hipMemcpyDeviceToHost);
         const double n = (double)ITERS * 32 * per_issue;
-        printf("%-28s %d waves/SIMD: %6.2f cycles per instruction per wave  (%5.2f SIMD cycles per instruction)\n", name, threads / 256, c / n, c / n / (threads / 256));
+        // wall clock: n instructions per wave, threads / 256 waves per SIMD -> ns of SIMD time per instruction
+        printf("%-28s %d waves/SIMD: %6.2f clock64 ticks per instruction per wave (%5.2f per SIMD); wall %8.1f us = %5.2f ns of SIMD time per instruction\n",
+               name, threads / 256, c / n, c / n / (threads / 256), ms * 1e3, ms * 1e6 / (n * (threads / 256)));
     }
 }
 int main() {
