@@ -82,6 +82,19 @@ def main():
             perm = np.argsort(key, kind='stable')
             _, prof, _ = run(perm)
             report('tile %d rays x window %d samples' % (R, D), prof, perm)
+        # 2-D pixel tiles (round 6): rays grouped by TW x TH pixel tiles of the image (the rays of a frame are the True pixels of
+        # batch['mask_at_box'] in row-major order), inside a tile by depth windows of D samples, inside a window pixel-major
+        if os.environ.get('KNN_TILES2D'):
+            mask = np.asarray(bnp['mask_at_box']).reshape(RES, RES)
+            py, px = np.nonzero(mask)
+            assert py.shape[0] == ro.shape[0]
+            for TW, TH, D in [tuple(int(v) for v in a.split('x')) for a in os.environ['KNN_TILES2D'].split(',')]:
+                ty, tx = py[ray] // TH, px[ray] // TW
+                inner = (py[ray] % TH) * TW + (px[ray] % TW)
+                key = ((ty * 4096 + tx) * (S // D + 1) + smp // D) * (TW * TH * S) + inner * S + smp
+                perm = np.argsort(key, kind='stable')
+                _, prof, _ = run(perm)
+                report('2-D tile %dx%d px x window %d' % (TW, TH, D), prof, perm)
         if os.environ.get('KNN_ORDERS'):
             return
         lo = pts.min(0)
